@@ -1,0 +1,367 @@
+/*
+ * cz_oracle.c -- CPU restatement of the CubeZ hot-path grid kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle for the HIP path:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The product (cubez_amd/) never links, imports or calls it.
+ *
+ * Every function restates one Fortran subroutine of the reference
+ * (/root/reference/src/cz_f90) with the same argument list, the same
+ * operation order and the same floating-point association, so that -- built
+ * without FP contraction and run with one thread -- its outputs are bit-for-bit
+ * those of the reference (checked by tests/test_oracle_vs_ref.py against
+ * oracle/_ref, the reference's own Fortran compiled with amdflang, and against
+ * the fixtures in tests/golden/ that were generated from it).
+ *
+ * Parity status: PINNED (oracle/_ref + tests/golden).
+ *
+ * Layout (cz_solver.f90:29): every 3-D array is
+ *   real p(1-g:sz(3)+g, 1-g:sz(1)+g, 1-g:sz(2)+g)      -- K fastest, then I, then J
+ * sz = (NI, NJ, NK) without guide cells, g = guide width (2 in the reference).
+ *
+ * Precision is a compile-time switch exactly as in the reference
+ * (cz_Define.h:28-37): -DCZ_REAL_IS_DOUBLE builds the FP64 variant.
+ *
+ * Extra output not in the reference: the *_w entry points additionally return
+ * the residual / dot accumulated in double over the SAME per-point terms
+ * (each term still rounded to REAL first).  The reference accumulates in REAL
+ * sequentially (cz_solver.f90:294,348,384); that value moves with summation
+ * order (SURVEY.md finding 3), so GPU-vs-oracle residual parity is stated on
+ * the wide accumulation while the REAL one pins the oracle to the reference.
+ */
+#include <math.h>
+#include <stddef.h>
+
+#ifdef CZ_REAL_IS_DOUBLE
+typedef double REAL;
+#define R_SIN sin
+#define R_ASIN asin
+#else
+typedef float REAL;
+#define R_SIN sinf
+#define R_ASIN asinf
+#endif
+
+/* 1-based (k,i,j) -> linear index, lower bound 1-g on every axis */
+#define IDX(k, i, j) ((size_t)((k) + g - 1) + (size_t)((i) + g - 1) * nk + (size_t)((j) + g - 1) * nk * ni)
+
+#define UNPACK_SZ                          \
+  const int g = *gp;                       \
+  const size_t nk = (size_t)(sz[2] + 2 * g); \
+  const size_t ni = (size_t)(sz[0] + 2 * g); \
+  (void)ni
+
+#define UNPACK_IDX                                   \
+  const int ist = idx[0], ied = idx[1];              \
+  const int jst = idx[2], jed = idx[3];              \
+  const int kst = idx[4], ked = idx[5]
+
+#define NPTS ((double)(ied - ist + 1) * (double)(jed - jst + 1) * (double)(ked - kst + 1))
+
+int oracle_real_bytes(void) { return (int)sizeof(REAL); }
+
+/* ---- bc_k : cz_solver.f90:22-191 ------------------------------------------------
+ * Dirichlet faces where nID(face) < 0.  K faces first (sin*sin), then I faces,
+ * then J faces (zero) -- so edges end up 0.  nID order: I-,I+,J-,J+,K-,K+
+ * (cz_fparam.fi:10-16). */
+void oracle_bc_k(const int* sz, const int* gp, REAL* p, const REAL* dh_p, const REAL* org, const int* nID) {
+  UNPACK_SZ;
+  const int ix = sz[0], jx = sz[1], kx = sz[2];
+  const REAL dh = *dh_p;
+  const REAL pi = (REAL)2.0 * R_ASIN((REAL)1.0); /* :36 */
+  if (nID[4] < 0) {                              /* K_MINUS :41-64 */
+    for (int j = 1; j <= jx; j++)
+      for (int i = 1; i <= ix; i++) {
+        REAL x = org[0] + dh * (REAL)(i - 1);
+        REAL y = org[1] + dh * (REAL)(j - 1);
+        p[IDX(1, i, j)] = R_SIN(pi * x) * R_SIN(pi * y);
+      }
+  }
+  if (nID[5] < 0) { /* K_PLUS :67-90 */
+    for (int j = 1; j <= jx; j++)
+      for (int i = 1; i <= ix; i++) {
+        REAL x = org[0] + dh * (REAL)(i - 1);
+        REAL y = org[1] + dh * (REAL)(j - 1);
+        p[IDX(kx, i, j)] = R_SIN(pi * x) * R_SIN(pi * y);
+      }
+  }
+  if (nID[0] < 0) /* I_MINUS :93-113 */
+    for (int k = 1; k <= kx; k++)
+      for (int j = 1; j <= jx; j++) p[IDX(k, 1, j)] = (REAL)0.0;
+  if (nID[1] < 0) /* I_PLUS :116-137 */
+    for (int k = 1; k <= kx; k++)
+      for (int j = 1; j <= jx; j++) p[IDX(k, ix, j)] = (REAL)0.0;
+  if (nID[2] < 0) /* J_MINUS :140-161 */
+    for (int k = 1; k <= kx; k++)
+      for (int i = 1; i <= ix; i++) p[IDX(k, i, 1)] = (REAL)0.0;
+  if (nID[3] < 0) /* J_PLUS :164-185 */
+    for (int k = 1; k <= kx; k++)
+      for (int i = 1; i <= ix; i++) p[IDX(k, i, jx)] = (REAL)0.0;
+}
+
+/* ---- jacobi : cz_solver.f90:284-387 ---------------------------------------------
+ * wk2 = p + ((ss-b)/dd - p)*omg on the inner box, res1 += dp*dp (REAL), then
+ * p <- wk2 on the inner box, res += dble(res1), flop += 18*npts. */
+void oracle_jacobi_w(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* cf, const REAL* omg_p,
+                     const REAL* b, double* res, REAL* wk2, double* flop, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL c1 = cf[0], c2 = cf[1], c3 = cf[2], c4 = cf[3], c5 = cf[4], c6 = cf[5], dd = cf[6];
+  const REAL omg = *omg_p;
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  *flop += 18.0 * NPTS; /* :315-318 */
+#pragma omp parallel
+  {
+#pragma omp for schedule(static) collapse(2) reduction(+ : res1, resw)
+    for (int j = jst; j <= jed; j++)
+      for (int i = ist; i <= ied; i++)
+        for (int k = kst; k <= ked; k++) { /* :334-351 */
+          REAL pp = p[IDX(k, i, j)];
+          REAL bb = b[IDX(k, i, j)];
+          REAL ss = c1 * p[IDX(k, i + 1, j)] + c2 * p[IDX(k, i - 1, j)] + c3 * p[IDX(k, i, j + 1)] +
+                    c4 * p[IDX(k, i, j - 1)] + c5 * p[IDX(k + 1, i, j)] + c6 * p[IDX(k - 1, i, j)];
+          REAL dp = ((ss - bb) / dd - pp) * omg;
+          REAL pn = pp + dp;
+          wk2[IDX(k, i, j)] = pn;
+          REAL d2 = dp * dp;
+          res1 = res1 + d2;
+          resw += (double)d2;
+        }
+    /* The reference has END DO NOWAIT here (:355), i.e. a data race with >1 thread
+     * (SURVEY.md finding 2).  The oracle keeps the implicit barrier: it is the
+     * single-thread semantics that are the contract. */
+#pragma omp for schedule(static) collapse(2)
+    for (int j = jst; j <= jed; j++)
+      for (int i = ist; i <= ied; i++)
+        for (int k = kst; k <= ked; k++) p[IDX(k, i, j)] = wk2[IDX(k, i, j)]; /* :369-375 */
+  }
+  *res = *res + (double)res1; /* :384 */
+  if (res_wide) *res_wide += resw;
+}
+
+void oracle_jacobi(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* cf, const REAL* omg,
+                   const REAL* b, double* res, REAL* wk2, double* flop) {
+  oracle_jacobi_w(p, sz, idx, gp, cf, omg, b, res, wk2, flop, NULL);
+}
+
+/* ---- psor2sma_core : cz_solver.f90:404-493 --------------------------------------
+ * in-place update of the points k = kst+mod(i+j+ofst+color,2), ked, 2 (:419,466). */
+void oracle_psor2sma_core_w(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* cf,
+                            const int* ofst, const int* color, const REAL* omg_p, const REAL* b, double* res,
+                            double* flop, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const int kp = *ofst + *color;
+  const REAL c1 = cf[0], c2 = cf[1], c3 = cf[2], c4 = cf[3], c5 = cf[4], c6 = cf[5], dd = cf[6];
+  const REAL omg = *omg_p;
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  *flop += 18.0 * 0.5 * NPTS; /* :438-441 */
+#pragma omp parallel for schedule(static) collapse(2) reduction(+ : res1, resw)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst + ((i + j + kp) % 2); k <= ked; k += 2) { /* :466 */
+        REAL pp = p[IDX(k, i, j)];
+        REAL bb = b[IDX(k, i, j)];
+        REAL ss = c1 * p[IDX(k, i + 1, j)] + c2 * p[IDX(k, i - 1, j)] + c3 * p[IDX(k, i, j + 1)] +
+                  c4 * p[IDX(k, i, j - 1)] + c5 * p[IDX(k + 1, i, j)] + c6 * p[IDX(k - 1, i, j)];
+        REAL dp = ((ss - bb) / dd - pp) * omg;
+        REAL pn = pp + dp;
+        p[IDX(k, i, j)] = pn;
+        REAL d2 = dp * dp;
+        res1 = res1 + d2;
+        resw += (double)d2;
+      }
+  *res = *res + (double)res1; /* :490 */
+  if (res_wide) *res_wide += resw;
+}
+
+void oracle_psor2sma_core(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* cf, const int* ofst,
+                          const int* color, const REAL* omg, const REAL* b, double* res, double* flop) {
+  oracle_psor2sma_core_w(p, sz, idx, gp, cf, ofst, color, omg, b, res, flop, NULL);
+}
+
+/* ---- blas_clear / blas_copy : cz_blas.f90:112-149 / 159-195 (full array incl. guide cells) */
+void oracle_blas_clear(REAL* x, const int* sz, const int* gp) {
+  const int g = *gp;
+  const size_t n = (size_t)(sz[0] + 2 * g) * (size_t)(sz[1] + 2 * g) * (size_t)(sz[2] + 2 * g);
+  for (size_t m = 0; m < n; m++) x[m] = (REAL)0.0;
+}
+
+void oracle_blas_copy(REAL* y, const REAL* x, const int* sz, const int* gp) {
+  const int g = *gp;
+  const size_t n = (size_t)(sz[0] + 2 * g) * (size_t)(sz[1] + 2 * g) * (size_t)(sz[2] + 2 * g);
+  for (size_t m = 0; m < n; m++) y[m] = x[m];
+}
+
+/* ---- blas_triad : cz_blas.f90:255-308   z = a*x + y */
+void oracle_blas_triad(REAL* z, const REAL* x, const REAL* y, const REAL* a_p, const int* sz, const int* idx,
+                       const int* gp, double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL a = *a_p;
+  *flop += 2.0 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) z[IDX(k, i, j)] = a * x[IDX(k, i, j)] + y[IDX(k, i, j)]; /* :297 */
+}
+
+/* ---- blas_dot1 : cz_blas.f90:320-373   r = sum p*p (REAL accumulator, overwritten) */
+void oracle_blas_dot1_w(REAL* r, const REAL* p, const int* sz, const int* idx, const int* gp, double* flop,
+                        double* r_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  REAL acc = (REAL)0.0;
+  double accw = 0.0;
+  *flop += 2.0 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2) reduction(+ : acc, accw)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        REAL q = p[IDX(k, i, j)];
+        REAL t = q * q;
+        acc = acc + t; /* :361-362 */
+        accw += (double)t;
+      }
+  *r = acc;
+  if (r_wide) *r_wide = accw;
+}
+
+void oracle_blas_dot1(REAL* r, const REAL* p, const int* sz, const int* idx, const int* gp, double* flop) {
+  oracle_blas_dot1_w(r, p, sz, idx, gp, flop, NULL);
+}
+
+/* ---- blas_dot2 : cz_blas.f90:386-437   r = sum p*q */
+void oracle_blas_dot2_w(REAL* r, const REAL* p, const REAL* q, const int* sz, const int* idx, const int* gp,
+                        double* flop, double* r_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  REAL acc = (REAL)0.0;
+  double accw = 0.0;
+  *flop += 2.0 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2) reduction(+ : acc, accw)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        REAL t = p[IDX(k, i, j)] * q[IDX(k, i, j)];
+        acc = acc + t; /* :426 */
+        accw += (double)t;
+      }
+  *r = acc;
+  if (r_wide) *r_wide = accw;
+}
+
+void oracle_blas_dot2(REAL* r, const REAL* p, const REAL* q, const int* sz, const int* idx, const int* gp,
+                      double* flop) {
+  oracle_blas_dot2_w(r, p, q, sz, idx, gp, flop, NULL);
+}
+
+/* ---- blas_bicg_1 : cz_blas.f90:452-502   p = r + beta*(p - omg*q) */
+void oracle_blas_bicg_1(REAL* p, const REAL* r, const REAL* q, const REAL* beta_p, const REAL* omg_p,
+                        const int* sz, const int* idx, const int* gp, double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL beta = *beta_p, omg = *omg_p;
+  *flop += 4.0 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++)
+        p[IDX(k, i, j)] = r[IDX(k, i, j)] + beta * (p[IDX(k, i, j)] - omg * q[IDX(k, i, j)]); /* :490 */
+}
+
+/* ---- blas_bicg_2 : cz_blas.f90:517-566   z = a*x + b*y + z */
+void oracle_blas_bicg_2(REAL* z, const REAL* x, const REAL* y, const REAL* a_p, const REAL* b_p, const int* sz,
+                        const int* idx, const int* gp, double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL a = *a_p, b = *b_p;
+  *flop += 4.0 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++)
+        z[IDX(k, i, j)] = a * x[IDX(k, i, j)] + b * y[IDX(k, i, j)] + z[IDX(k, i, j)]; /* :554 */
+}
+
+/* ---- blas_calc_ax : cz_blas.f90:579-644   ap = ss - dd*p */
+void oracle_blas_calc_ax(REAL* ap, const REAL* p, const int* sz, const int* idx, const int* gp, const REAL* cf,
+                         double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL c1 = cf[0], c2 = cf[1], c3 = cf[2], c4 = cf[3], c5 = cf[4], c6 = cf[5], dd = cf[6];
+  *flop += 13.0 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        REAL ss = c1 * p[IDX(k, i + 1, j)] + c2 * p[IDX(k, i - 1, j)] + c3 * p[IDX(k, i, j + 1)] +
+                  c4 * p[IDX(k, i, j - 1)] + c5 * p[IDX(k + 1, i, j)] + c6 * p[IDX(k - 1, i, j)];
+        ap[IDX(k, i, j)] = (ss - dd * p[IDX(k, i, j)]); /* :626-632 */
+      }
+}
+
+/* ---- blas_calc_rk : cz_blas.f90:658-723   r = b - (ss - dd*p) */
+void oracle_blas_calc_rk(REAL* r, const REAL* p, const REAL* b, const int* sz, const int* idx, const int* gp,
+                         const REAL* cf, double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL c1 = cf[0], c2 = cf[1], c3 = cf[2], c4 = cf[3], c5 = cf[4], c6 = cf[5], dd = cf[6];
+  *flop += 14.0 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        REAL ss = c1 * p[IDX(k, i + 1, j)] + c2 * p[IDX(k, i - 1, j)] + c3 * p[IDX(k, i, j + 1)] +
+                  c4 * p[IDX(k, i, j - 1)] + c5 * p[IDX(k + 1, i, j)] + c6 * p[IDX(k - 1, i, j)];
+        r[IDX(k, i, j)] = (b[IDX(k, i, j)] - (ss - dd * p[IDX(k, i, j)])); /* :705-711 */
+      }
+}
+
+/* ---- exact_t / err_t : cz_utility.f90:52-82 / 86-129 (the reference's only known-answer check) */
+void oracle_exact_t(const int* sz, const int* gp, REAL* e, const REAL* dh_p, const REAL* org) {
+  UNPACK_SZ;
+  const int ix = sz[0], jx = sz[1], kx = sz[2];
+  const REAL dh = *dh_p;
+#ifdef CZ_REAL_IS_DOUBLE
+  const REAL r2 = sqrt(2.0);
+#else
+  const REAL r2 = sqrtf(2.0f);
+#endif
+  const REAL pi = (REAL)2.0 * R_ASIN((REAL)1.0);
+  for (int j = 1; j <= jx; j++)
+    for (int i = 1; i <= ix; i++)
+      for (int k = 1; k <= kx; k++) {
+        REAL x = org[0] + dh * (REAL)(i - 1);
+        REAL y = org[1] + dh * (REAL)(j - 1);
+        REAL z = org[2] + dh * (REAL)(k - 1);
+#ifdef CZ_REAL_IS_DOUBLE
+        e[IDX(k, i, j)] = sin(pi * x) * sin(pi * y) / sinh(r2 * pi) * (sinh(r2 * pi * z) - sinh(r2 * pi * (z - 1.0)));
+#else
+        e[IDX(k, i, j)] =
+            sinf(pi * x) * sinf(pi * y) / sinhf(r2 * pi) * (sinhf(r2 * pi * z) - sinhf(r2 * pi * (z - 1.0f)));
+#endif
+      }
+}
+
+void oracle_err_t(const int* sz, const int* idx, const int* gp, double* d, const REAL* p, REAL* e, int* loc) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  *d = 0.0;
+  loc[0] = loc[1] = loc[2] = -1;
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        REAL r = p[IDX(k, i, j)] - e[IDX(k, i, j)];
+        e[IDX(k, i, j)] = r;
+        double q = fabs((double)r);
+        if (*d < q) {
+          *d = q;
+          loc[0] = i;
+          loc[1] = j;
+          loc[2] = k;
+        }
+      }
+}

@@ -1,0 +1,349 @@
+"""ctypes front-end of the parity oracle + a restatement of the reference's host loops.
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from cubez_amd/ (the product).
+
+Two interchangeable kernel back-ends, same call signatures:
+
+* ``kind="oracle"``  oracle/liboracle_{f32,f64}.so -- the C restatement (cz_oracle.c)
+* ``kind="ref"``     oracle/_ref/libczref_{f32,f64}.so -- the reference's own Fortran
+                      (cz_solver.f90 / cz_blas.f90 / cz_utility.f90) compiled by oracle/Makefile
+
+The host loops below restate /root/reference/src/cz_cpp/cz_Poisson.cpp
+(JACOBI :30-82, RBSOR :159-235, Fdot1/2 :239-270, Preconditioner :273-322,
+PBiCGSTAB :332-504) and the set-up part of cz_Evaluate.cpp (:56-99, :160-177,
+:222-224, :375-391) for the single-domain case, with REAL_TYPE scalar arithmetic
+emulated by numpy scalars of the build precision.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GUIDE = 2  # cz_Define.h:40
+FLT_MIN = 1.17549435e-38
+EPS = 1.0e-5  # cz.h:162
+LC_MAX = 8  # cz_Poisson.cpp:280
+
+_c_int_p = C.POINTER(C.c_int)
+_c_dbl_p = C.POINTER(C.c_double)
+
+
+def lib_path(kind: str, prec: str) -> str:
+    if kind == "oracle":
+        return os.path.join(_HERE, f"liboracle_{prec}.so")
+    if kind == "ref":
+        return os.path.join(_HERE, "_ref", f"libczref_{prec}.so")
+    raise ValueError(kind)
+
+
+def have(kind: str, prec: str = "f32") -> bool:
+    return os.path.exists(lib_path(kind, prec))
+
+
+def _ia(v):
+    return np.ascontiguousarray(v, dtype=np.int32)
+
+
+class Kernels:
+    """Grid kernels of one back-end/precision.  Arrays are numpy, shape (NJ+4, NI+4, NK+4), C order
+    (= the reference's K-fastest Fortran layout)."""
+
+    def __init__(self, kind: str = "oracle", prec: str = "f32"):
+        self.kind, self.prec = kind, prec
+        self.real = np.float32 if prec == "f32" else np.float64
+        self.creal = C.c_float if prec == "f32" else C.c_double
+        self.lib = C.CDLL(lib_path(kind, prec))
+        self._pre, self._suf = ("oracle_", "") if kind == "oracle" else ("", "_")
+
+    # -- helpers -----------------------------------------------------------------
+    def _f(self, name):
+        return getattr(self.lib, f"{self._pre}{name}{self._suf}")
+
+    def _rp(self, a):
+        assert a.dtype == self.real and a.flags["C_CONTIGUOUS"], (a.dtype, self.real)
+        return a.ctypes.data_as(C.c_void_p)
+
+    def _rs(self, v):
+        return C.byref(self.creal(float(v)))
+
+    def _ip(self, a):
+        return a.ctypes.data_as(_c_int_p)
+
+    def alloc(self, sz):
+        """czAllocR_S3D (cz.h:209-232): zero-filled (NJ+4, NI+4, NK+4)."""
+        return np.zeros((sz[1] + 2 * GUIDE, sz[0] + 2 * GUIDE, sz[2] + 2 * GUIDE), dtype=self.real)
+
+    # -- kernels -----------------------------------------------------------------
+    def bc_k(self, sz, p, dh, org, nID):
+        sz, nID, g = _ia(sz), _ia(nID), C.c_int(GUIDE)
+        org = np.ascontiguousarray(org, dtype=self.real)
+        self._f("bc_k")(self._ip(sz), C.byref(g), self._rp(p), self._rs(dh), self._rp(org), self._ip(nID))
+
+    def jacobi(self, p, sz, idx, cf, omg, b, wk2, res=0.0, wide=None):
+        """returns res (+= dble(res1)); wide: optional 1-element float64 array accumulating in double
+        (oracle back-end only)."""
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        cf = np.ascontiguousarray(cf, dtype=self.real)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        args = [self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(cf), self._rs(omg), self._rp(b),
+                C.byref(r), self._rp(wk2), C.byref(fl)]
+        if wide is not None:
+            assert self.kind == "oracle"
+            self.lib.oracle_jacobi_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("jacobi")(*args)
+        self.last_flop = fl.value
+        return r.value
+
+    def psor2sma_core(self, p, sz, idx, cf, ofst, color, omg, b, res=0.0, wide=None):
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        cf = np.ascontiguousarray(cf, dtype=self.real)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        o, c = C.c_int(ofst), C.c_int(color)
+        args = [self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(cf), C.byref(o), C.byref(c),
+                self._rs(omg), self._rp(b), C.byref(r), C.byref(fl)]
+        if wide is not None:
+            assert self.kind == "oracle"
+            self.lib.oracle_psor2sma_core_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("psor2sma_core")(*args)
+        self.last_flop = fl.value
+        return r.value
+
+    def blas_clear(self, x, sz):
+        sz, g = _ia(sz), C.c_int(GUIDE)
+        self._f("blas_clear")(self._rp(x), self._ip(sz), C.byref(g))
+
+    def blas_copy(self, y, x, sz):
+        sz, g = _ia(sz), C.c_int(GUIDE)
+        self._f("blas_copy")(self._rp(y), self._rp(x), self._ip(sz), C.byref(g))
+
+    def blas_triad(self, z, x, y, a, sz, idx):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self._f("blas_triad")(self._rp(z), self._rp(x), self._rp(y), self._rs(a), self._ip(sz), self._ip(idx),
+                              C.byref(g), C.byref(fl))
+
+    def blas_dot1(self, p, sz, idx, wide=None):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        r = self.creal(0.0)
+        args = [C.byref(r), self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), C.byref(fl)]
+        if wide is not None:
+            assert self.kind == "oracle"
+            self.lib.oracle_blas_dot1_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("blas_dot1")(*args)
+        return self.real(r.value)
+
+    def blas_dot2(self, p, q, sz, idx, wide=None):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        r = self.creal(0.0)
+        args = [C.byref(r), self._rp(p), self._rp(q), self._ip(sz), self._ip(idx), C.byref(g), C.byref(fl)]
+        if wide is not None:
+            assert self.kind == "oracle"
+            self.lib.oracle_blas_dot2_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("blas_dot2")(*args)
+        return self.real(r.value)
+
+    def blas_bicg_1(self, p, r, q, beta, omg, sz, idx):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self._f("blas_bicg_1")(self._rp(p), self._rp(r), self._rp(q), self._rs(beta), self._rs(omg), self._ip(sz),
+                               self._ip(idx), C.byref(g), C.byref(fl))
+
+    def blas_bicg_2(self, z, x, y, a, b, sz, idx):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self._f("blas_bicg_2")(self._rp(z), self._rp(x), self._rp(y), self._rs(a), self._rs(b), self._ip(sz),
+                               self._ip(idx), C.byref(g), C.byref(fl))
+
+    def blas_calc_ax(self, ap, p, sz, idx, cf):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        cf = np.ascontiguousarray(cf, dtype=self.real)
+        self._f("blas_calc_ax")(self._rp(ap), self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(cf),
+                                C.byref(fl))
+
+    def blas_calc_rk(self, r, p, b, sz, idx, cf):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        cf = np.ascontiguousarray(cf, dtype=self.real)
+        self._f("blas_calc_rk")(self._rp(r), self._rp(p), self._rp(b), self._ip(sz), self._ip(idx), C.byref(g),
+                                self._rp(cf), C.byref(fl))
+
+    def exact_t(self, sz, e, dh, org):
+        sz, g = _ia(sz), C.c_int(GUIDE)
+        org = np.ascontiguousarray(org, dtype=self.real)
+        self._f("exact_t")(self._ip(sz), C.byref(g), self._rp(e), self._rs(dh), self._rp(org))
+
+    def err_t(self, sz, idx, p, e):
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        d = C.c_double(0.0)
+        loc = np.zeros(3, dtype=np.int32)
+        self._f("err_t")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(d), self._rp(p), self._rp(e), self._ip(loc))
+        return d.value, tuple(int(v) for v in loc)
+
+
+# ----------------------------------------------------------------------------------
+# host loops (single domain)
+# ----------------------------------------------------------------------------------
+def range_inner_index(size, nID):
+    """cz_miscel.cpp:20-52 -> (innerFidx[6], number of inner points)."""
+    ist = jst = kst = 2
+    ied, jed, ked = size
+    if nID[1] < 0:
+        ied = size[0] - 1
+    if nID[3] < 0:
+        jed = size[1] - 1
+    if nID[5] < 0:
+        ked = size[2] - 1
+    idx = [ist, ied, jst, jed, kst, ked]
+    return idx, float(ied - ist + 1) * float(jed - jst + 1) * float(ked - kst + 1)
+
+
+@dataclass
+class Result:
+    itr: int
+    res: float
+    history: list = field(default_factory=list)  # [(itr, res)]
+    P: np.ndarray | None = None
+    errmax: float | None = None
+    errloc: tuple | None = None
+
+    def history_text(self) -> str:
+        """the reference's history file (cz_Evaluate.cpp:218, cz_Poisson.cpp:71)."""
+        return "Itration      Residual\n" + "".join("%6d, %13.6e\n" % (i, r) for i, r in self.history)
+
+
+class CZ:
+    """Single-domain restatement of class CZ's solve path (cz.h:84-181)."""
+
+    def __init__(self, kernels: Kernels):
+        self.k = kernels
+        R = kernels.real
+        self.R = R
+        self.cf = np.array([1, 1, 1, 1, 1, 1, 6], dtype=R)  # cz.h:169-172
+        self.eps = EPS
+        self.nID = [-1] * 6  # DomainInfo.h:61
+        self.history = []
+
+    # cz_Evaluate.cpp:56-99,160-177,222-224,239-288,375-391
+    def setup(self, gsz, coef):
+        R = self.R
+        self.size = [int(v) for v in gsz]
+        self.pitch = R(1.0 / float(R(self.size[2] - 1)))  # :88
+        self.origin = np.zeros(3, dtype=R)
+        self.ac1 = R(float(coef))  # :99
+        self.idx, npts = range_inner_index(self.size, self.nID)
+        self.res_normal = 1.0 / npts
+        k = self.k
+        self.P, self.RHS, self.WRK = k.alloc(self.size), k.alloc(self.size), k.alloc(self.size)
+        k.bc_k(self.size, self.P, self.pitch, self.origin, self.nID)
+        k.bc_k(self.size, self.RHS, self.pitch, self.origin, self.nID)
+
+    # cz_Poisson.cpp:30-82
+    def JACOBI(self, X, B, itr_max, converge_check=True):
+        k, res, itr = self.k, 0.0, 1
+        while itr <= itr_max:
+            res = k.jacobi(X, self.size, self.idx, self.cf, self.ac1, B, self.WRK, res=0.0)
+            if converge_check:
+                res = math.sqrt(res * self.res_normal)
+                self.history.append((itr, res))
+                k.bc_k(self.size, X, self.pitch, self.origin, self.nID)
+                if res < self.eps:
+                    break
+            itr += 1
+        return itr, res
+
+    # cz_Poisson.cpp:159-235
+    def RBSOR(self, X, B, itr_max, converge_check=True):
+        k, res, itr = self.k, 0.0, 1
+        ip = 0  # numProc == 1 (:183-186)
+        while itr <= itr_max:
+            res = 0.0
+            for color in (0, 1):
+                res = k.psor2sma_core(X, self.size, self.idx, self.cf, ip, color, self.ac1, B, res=res)
+            if converge_check:
+                res = math.sqrt(res * self.res_normal)
+                self.history.append((itr, res))
+                k.bc_k(self.size, X, self.pitch, self.origin, self.nID)
+                if res < self.eps:
+                    break
+            itr += 1
+        return itr, res
+
+    # cz_Poisson.cpp:273-322
+    def Preconditioner(self, xx, bb, pc):
+        if pc == "jacobi":
+            self.JACOBI(xx, bb, LC_MAX, converge_check=False)
+        elif pc == "sor2sma":
+            self.RBSOR(xx, bb, LC_MAX, converge_check=False)
+        else:
+            self.k.blas_copy(xx, bb, self.size)
+
+    # cz_Poisson.cpp:332-504
+    def PBiCGSTAB(self, X, B, ItrMax, pc):
+        k, R, sz, idx = self.k, self.R, self.size, self.idx
+        a = {n: k.alloc(sz) for n in ("p", "p_", "r", "r0", "q", "s", "s_", "t_")}
+        res = 0.0
+        k.blas_clear(a["q"], sz)
+        k.blas_calc_rk(a["r"], X, B, sz, idx, self.cf)
+        k.blas_copy(a["r0"], a["r"], sz)
+        rho_old, alpha, omega = R(1.0), R(0.0), R(1.0)
+        itr = 1
+        while itr < ItrMax:  # strict '<' (:373)
+            rho = k.blas_dot2(a["r"], a["r0"], sz, idx)
+            if abs(float(rho)) < FLT_MIN:
+                itr = 0
+                break
+            if itr == 1:
+                k.blas_copy(a["p"], a["r"], sz)
+            else:
+                beta = R(R(R(rho / rho_old) * alpha) / omega)  # :394
+                k.blas_bicg_1(a["p"], a["r"], a["q"], beta, omega, sz, idx)
+            k.blas_clear(a["p_"], sz)
+            self.Preconditioner(a["p_"], a["p"], pc)
+            k.blas_calc_ax(a["q"], a["p_"], sz, idx, self.cf)
+            alpha = R(rho / k.blas_dot2(a["q"], a["r0"], sz, idx))  # :427
+            k.blas_triad(a["s"], a["q"], a["r"], R(-alpha), sz, idx)
+            k.blas_clear(a["s_"], sz)
+            self.Preconditioner(a["s_"], a["s"], pc)
+            k.blas_calc_ax(a["t_"], a["s_"], sz, idx, self.cf)
+            omega = R(k.blas_dot2(a["t_"], a["s"], sz, idx) / k.blas_dot1(a["t_"], sz, idx))  # :464
+            k.blas_bicg_2(X, a["p_"], a["s_"], alpha, omega, sz, idx)
+            k.blas_triad(a["r"], a["t_"], a["s"], R(-omega), sz, idx)
+            res = float(k.blas_dot1(a["r"], sz, idx))
+            res = math.sqrt(res * self.res_normal)
+            self.history.append((itr, res))
+            k.bc_k(sz, X, self.pitch, self.origin, self.nID)
+            if res < self.eps:
+                break
+            rho_old = rho
+            itr += 1
+        return itr, res
+
+    def error_max(self):
+        """debug epilogue, cz_Evaluate.cpp:550-563."""
+        e = self.k.alloc(self.size)
+        self.k.exact_t(self.size, e, self.pitch, self.origin)
+        return self.k.err_t(self.size, self.idx, self.P, e)
+
+
+def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", with_error=False) -> Result:
+    """``cz gsz_x gsz_y gsz_z solver ItrMax coef [precond]`` on the chosen back-end, one thread semantics."""
+    cz = CZ(Kernels(kind, prec))
+    cz.setup(gsz, coef)
+    if solver == "jacobi":
+        itr, res = cz.JACOBI(cz.P, cz.RHS, itr_max)
+    elif solver == "sor2sma":
+        itr, res = cz.RBSOR(cz.P, cz.RHS, itr_max)
+    elif solver == "pbicgstab":
+        itr, res = cz.PBiCGSTAB(cz.P, cz.RHS, itr_max, precond or "none")
+    else:
+        raise ValueError(solver)
+    out = Result(itr=itr, res=res, history=cz.history, P=cz.P)
+    if with_error:
+        out.errmax, out.errloc = cz.error_max()
+    return out
