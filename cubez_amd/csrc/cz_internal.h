@@ -1,0 +1,35 @@
+// cz_internal.h -- shared by cz_kernels.hip and cz_driver.cpp (not part of the public C-ABI)
+#ifndef CZ_INTERNAL_H_
+#define CZ_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "cz_hip.h"
+
+// The reference ABI has no error channel: any HIP failure is fatal and loud.
+#define HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) {                                                                               \
+      fprintf(stderr, "czhip: HIP error %d (%s) at %s:%d: %s\n", (int)e_, hipGetErrorString(e_), __FILE__, \
+              __LINE__, #expr);                                                                           \
+      exit(1);                                                                                            \
+    }                                                                                                     \
+  } while (0)
+
+namespace czhip_internal {
+hipStream_t stream();
+void triad_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, const int* sz, const int* idx, int g);
+void bicg1_async(CZ_REAL* p, const CZ_REAL* r, const CZ_REAL* q, CZ_REAL beta, CZ_REAL omg, const int* sz, const int* idx, int g);
+void bicg2_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, CZ_REAL b, const int* sz, const int* idx, int g);
+void calc_ax_async(CZ_REAL* ap, const CZ_REAL* p, const int* sz, const int* idx, int g, const CZ_REAL* cf);
+void calc_rk_async(CZ_REAL* r, const CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf);
+void dot1_async(const CZ_REAL* p, const int* sz, const int* idx, int g, double* dst_dev);
+void dot2_async(const CZ_REAL* p, const CZ_REAL* q, const int* sz, const int* idx, int g, double* dst_dev);
+void bc_async(const int* sz, int g, CZ_REAL* p, CZ_REAL dh, const CZ_REAL* org, const int* nID);
+}  // namespace czhip_internal
+
+#endif

@@ -1,0 +1,996 @@
+// cz_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the CubeZ hot path + the C-ABI of include/cz_hip.h
+// parts 1-3.  One translation unit per precision (-DCZ_REAL_IS_DOUBLE for FP64), compiled with
+// -ffp-contract=off so that every sweep reproduces the reference's un-fused FP32/FP64 arithmetic bit for bit
+// (SURVEY.md section 7 "hard parts").
+//
+// Data layout (cz_solver.f90:29): arrays are dense (NK+2g, NI+2g, NJ+2g), K fastest.  A (k,i) PLANE of one j is
+// therefore one contiguous run of (NK+2g)*(NI+2g) elements: row i+1 follows row i directly.  The stencil kernel
+// exploits this by treating a plane as a 1-D array of 16-byte vectors (float4 / double2):
+//     k+-1 neighbour = +-1 element, i+-1 neighbour = +-R vectors (R = (NK+2g)/V), j+-1 neighbour = +-1 plane.
+// A workgroup owns a contiguous SEGMENT of S = TB*M vectors of the plane (about S/R rows) and marches it through
+// a CHUNK of TJ consecutive planes (2.5-D blocking): plane j-1/j/j+1 values of its own vectors live in registers
+// (a 3-deep queue that rotates as j advances), the centre plane j of the segment plus one row of halo on either
+// side is staged in LDS (double-buffered, one barrier per plane) for the i+-1 and the vector-crossing k+-1
+// neighbours.  Every global access is a 16-byte-per-lane fully coalesced load/store; each p and b element is read
+// from HBM once per sweep (plus R-vector row halos shared with the neighbouring workgroup through L2 and two
+// planes per chunk), each new element is written once.  No MFMA: 18 flop per 12 bytes is far below the ridge.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "cz_hip.h"
+#include "cz_internal.h"
+
+typedef CZ_REAL REAL;
+#ifdef CZ_REAL_IS_DOUBLE
+constexpr int VW = 2;  // elements per 16-byte vector
+#else
+constexpr int VW = 4;
+#endif
+
+namespace {
+
+template <int V>
+struct alignas(sizeof(REAL) * V) Vec {
+  REAL v[V];
+};
+
+struct Coef {
+  REAL c1, c2, c3, c4, c5, c6, dd, omg;
+};
+
+// Geometry of one launch, all in PADDED 0-based indices (kk = k+g-1, ...).
+struct Geom {
+  int R;            // vectors per k-row = (NK+2g)/V
+  long long PSV;    // vectors per plane = R*(NI+2g)
+  int kk0, kk1;     // inner k range (inclusive)
+  int jj0, jj1;     // inner j range (inclusive)
+  long long F0;     // first vector of the update range inside a plane = ii0*R
+  long long Fend;   // one past the last vector of the update range    = (ii1+1)*R
+  int nseg;         // segments per plane
+  int TJ;           // planes per chunk
+  int S;            // vectors per segment
+};
+
+enum { MODE_JACOBI = 0, MODE_RB = 1, MODE_AX = 2, MODE_RK = 3 };
+
+template <int V>
+__device__ __forceinline__ Vec<V> ldv(const REAL* base, long long vec_index) {
+  return *reinterpret_cast<const Vec<V>*>(base + vec_index * V);
+}
+template <int V>
+__device__ __forceinline__ void stv(REAL* base, long long vec_index, const Vec<V>& x) {
+  *reinterpret_cast<Vec<V>*>(base + vec_index * V) = x;
+}
+template <int V>
+__device__ __forceinline__ Vec<V> zerov() {
+  Vec<V> z;
+#pragma unroll
+  for (int c = 0; c < V; c++) z.v[c] = (REAL)0;
+  return z;
+}
+
+// deterministic block reduction of one double per thread: wave64 shuffle tree, then LDS across waves.
+template <int TB>
+__device__ __forceinline__ double block_sum(double x, double* wsum /* TB/64 doubles of LDS */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) wsum[wave] = x;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < TB / 64; w++) s += wsum[w];
+  }
+  return s;  // valid on thread 0
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The 7-point sweep.  MODE selects the point update:
+//   JACOBI  cz_solver.f90:334-351   out = p + ((ss-b)/dd - p)*omg , acc += dp*dp
+//   RB      cz_solver.f90:466-480   same, in place (OUT == P), only points of one colour
+//   AX      cz_blas.f90:626-632     out = ss - dd*p
+//   RK      cz_blas.f90:705-711     out = b - (ss - dd*p)
+// with ss = c1*p(i+1) + c2*p(i-1) + c3*p(j+1) + c4*p(j-1) + c5*p(k+1) + c6*p(k-1), left to right.
+// Elements outside the inner box are never written.
+// ------------------------------------------------------------------------------------------------------------
+template <int V, int TB, int M, int PF, int MODE>
+__global__ void __launch_bounds__(TB)
+stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, double* __restrict__ partials,
+          const int* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0) return;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int R = g.R;
+  const int L = g.S + 2 * R;  // vectors per LDS buffer
+  Vec<V>* ldsv = reinterpret_cast<Vec<V>*>(smem);
+  REAL* ldsf = reinterpret_cast<REAL*>(smem);
+  double* wsum = reinterpret_cast<double*>(smem + (size_t)2 * L * sizeof(Vec<V>));
+
+  // XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a
+  // contiguous run of logical ids so that row-adjacent segments (which share halo rows) meet in one L2.
+  int lb = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) lb = (lb & 7) * (nblk >> 3) + (lb >> 3);
+  const int seg = lb % g.nseg;
+  const int chunk = lb / g.nseg;
+
+  const long long fb = g.F0 + (long long)seg * g.S;
+  const int ja = g.jj0 + chunk * g.TJ;
+  int jb = ja + g.TJ - 1;
+  if (jb > g.jj1) jb = g.jj1;
+
+  double acc = 0.0;
+
+  if (ja <= jb && fb < g.Fend) {
+    // per-vector constants of this thread
+    long long f[M];
+    unsigned mk[M];   // bit c set: component c is an inner point (k range, valid row)
+    int pbase[M];     // (kk + ii + par) & 1 of component 0 (MODE_RB)
+    const long long lim_ld = g.Fend + R;  // vectors below this exist in the plane (row ii1+1 is a halo row)
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      f[m] = fb + t + m * TB;
+      const long long row = f[m] / R;
+      const int kv = (int)(f[m] - row * R);
+      unsigned bits = 0;
+      if (f[m] < g.Fend) {
+#pragma unroll
+        for (int cc = 0; cc < V; cc++) {
+          const int kk = kv * V + cc;
+          if (kk >= g.kk0 && kk <= g.kk1) bits |= 1u << cc;
+        }
+      }
+      mk[m] = bits;
+      pbase[m] = (kv * V + (int)row + par) & 1;
+    }
+
+    Vec<V> pm[M], pc[M], pn[M], bb[M];
+    Vec<V> pnn[PF ? M : 1], bbn[PF ? M : 1];
+
+    const REAL* Pm = P + (long long)(ja - 1) * g.PSV * V;
+    const REAL* Pc = P + (long long)ja * g.PSV * V;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      const bool ok = f[m] < lim_ld;
+      pm[m] = ok ? ldv<V>(Pm, f[m]) : zerov<V>();
+      pc[m] = ok ? ldv<V>(Pc, f[m]) : zerov<V>();
+    }
+    // stage plane ja (own vectors + halo rows) into LDS buffer 0
+    {
+      Vec<V>* buf = ldsv;
+#pragma unroll
+      for (int m = 0; m < M; m++) buf[R + t + m * TB] = pc[m];
+      for (int h = t; h < R; h += TB) {
+        buf[h] = ldv<V>(Pc, fb - R + h);
+        const long long fh = fb + g.S + h;
+        buf[R + g.S + h] = (fh < lim_ld) ? ldv<V>(Pc, fh) : zerov<V>();
+      }
+    }
+    if (PF) {
+      const REAL* Pn = P + (long long)(ja + 1) * g.PSV * V;
+      const REAL* Bc = B + (long long)ja * g.PSV * V;
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        pn[m] = (f[m] < lim_ld) ? ldv<V>(Pn, f[m]) : zerov<V>();
+        if (MODE != MODE_AX) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
+      }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int jj = ja; jj <= jb; jj++) {
+      const bool more = jj < jb;
+      const REAL* Pn = P + (long long)(jj + 1) * g.PSV * V;
+      // ---- issue the loads of the following step early
+      if (PF) {
+        if (more) {
+          const REAL* Pnn = Pn + g.PSV * V;
+          const REAL* Bn = B + (long long)(jj + 1) * g.PSV * V;
+#pragma unroll
+          for (int m = 0; m < M; m++) {
+            pnn[m] = (f[m] < lim_ld) ? ldv<V>(Pnn, f[m]) : zerov<V>();
+            if (MODE != MODE_AX) bbn[m] = (f[m] < g.Fend) ? ldv<V>(Bn, f[m]) : zerov<V>();
+          }
+        }
+      } else {
+        const REAL* Bc = B + (long long)jj * g.PSV * V;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          pn[m] = (f[m] < lim_ld) ? ldv<V>(Pn, f[m]) : zerov<V>();
+          if (MODE != MODE_AX) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
+        }
+      }
+      // halo rows of the next centre plane (only the first R threads; R <= TB in the common case)
+      Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
+      const bool halo_in_regs = (R <= TB);
+      if (more && halo_in_regs && t < R) {
+        hlo = ldv<V>(Pn, fb - R + t);
+        const long long fh = fb + g.S + t;
+        if (fh < lim_ld) hhi = ldv<V>(Pn, fh);
+      }
+
+      // ---- update plane jj
+      const Vec<V>* buf = ldsv + (size_t)cur * L;
+      const REAL* buff = ldsf + (size_t)cur * L * V;
+      REAL* Oc = OUT + (long long)jj * g.PSV * V;
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        if (mk[m] == 0) continue;
+        const int li = t + m * TB;
+        const Vec<V> im = buf[li];
+        const Vec<V> ip = buf[li + 2 * R];
+        const REAL kl = buff[(R + li) * V - 1];
+        const REAL kr = buff[(R + li) * V + V];
+        Vec<V> o;
+        unsigned wmask = mk[m];
+        if (MODE == MODE_RB) {
+          // colour: (kk + ii + jj + par) even
+          unsigned cm = 0;
+#pragma unroll
+          for (int cc = 0; cc < V; cc++)
+            if (((pbase[m] + cc + jj) & 1) == 0) cm |= 1u << cc;
+          wmask &= cm;
+        }
+#pragma unroll
+        for (int cc = 0; cc < V; cc++) {
+          const REAL pp = pc[m].v[cc];
+          const REAL km1 = (cc == 0) ? kl : pc[m].v[cc > 0 ? cc - 1 : 0];
+          const REAL kp1 = (cc == V - 1) ? kr : pc[m].v[cc < V - 1 ? cc + 1 : V - 1];
+          const REAL ss = c.c1 * ip.v[cc] + c.c2 * im.v[cc] + c.c3 * pn[m].v[cc] + c.c4 * pm[m].v[cc] + c.c5 * kp1 +
+                          c.c6 * km1;
+          if (MODE == MODE_JACOBI || MODE == MODE_RB) {
+            const REAL dp = ((ss - bb[m].v[cc]) / c.dd - pp) * c.omg;
+            o.v[cc] = pp + dp;
+            const REAL d2 = dp * dp;
+            if (wmask & (1u << cc)) acc += (double)d2;
+          } else if (MODE == MODE_AX) {
+            o.v[cc] = ss - c.dd * pp;
+          } else {
+            o.v[cc] = bb[m].v[cc] - (ss - c.dd * pp);
+          }
+        }
+        if (MODE == MODE_RB) {
+          // in place: components of the other colour / outside the box keep their value; a full-vector store
+          // of unchanged bits is harmless because every element is owned by exactly one thread.
+          if (mk[m] == (1u << V) - 1) {
+#pragma unroll
+            for (int cc = 0; cc < V; cc++)
+              if (!(wmask & (1u << cc))) o.v[cc] = pc[m].v[cc];
+            stv<V>(Oc, f[m], o);
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < V; cc++)
+              if (wmask & (1u << cc)) Oc[f[m] * V + cc] = o.v[cc];
+          }
+        } else {
+          if (wmask == (1u << V) - 1) {
+            stv<V>(Oc, f[m], o);
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < V; cc++)
+              if (wmask & (1u << cc)) Oc[f[m] * V + cc] = o.v[cc];
+          }
+        }
+      }
+
+      // ---- stage plane jj+1 into the other LDS buffer, rotate the register queue
+      if (more) {
+        Vec<V>* nbuf = ldsv + (size_t)(cur ^ 1) * L;
+#pragma unroll
+        for (int m = 0; m < M; m++) nbuf[R + t + m * TB] = pn[m];
+        if (halo_in_regs) {
+          if (t < R) {
+            nbuf[t] = hlo;
+            nbuf[R + g.S + t] = hhi;
+          }
+        } else {
+          for (int h = t; h < R; h += TB) {
+            nbuf[h] = ldv<V>(Pn, fb - R + h);
+            const long long fh = fb + g.S + h;
+            nbuf[R + g.S + h] = (fh < lim_ld) ? ldv<V>(Pn, fh) : zerov<V>();
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        pm[m] = pc[m];
+        pc[m] = pn[m];
+        if (PF) {
+          pn[m] = pnn[m];
+          bb[m] = bbn[m];
+        }
+      }
+      cur ^= 1;
+    }
+  }
+
+  if (MODE == MODE_JACOBI || MODE == MODE_RB) {
+    __syncthreads();
+    const double s = block_sum<TB>(acc, wsum);
+    if (t == 0) partials[lb] = s;
+  }
+}
+
+// sum of n partials in a fixed order -> dst[0] (= or +=).  One workgroup: deterministic.
+__global__ void __launch_bounds__(1024)
+reduce_partials_k(const double* __restrict__ partials, int n, double* __restrict__ dst, int accumulate,
+                  const int* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0) return;
+  __shared__ double wsum[16];
+  double x = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) x += partials[i];
+  const double s = block_sum<1024>(x, wsum);
+  if (threadIdx.x == 0) dst[0] = accumulate ? dst[0] + s : s;
+}
+
+// cz_Poisson.cpp:67-77 on the device
+__global__ void check_k(const double* res_dev, double res_normal, double eps, int itr, double* hist, int* flag,
+                        int* conv_itr) {
+  if (*flag != 0) return;
+  double r = res_dev[0];
+  r *= res_normal;
+  r = sqrt(r);
+  hist[itr] = r;
+  if (r < eps) {
+    *flag = 1;
+    *conv_itr = itr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// element-wise kernels on the inner box (cz_blas.f90): one vector per thread, blockIdx.y = plane
+// ------------------------------------------------------------------------------------------------------------
+enum { OP_TRIAD = 0, OP_BICG1 = 1, OP_BICG2 = 2, OP_COPY = 3 };
+
+struct EGeom {
+  int R;
+  long long PSV;
+  int kk0, kk1, jj0;
+  long long F0, Fend;
+};
+
+template <int V, int OP>
+__global__ void __launch_bounds__(256)
+ewise_k(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL b, EGeom g) {
+  const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= g.Fend) return;
+  const long long pv = (long long)(g.jj0 + blockIdx.y) * g.PSV + f;
+  const int kv = (int)(f % g.R);
+  unsigned mk = 0;
+#pragma unroll
+  for (int cc = 0; cc < V; cc++) {
+    const int kk = kv * V + cc;
+    if (kk >= g.kk0 && kk <= g.kk1) mk |= 1u << cc;
+  }
+  if (mk == 0) return;
+  Vec<V> x = ldv<V>(X, pv), y, z, o;
+  if (OP != OP_COPY) y = ldv<V>(Y, pv);
+  if (OP == OP_BICG1 || OP == OP_BICG2) z = ldv<V>(Z, pv);
+#pragma unroll
+  for (int cc = 0; cc < V; cc++) {
+    if (OP == OP_TRIAD) o.v[cc] = a * x.v[cc] + y.v[cc];                              // cz_blas.f90:297
+    if (OP == OP_BICG1) o.v[cc] = x.v[cc] + a * (z.v[cc] - b * y.v[cc]);              // :490  p = r + beta*(p - omg*q)
+    if (OP == OP_BICG2) o.v[cc] = a * x.v[cc] + b * y.v[cc] + z.v[cc];                // :554
+    if (OP == OP_COPY) o.v[cc] = x.v[cc];
+  }
+  if (mk == (1u << V) - 1) {
+    stv<V>(Z, pv, o);
+  } else {
+#pragma unroll
+    for (int cc = 0; cc < V; cc++)
+      if (mk & (1u << cc)) Z[pv * V + cc] = o.v[cc];
+  }
+}
+
+// dot products (cz_blas.f90:361-362, :426): per-point product in REAL, accumulated in double.
+template <int V, int TWO>
+__global__ void __launch_bounds__(256)
+dot_k(const REAL* X, const REAL* Y, EGeom g, double* __restrict__ partials) {
+  __shared__ double wsum[4];
+  const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  if (f < g.Fend) {
+    const long long pv = (long long)(g.jj0 + blockIdx.y) * g.PSV + f;
+    const int kv = (int)(f % g.R);
+    const Vec<V> x = ldv<V>(X, pv);
+    Vec<V> y = x;
+    if (TWO) y = ldv<V>(Y, pv);
+#pragma unroll
+    for (int cc = 0; cc < V; cc++) {
+      const int kk = kv * V + cc;
+      const REAL tt = x.v[cc] * y.v[cc];
+      if (kk >= g.kk0 && kk <= g.kk1) acc += (double)tt;
+    }
+  }
+  const double s = block_sum<256>(acc, wsum);
+  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bc_k (cz_solver.f90:22-191): the sin*sin table is evaluated on the HOST with the host libm -- the same sinf/sin
+// the reference's Fortran calls -- so the Dirichlet data are bit-identical to the reference's; the kernels only
+// scatter it.  Three launches in the reference's order: K faces, then I faces, then J faces (edges end up 0).
+// ------------------------------------------------------------------------------------------------------------
+__global__ void bc_kface_k(REAL* p, const REAL* __restrict__ tab, int ix, int jx, int kface, int g, int nkp, int nip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y + 1;
+  if (i > ix) return;
+  p[(size_t)(kface + g - 1) + (size_t)(i + g - 1) * nkp + (size_t)(j + g - 1) * nkp * nip] = tab[(size_t)(j - 1) * ix + (i - 1)];
+}
+__global__ void bc_iface_k(REAL* p, int jx, int kx, int iface, int g, int nkp, int nip) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x + 1, j = blockIdx.y + 1;
+  if (k > kx) return;
+  p[(size_t)(k + g - 1) + (size_t)(iface + g - 1) * nkp + (size_t)(j + g - 1) * nkp * nip] = (REAL)0;
+}
+__global__ void bc_jface_k(REAL* p, int ix, int kx, int jface, int g, int nkp, int nip) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x + 1, i = blockIdx.y + 1;
+  if (k > kx) return;
+  p[(size_t)(k + g - 1) + (size_t)(i + g - 1) * nkp + (size_t)(jface + g - 1) * nkp * nip] = (REAL)0;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+struct Tuning {
+  int threads = 256, m = 2, tj = 0 /* 0 = auto */, pf = 1;
+};
+
+struct Ctx {
+  bool ready = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  double* partials = nullptr;   // device
+  size_t partials_cap = 0;
+  double* scal_dev = nullptr;   // a few device doubles for the synchronous entry points
+  double* scal_host = nullptr;  // pinned
+  Tuning tune;
+  std::map<std::vector<double>, REAL*> bc_tabs;  // key: ix, jx, dh, org0, org1
+  int num_cu = 256;
+};
+Ctx ctx;
+
+void ensure_init() {
+  if (!ctx.ready) czhip_init(-1);
+}
+
+void ensure_partials(size_t n) {
+  if (n <= ctx.partials_cap) return;
+  if (ctx.partials) {
+    HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    HIP_CHECK(hipFree(ctx.partials));
+  }
+  size_t cap = n < 65536 ? 65536 : n;
+  HIP_CHECK(hipMalloc(&ctx.partials, cap * sizeof(double)));
+  ctx.partials_cap = cap;
+}
+
+struct Box {
+  int ni, nj, nk, g, nkp, nip, njp;
+  int kk0, kk1, ii0, ii1, jj0, jj1;
+  bool empty;
+};
+
+Box make_box(const int* sz, const int* idx, int g) {
+  Box b;
+  b.ni = sz[0], b.nj = sz[1], b.nk = sz[2], b.g = g;
+  b.nkp = b.nk + 2 * g, b.nip = b.ni + 2 * g, b.njp = b.nj + 2 * g;
+  // 1-based inclusive (ist,ied,jst,jed,kst,ked) -> padded 0-based
+  b.ii0 = idx[0] + g - 1, b.ii1 = idx[1] + g - 1;
+  b.jj0 = idx[2] + g - 1, b.jj1 = idx[3] + g - 1;
+  b.kk0 = idx[4] + g - 1, b.kk1 = idx[5] + g - 1;
+  b.empty = b.ii1 < b.ii0 || b.jj1 < b.jj0 || b.kk1 < b.kk0;
+  // the 7-point stencil reads one layer around the box: it must exist inside the padded array
+  if (!b.empty && (g < 1 || b.ii0 < 1 || b.jj0 < 1 || b.kk0 < 1 || b.ii1 > b.nip - 2 || b.jj1 > b.njp - 2 || b.kk1 > b.nkp - 2)) {
+    fprintf(stderr, "czhip: index range (%d..%d, %d..%d, %d..%d) does not fit sz=(%d,%d,%d) g=%d\n", idx[0], idx[1], idx[2],
+            idx[3], idx[4], idx[5], sz[0], sz[1], sz[2], g);
+    exit(1);
+  }
+  return b;
+}
+
+inline bool vec_ok(const Box& b, std::initializer_list<const void*> ptrs) {
+  if (b.nkp % VW != 0) return false;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15u)) return false;
+  return true;
+}
+
+template <int V>
+EGeom make_egeom(const Box& b) {
+  EGeom e;
+  e.R = b.nkp / V;
+  e.PSV = (long long)e.R * b.nip;
+  e.kk0 = b.kk0, e.kk1 = b.kk1, e.jj0 = b.jj0;
+  e.F0 = (long long)b.ii0 * e.R;
+  e.Fend = (long long)(b.ii1 + 1) * e.R;
+  return e;
+}
+
+template <int V, int TB, int M, int PF, int MODE>
+void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, const Box& b, int par, int tj_req,
+                         const int* skip, int* nblk_out) {
+  Geom g;
+  g.R = b.nkp / V;
+  g.PSV = (long long)g.R * b.nip;
+  g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
+  g.F0 = (long long)b.ii0 * g.R;
+  g.Fend = (long long)(b.ii1 + 1) * g.R;
+  g.S = TB * M;
+  const long long nf = g.Fend - g.F0;
+  g.nseg = (int)((nf + g.S - 1) / g.S);
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  int tj = tj_req;
+  if (tj <= 0) {
+    // auto: enough workgroups to fill the chip a few times over, chunk count a multiple of 8 (XCD remap)
+    const int waves_per_wg = TB / 64;
+    const long long want = (long long)ctx.num_cu * 32 / waves_per_wg;  // one full residency of waves
+    int nchunk = (int)((want + g.nseg - 1) / g.nseg);
+    nchunk = ((nchunk + 7) / 8) * 8;
+    if (nchunk > nplanes) nchunk = nplanes;
+    if (nchunk < 1) nchunk = 1;
+    tj = (nplanes + nchunk - 1) / nchunk;
+  }
+  if (tj > nplanes) tj = nplanes;
+  g.TJ = tj;
+  int nchunk = (nplanes + tj - 1) / tj;
+  // pad the chunk count to a multiple of 8 when that costs nothing but empty workgroups (keeps the remap on)
+  if (((long long)nchunk * g.nseg) % 8 != 0 && nchunk >= 8) nchunk = ((nchunk + 7) / 8) * 8;
+  const long long nblk = (long long)nchunk * g.nseg;
+  const size_t lds = (size_t)2 * (g.S + 2 * g.R) * sizeof(Vec<V>) + 16 * sizeof(double);
+  if (lds > 160 * 1024) {
+    fprintf(stderr, "czhip: k-row of %d elements needs %zu bytes of LDS (>160 KiB)\n", b.nkp, lds);
+    exit(1);
+  }
+  if (MODE == MODE_JACOBI || MODE == MODE_RB) ensure_partials((size_t)nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil_k<V, TB, M, PF, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((stencil_k<V, TB, M, PF, MODE>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, P, B, OUT, c, g, par,
+                     ctx.partials, skip);
+  HIP_CHECK(hipGetLastError());
+  if (nblk_out) *nblk_out = (int)nblk;
+}
+
+template <int MODE>
+void launch_stencil(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, const Box& b, int par, const int* skip,
+                    int* nblk_out) {
+  const Tuning& tu = ctx.tune;
+  if (!vec_ok(b, {P, B, OUT})) {
+    launch_stencil_inst<1, 256, 2, 0, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out);
+    return;
+  }
+#define CZ_INST(TB_, M_, PF_)                                                                      \
+  if (tu.threads == TB_ && tu.m == M_ && tu.pf == PF_) {                                           \
+    launch_stencil_inst<VW, TB_, M_, PF_, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out);      \
+    return;                                                                                        \
+  }
+  if (MODE == MODE_JACOBI || MODE == MODE_RB) {
+    CZ_INST(256, 1, 0) CZ_INST(256, 1, 1) CZ_INST(256, 2, 0) CZ_INST(256, 2, 1) CZ_INST(256, 4, 0) CZ_INST(256, 4, 1)
+    CZ_INST(512, 1, 0) CZ_INST(512, 1, 1) CZ_INST(512, 2, 0) CZ_INST(512, 2, 1) CZ_INST(512, 4, 0) CZ_INST(512, 4, 1)
+    CZ_INST(1024, 1, 0) CZ_INST(1024, 1, 1) CZ_INST(1024, 2, 0) CZ_INST(1024, 2, 1)
+  }
+#undef CZ_INST
+  launch_stencil_inst<VW, 256, 2, 1, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out);
+}
+
+void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
+  hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(1024), 0, ctx.stream, ctx.partials, n, dst, accumulate, skip);
+  HIP_CHECK(hipGetLastError());
+}
+
+Coef make_coef(const REAL* cf, REAL omg) {
+  Coef c;
+  c.c1 = cf[0], c.c2 = cf[1], c.c3 = cf[2], c.c4 = cf[3], c.c5 = cf[4], c.c6 = cf[5], c.dd = cf[6], c.omg = omg;
+  return c;
+}
+
+template <int OP>
+void launch_ewise(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL bcoef, const Box& b) {
+  if (b.empty) return;
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  if (vec_ok(b, {Z, X, Y})) {
+    EGeom e = make_egeom<VW>(b);
+    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
+    hipLaunchKernelGGL((ewise_k<VW, OP>), grid, dim3(256), 0, ctx.stream, Z, X, Y, a, bcoef, e);
+  } else {
+    EGeom e = make_egeom<1>(b);
+    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
+    hipLaunchKernelGGL((ewise_k<1, OP>), grid, dim3(256), 0, ctx.stream, Z, X, Y, a, bcoef, e);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
+// dot -> device double dst[0]
+template <int TWO>
+void launch_dot(const REAL* X, const REAL* Y, const Box& b, double* dst) {
+  if (b.empty) {
+    HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  size_t nblk;
+  if (vec_ok(b, {X, Y})) {
+    EGeom e = make_egeom<VW>(b);
+    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
+    nblk = (size_t)grid.x * grid.y;
+    ensure_partials(nblk);
+    hipLaunchKernelGGL((dot_k<VW, TWO>), grid, dim3(256), 0, ctx.stream, X, Y, e, ctx.partials);
+  } else {
+    EGeom e = make_egeom<1>(b);
+    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
+    nblk = (size_t)grid.x * grid.y;
+    ensure_partials(nblk);
+    hipLaunchKernelGGL((dot_k<1, TWO>), grid, dim3(256), 0, ctx.stream, X, Y, e, ctx.partials);
+  }
+  HIP_CHECK(hipGetLastError());
+  reduce_partials((int)nblk, dst, 0, nullptr);
+}
+
+double read_scalar(int slot) {
+  HIP_CHECK(hipMemcpyAsync(ctx.scal_host + slot, ctx.scal_dev + slot, sizeof(double), hipMemcpyDeviceToHost, ctx.stream));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  return ctx.scal_host[slot];
+}
+
+inline double npts(const int* idx) {
+  return (double)(idx[1] - idx[0] + 1) * (double)(idx[3] - idx[2] + 1) * (double)(idx[5] - idx[4] + 1);
+}
+
+// Host evaluation of the Dirichlet table sin(pi*x)*sin(pi*y), cz_solver.f90:36,52-58.
+REAL* bc_table(int ix, int jx, REAL dh, const REAL* org) {
+  std::vector<double> key = {(double)ix, (double)jx, (double)dh, (double)org[0], (double)org[1]};
+  auto it = ctx.bc_tabs.find(key);
+  if (it != ctx.bc_tabs.end()) return it->second;
+  std::vector<REAL> tab((size_t)ix * jx);
+  volatile REAL one = (REAL)1.0;  // keep asin() a run-time libm call like the rest
+#ifdef CZ_REAL_IS_DOUBLE
+  const REAL pi = 2.0 * asin(one);
+#else
+  const REAL pi = 2.0f * asinf(one);
+#endif
+  for (int j = 1; j <= jx; j++)
+    for (int i = 1; i <= ix; i++) {
+      const REAL x = org[0] + dh * (REAL)(i - 1);
+      const REAL y = org[1] + dh * (REAL)(j - 1);
+#ifdef CZ_REAL_IS_DOUBLE
+      tab[(size_t)(j - 1) * ix + (i - 1)] = sin(pi * x) * sin(pi * y);
+#else
+      tab[(size_t)(j - 1) * ix + (i - 1)] = sinf(pi * x) * sinf(pi * y);
+#endif
+    }
+  REAL* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, tab.size() * sizeof(REAL)));
+  HIP_CHECK(hipMemcpy(d, tab.data(), tab.size() * sizeof(REAL), hipMemcpyHostToDevice));
+  ctx.bc_tabs[key] = d;
+  return d;
+}
+
+}  // namespace
+
+// ============================================================================================================
+// Part 2: runtime
+// ============================================================================================================
+extern "C" {
+
+int czhip_real_bytes(void) { return (int)sizeof(REAL); }
+const char* czhip_arch(void) { return "gfx950"; }
+
+int czhip_init(int device) {
+  if (ctx.ready) return 0;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0) {
+    fprintf(stderr, "czhip: no HIP device available (%s) -- this library has no CPU fallback\n", hipGetErrorString(e));
+    exit(1);
+  }
+  if (device < 0) {
+    const char* lr = getenv("LOCAL_RANK");
+    device = lr ? atoi(lr) % ndev : 0;
+  }
+  HIP_CHECK(hipSetDevice(device));
+  ctx.device = device;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  ctx.num_cu = prop.multiProcessorCount;
+  HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+  HIP_CHECK(hipMalloc(&ctx.scal_dev, 16 * sizeof(double)));
+  HIP_CHECK(hipMemset(ctx.scal_dev, 0, 16 * sizeof(double)));
+  HIP_CHECK(hipHostMalloc(&ctx.scal_host, 16 * sizeof(double), hipHostMallocDefault));
+  ctx.ready = true;
+  ensure_partials(65536);
+  const char* tu = getenv("CZHIP_TUNING");  // "threads,m,tj,pf"
+  if (tu) {
+    int a = 0, b = 0, c = 0, d = -1;
+    if (sscanf(tu, "%d,%d,%d,%d", &a, &b, &c, &d) >= 2) czhip_set_tuning(a, b, c < 0 ? 0 : c, d);
+  }
+  return 0;
+}
+
+void czhip_finalize(void) {
+  if (!ctx.ready) return;
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  for (auto& kv : ctx.bc_tabs) (void)hipFree(kv.second);
+  ctx.bc_tabs.clear();
+  (void)hipFree(ctx.partials);
+  (void)hipFree(ctx.scal_dev);
+  (void)hipHostFree(ctx.scal_host);
+  (void)hipStreamDestroy(ctx.stream);
+  ctx = Ctx();
+}
+
+CZ_REAL* czhip_alloc_s3d(const int* sz) {
+  ensure_init();
+  const size_t n = (size_t)(sz[0] + 4) * (size_t)(sz[1] + 4) * (size_t)(sz[2] + 4);  // GUIDE = 2, cz_Define.h:40
+  REAL* p = nullptr;
+  HIP_CHECK(hipMalloc(&p, n * sizeof(REAL)));
+  HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(REAL), ctx.stream));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  return p;
+}
+
+void czhip_free(void* d) {
+  if (!d) return;
+  ensure_init();
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  HIP_CHECK(hipFree(d));
+}
+
+void czhip_h2d(void* dst, const void* src, size_t bytes) {
+  ensure_init();
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+}
+
+void czhip_d2h(void* dst, const void* src, size_t bytes) {
+  ensure_init();
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+}
+
+void czhip_sync(void) {
+  ensure_init();
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void* czhip_stream(void) {
+  ensure_init();
+  return (void*)ctx.stream;
+}
+
+int czhip_set_tuning(int threads, int m, int tj, int pf) {
+  Tuning t = ctx.tune;
+  if (threads > 0) t.threads = threads;
+  if (m > 0) t.m = m;
+  if (tj >= 0) t.tj = tj;
+  if (pf >= 0) t.pf = pf;
+  const bool ok = (t.threads == 256 || t.threads == 512 || t.threads == 1024) && (t.m == 1 || t.m == 2 || (t.m == 4 && t.threads != 1024)) &&
+                  (t.pf == 0 || t.pf == 1);
+  if (!ok) return 1;
+  ctx.tune = t;
+  return 0;
+}
+
+void czhip_get_tuning(int* threads, int* m, int* tj, int* pf) {
+  *threads = ctx.tune.threads, *m = ctx.tune.m, *tj = ctx.tune.tj, *pf = ctx.tune.pf;
+}
+
+// ============================================================================================================
+// Part 3: asynchronous operations
+// ============================================================================================================
+void czhip_jacobi_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g,
+                        const CZ_REAL* cf, CZ_REAL omg, double* res_dev, int accumulate, const int* skip) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  int nblk = 0;
+  launch_stencil<MODE_JACOBI>(p_in, b, p_out, make_coef(cf, omg), bx, 0, skip, &nblk);
+  reduce_partials(nblk, res_dev, accumulate, skip);
+}
+
+void czhip_rbsor_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf, int ofst,
+                       int color, CZ_REAL omg, double* res_dev, int accumulate, const int* skip) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  // cz_solver.f90:466  k = kst + mod(i+j+kp,2), step 2  <=>  (k + i + j + kst + kp) even  (1-based)
+  // padded 0-based indices shift each of k,i,j by g-1
+  const int par = (3 * (g - 1) + idx[4] + ofst + color) & 1;
+  int nblk = 0;
+  launch_stencil<MODE_RB>(p, b, p, make_coef(cf, omg), bx, par, skip, &nblk);
+  reduce_partials(nblk, res_dev, accumulate, skip);
+}
+
+void czhip_check_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
+                       int* conv_itr_dev) {
+  ensure_init();
+  hipLaunchKernelGGL(check_k, dim3(1), dim3(1), 0, ctx.stream, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ============================================================================================================
+// Part 1: drop-in kernels (synchronous, reference semantics)
+// ============================================================================================================
+void bc_k_(int* sz, int* gp, CZ_REAL* p, CZ_REAL* dh, CZ_REAL* org, int* nID) {
+  ensure_init();
+  const int g = *gp, ix = sz[0], jx = sz[1], kx = sz[2];
+  const int nkp = kx + 2 * g, nip = ix + 2 * g;
+  // nID order I-,I+,J-,J+,K-,K+ (cz_fparam.fi:10-16)
+  if (nID[4] < 0 || nID[5] < 0) {
+    const REAL* tab = bc_table(ix, jx, *dh, org);
+    dim3 grid((ix + 127) / 128, jx);
+    if (nID[4] < 0) hipLaunchKernelGGL(bc_kface_k, grid, dim3(128), 0, ctx.stream, p, tab, ix, jx, 1, g, nkp, nip);
+    if (nID[5] < 0) hipLaunchKernelGGL(bc_kface_k, grid, dim3(128), 0, ctx.stream, p, tab, ix, jx, kx, g, nkp, nip);
+  }
+  {
+    dim3 grid((kx + 127) / 128, jx);
+    if (nID[0] < 0) hipLaunchKernelGGL(bc_iface_k, grid, dim3(128), 0, ctx.stream, p, jx, kx, 1, g, nkp, nip);
+    if (nID[1] < 0) hipLaunchKernelGGL(bc_iface_k, grid, dim3(128), 0, ctx.stream, p, jx, kx, ix, g, nkp, nip);
+  }
+  {
+    dim3 grid((kx + 127) / 128, ix);
+    if (nID[2] < 0) hipLaunchKernelGGL(bc_jface_k, grid, dim3(128), 0, ctx.stream, p, ix, kx, 1, g, nkp, nip);
+    if (nID[3] < 0) hipLaunchKernelGGL(bc_jface_k, grid, dim3(128), 0, ctx.stream, p, ix, kx, jx, g, nkp, nip);
+  }
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void jacobi_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, CZ_REAL* omg, CZ_REAL* b, double* res, CZ_REAL* wk2,
+             double* flop) {
+  ensure_init();
+  *flop += 18.0 * npts(idx);  // cz_solver.f90:315-318
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  czhip_jacobi_async(p, wk2, b, sz, idx, *g, cf, *omg, ctx.scal_dev + 0, 0, nullptr);
+  launch_ewise<OP_COPY>(p, wk2, nullptr, (REAL)0, (REAL)0, bx);  // p <- wk2 on the inner box (:369-375)
+  *res += read_scalar(0);                                          // :384 (double accumulation)
+}
+
+void psor2sma_core_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, int* ip, int* color, CZ_REAL* omg, CZ_REAL* b,
+                    double* res, double* flop) {
+  ensure_init();
+  *flop += 18.0 * 0.5 * npts(idx);  // :438-441
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  czhip_rbsor_async(p, b, sz, idx, *g, cf, *ip, *color, *omg, ctx.scal_dev + 0, 0, nullptr);
+  *res += read_scalar(0);
+}
+
+void blas_clear_(CZ_REAL* x, int* sz, int* g) {
+  ensure_init();
+  const size_t n = (size_t)(sz[0] + 2 * *g) * (size_t)(sz[1] + 2 * *g) * (size_t)(sz[2] + 2 * *g);
+  HIP_CHECK(hipMemsetAsync(x, 0, n * sizeof(REAL), ctx.stream));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void blas_copy_(CZ_REAL* dst, CZ_REAL* src, int* sz, int* g) {
+  ensure_init();
+  const size_t n = (size_t)(sz[0] + 2 * *g) * (size_t)(sz[1] + 2 * *g) * (size_t)(sz[2] + 2 * *g);
+  HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(REAL), hipMemcpyDeviceToDevice, ctx.stream));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void blas_triad_(CZ_REAL* z, CZ_REAL* x, CZ_REAL* y, CZ_REAL* a, int* sz, int* idx, int* g, double* flop) {
+  ensure_init();
+  *flop += 2.0 * npts(idx);
+  launch_ewise<OP_TRIAD>(z, x, y, *a, (REAL)0, make_box(sz, idx, *g));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void blas_dot1_(CZ_REAL* r, CZ_REAL* p, int* sz, int* idx, int* g, double* flop) {
+  ensure_init();
+  *flop += 2.0 * npts(idx);
+  launch_dot<0>(p, p, make_box(sz, idx, *g), ctx.scal_dev + 1);
+  *r = (REAL)read_scalar(1);
+}
+
+void blas_dot2_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* q, int* sz, int* idx, int* g, double* flop) {
+  ensure_init();
+  *flop += 2.0 * npts(idx);
+  launch_dot<1>(p, q, make_box(sz, idx, *g), ctx.scal_dev + 1);
+  *r = (REAL)read_scalar(1);
+}
+
+void blas_bicg_1_(CZ_REAL* p, CZ_REAL* r, CZ_REAL* q, CZ_REAL* beta, CZ_REAL* omg, int* sz, int* idx, int* g, double* flop) {
+  ensure_init();
+  *flop += 4.0 * npts(idx);
+  launch_ewise<OP_BICG1>(p, r, q, *beta, *omg, make_box(sz, idx, *g));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void blas_bicg_2_(CZ_REAL* z, CZ_REAL* x, CZ_REAL* y, CZ_REAL* a, CZ_REAL* b, int* sz, int* idx, int* g, double* flop) {
+  ensure_init();
+  *flop += 4.0 * npts(idx);
+  launch_ewise<OP_BICG2>(z, x, y, *a, *b, make_box(sz, idx, *g));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void blas_calc_ax_(CZ_REAL* ap, CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, double* flop) {
+  ensure_init();
+  *flop += 13.0 * npts(idx);
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_stencil<MODE_AX>(p, p, ap, make_coef(cf, (REAL)0), bx, 0, nullptr, nullptr);
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void blas_calc_rk_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g, CZ_REAL* cf, double* flop) {
+  ensure_init();
+  *flop += 14.0 * npts(idx);
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_stencil<MODE_RK>(p, b, r, make_coef(cf, (REAL)0), bx, 0, nullptr, nullptr);
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+}  // extern "C"
+
+// internal hooks for the driver (cz_driver.cpp): asynchronous forms of the blas kernels
+namespace czhip_internal {
+hipStream_t stream() {
+  ensure_init();
+  return ctx.stream;
+}
+void triad_async(REAL* z, const REAL* x, const REAL* y, REAL a, const int* sz, const int* idx, int g) {
+  launch_ewise<OP_TRIAD>(z, x, y, a, (REAL)0, make_box(sz, idx, g));
+}
+void bicg1_async(REAL* p, const REAL* r, const REAL* q, REAL beta, REAL omg, const int* sz, const int* idx, int g) {
+  launch_ewise<OP_BICG1>(p, r, q, beta, omg, make_box(sz, idx, g));
+}
+void bicg2_async(REAL* z, const REAL* x, const REAL* y, REAL a, REAL b, const int* sz, const int* idx, int g) {
+  launch_ewise<OP_BICG2>(z, x, y, a, b, make_box(sz, idx, g));
+}
+void calc_ax_async(REAL* ap, const REAL* p, const int* sz, const int* idx, int g, const REAL* cf) {
+  const Box bx = make_box(sz, idx, g);
+  if (!bx.empty) launch_stencil<MODE_AX>(p, p, ap, make_coef(cf, (REAL)0), bx, 0, nullptr, nullptr);
+}
+void calc_rk_async(REAL* r, const REAL* p, const REAL* b, const int* sz, const int* idx, int g, const REAL* cf) {
+  const Box bx = make_box(sz, idx, g);
+  if (!bx.empty) launch_stencil<MODE_RK>(p, b, r, make_coef(cf, (REAL)0), bx, 0, nullptr, nullptr);
+}
+void dot1_async(const REAL* p, const int* sz, const int* idx, int g, double* dst_dev) {
+  launch_dot<0>(p, p, make_box(sz, idx, g), dst_dev);
+}
+void dot2_async(const REAL* p, const REAL* q, const int* sz, const int* idx, int g, double* dst_dev) {
+  launch_dot<1>(p, q, make_box(sz, idx, g), dst_dev);
+}
+void bc_async(const int* sz, int g, REAL* p, REAL dh, const REAL* org, const int* nID) {
+  // same launches as bc_k_ without the trailing synchronisation
+  const int ix = sz[0], jx = sz[1], kx = sz[2];
+  const int nkp = kx + 2 * g, nip = ix + 2 * g;
+  if (nID[4] < 0 || nID[5] < 0) {
+    const REAL* tab = bc_table(ix, jx, dh, org);
+    dim3 grid((ix + 127) / 128, jx);
+    if (nID[4] < 0) hipLaunchKernelGGL(bc_kface_k, grid, dim3(128), 0, ctx.stream, p, tab, ix, jx, 1, g, nkp, nip);
+    if (nID[5] < 0) hipLaunchKernelGGL(bc_kface_k, grid, dim3(128), 0, ctx.stream, p, tab, ix, jx, kx, g, nkp, nip);
+  }
+  {
+    dim3 grid((kx + 127) / 128, jx);
+    if (nID[0] < 0) hipLaunchKernelGGL(bc_iface_k, grid, dim3(128), 0, ctx.stream, p, jx, kx, 1, g, nkp, nip);
+    if (nID[1] < 0) hipLaunchKernelGGL(bc_iface_k, grid, dim3(128), 0, ctx.stream, p, jx, kx, ix, g, nkp, nip);
+  }
+  {
+    dim3 grid((kx + 127) / 128, ix);
+    if (nID[2] < 0) hipLaunchKernelGGL(bc_jface_k, grid, dim3(128), 0, ctx.stream, p, ix, kx, 1, g, nkp, nip);
+    if (nID[3] < 0) hipLaunchKernelGGL(bc_jface_k, grid, dim3(128), 0, ctx.stream, p, ix, kx, jx, g, nkp, nip);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+}  // namespace czhip_internal

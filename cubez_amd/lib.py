@@ -1,0 +1,174 @@
+"""ctypes binding of include/cz_hip.h (parts 1-3: drop-in kernels, runtime, async operations)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+GUIDE = 2  # /root/reference/src/cz_cpp/cz_Define.h:40
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LOADED: dict = {}
+
+# every symbol include/cz_hip.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_SYMBOLS = [
+    "bc_k_", "jacobi_", "psor2sma_core_", "blas_clear_", "blas_copy_", "blas_triad_", "blas_dot1_", "blas_dot2_",
+    "blas_bicg_1_", "blas_bicg_2_", "blas_calc_ax_", "blas_calc_rk_",
+    "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
+    "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
+    "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async",
+    "cz_create", "cz_destroy", "cz_evaluate", "cz_setup", "cz_solve", "cz_sweeps", "cz_result_iter", "cz_result_res",
+    "cz_history", "cz_field", "cz_local_size", "cz_error_max", "cz_set_quiet", "cz_last_solve_seconds", "cz_kernel_ms",
+]
+
+
+def lib_path(prec: str) -> str:
+    return os.path.join(_HERE, f"libczhip_{prec}.so")
+
+
+def load(prec: str = "f32") -> C.CDLL:
+    """dlopen the HIP library of one precision.  Raises if it has not been built: there is no fallback."""
+    if prec not in _LOADED:
+        path = lib_path(prec)
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing -- build it with `make -C cubez_amd/csrc` "
+                               "(or __graft_entry__.build()); cubez_amd has no CPU fallback")
+        _LOADED[prec] = C.CDLL(path, mode=C.RTLD_LOCAL)
+    return _LOADED[prec]
+
+
+class DeviceArray:
+    """A device-resident S3D array, shape (NJ+4, NI+4, NK+4) K-fastest (czAllocR_S3D, cz.h:209-232)."""
+
+    def __init__(self, hip: "CzHip", sz):
+        self.hip, self.sz = hip, tuple(int(v) for v in sz)
+        self.shape = (self.sz[1] + 2 * GUIDE, self.sz[0] + 2 * GUIDE, self.sz[2] + 2 * GUIDE)
+        self.nbytes = int(np.prod(self.shape)) * hip.real().itemsize
+        arr = (C.c_int * 3)(*self.sz)
+        self.ptr = hip.lib.czhip_alloc_s3d(arr)
+
+    def put(self, host: np.ndarray):
+        assert host.shape == self.shape and host.dtype == self.hip.real
+        host = np.ascontiguousarray(host)
+        self.hip.lib.czhip_h2d(self.ptr, host.ctypes.data_as(C.c_void_p), self.nbytes)
+        return self
+
+    def get(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.hip.real)
+        self.hip.lib.czhip_d2h(out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes)
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip.lib.czhip_free(self.ptr)
+            self.ptr = None
+
+
+class CzHip:
+    """The drop-in kernels with the reference's argument conventions (everything by pointer)."""
+
+    def __init__(self, prec: str = "f32", device: int = -1):
+        self.prec = prec
+        self.real = np.float32 if prec == "f32" else np.float64
+        self.creal = C.c_float if prec == "f32" else C.c_double
+        self.lib = lib = load(prec)
+        lib.czhip_alloc_s3d.restype = C.c_void_p
+        lib.czhip_alloc_s3d.argtypes = [C.POINTER(C.c_int)]
+        lib.czhip_free.argtypes = [C.c_void_p]
+        lib.czhip_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.czhip_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.czhip_stream.restype = C.c_void_p
+        lib.czhip_arch.restype = C.c_char_p
+        assert lib.czhip_real_bytes() == np.dtype(self.real).itemsize
+        if lib.czhip_init(int(device)) != 0:
+            raise RuntimeError("czhip_init failed")
+
+    # -- helpers
+    def alloc(self, sz, host=None) -> DeviceArray:
+        a = DeviceArray(self, sz)
+        if host is not None:
+            a.put(host)
+        return a
+
+    @staticmethod
+    def _i(v):
+        v = np.ascontiguousarray(v, dtype=np.int32)
+        return v, v.ctypes.data_as(C.POINTER(C.c_int))
+
+    def _r(self, v):
+        v = np.ascontiguousarray(v, dtype=self.real)
+        return v, v.ctypes.data_as(C.c_void_p)
+
+    def _s(self, v):
+        return C.byref(self.creal(float(v)))
+
+    def set_tuning(self, threads=0, m=0, tj=-1, pf=-1) -> bool:
+        return self.lib.czhip_set_tuning(int(threads), int(m), int(tj), int(pf)) == 0
+
+    def sync(self):
+        self.lib.czhip_sync()
+
+    # -- part 1: same call shapes as oracle.cz_oracle.Kernels
+    def bc_k(self, sz, p: DeviceArray, dh, org, nID):
+        (_, szp), (_, nidp), (_, orgp), g = self._i(sz), self._i(nID), self._r(org), C.c_int(GUIDE)
+        self.lib.bc_k_(szp, C.byref(g), C.c_void_p(p.ptr), self._s(dh), orgp, nidp)
+
+    def jacobi(self, p, sz, idx, cf, omg, b, wk2, res=0.0):
+        (_, szp), (_, idxp), (_, cfp), g = self._i(sz), self._i(idx), self._r(cf), C.c_int(GUIDE)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self.lib.jacobi_(C.c_void_p(p.ptr), szp, idxp, C.byref(g), cfp, self._s(omg), C.c_void_p(b.ptr), C.byref(r),
+                         C.c_void_p(wk2.ptr), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def psor2sma_core(self, p, sz, idx, cf, ofst, color, omg, b, res=0.0):
+        (_, szp), (_, idxp), (_, cfp), g = self._i(sz), self._i(idx), self._r(cf), C.c_int(GUIDE)
+        r, fl, o, c = C.c_double(res), C.c_double(0.0), C.c_int(ofst), C.c_int(color)
+        self.lib.psor2sma_core_(C.c_void_p(p.ptr), szp, idxp, C.byref(g), cfp, C.byref(o), C.byref(c), self._s(omg),
+                                C.c_void_p(b.ptr), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def blas_clear(self, x, sz):
+        (_, szp), g = self._i(sz), C.c_int(GUIDE)
+        self.lib.blas_clear_(C.c_void_p(x.ptr), szp, C.byref(g))
+
+    def blas_copy(self, y, x, sz):
+        (_, szp), g = self._i(sz), C.c_int(GUIDE)
+        self.lib.blas_copy_(C.c_void_p(y.ptr), C.c_void_p(x.ptr), szp, C.byref(g))
+
+    def blas_triad(self, z, x, y, a, sz, idx):
+        (_, szp), (_, idxp), g, fl = self._i(sz), self._i(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self.lib.blas_triad_(C.c_void_p(z.ptr), C.c_void_p(x.ptr), C.c_void_p(y.ptr), self._s(a), szp, idxp, C.byref(g),
+                             C.byref(fl))
+
+    def blas_dot1(self, p, sz, idx):
+        (_, szp), (_, idxp), g, fl = self._i(sz), self._i(idx), C.c_int(GUIDE), C.c_double(0.0)
+        r = self.creal(0.0)
+        self.lib.blas_dot1_(C.byref(r), C.c_void_p(p.ptr), szp, idxp, C.byref(g), C.byref(fl))
+        return self.real(r.value)
+
+    def blas_dot2(self, p, q, sz, idx):
+        (_, szp), (_, idxp), g, fl = self._i(sz), self._i(idx), C.c_int(GUIDE), C.c_double(0.0)
+        r = self.creal(0.0)
+        self.lib.blas_dot2_(C.byref(r), C.c_void_p(p.ptr), C.c_void_p(q.ptr), szp, idxp, C.byref(g), C.byref(fl))
+        return self.real(r.value)
+
+    def blas_bicg_1(self, p, r, q, beta, omg, sz, idx):
+        (_, szp), (_, idxp), g, fl = self._i(sz), self._i(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self.lib.blas_bicg_1_(C.c_void_p(p.ptr), C.c_void_p(r.ptr), C.c_void_p(q.ptr), self._s(beta), self._s(omg), szp,
+                              idxp, C.byref(g), C.byref(fl))
+
+    def blas_bicg_2(self, z, x, y, a, b, sz, idx):
+        (_, szp), (_, idxp), g, fl = self._i(sz), self._i(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self.lib.blas_bicg_2_(C.c_void_p(z.ptr), C.c_void_p(x.ptr), C.c_void_p(y.ptr), self._s(a), self._s(b), szp, idxp,
+                              C.byref(g), C.byref(fl))
+
+    def blas_calc_ax(self, ap, p, sz, idx, cf):
+        (_, szp), (_, idxp), (_, cfp), g, fl = self._i(sz), self._i(idx), self._r(cf), C.c_int(GUIDE), C.c_double(0.0)
+        self.lib.blas_calc_ax_(C.c_void_p(ap.ptr), C.c_void_p(p.ptr), szp, idxp, C.byref(g), cfp, C.byref(fl))
+
+    def blas_calc_rk(self, r, p, b, sz, idx, cf):
+        (_, szp), (_, idxp), (_, cfp), g, fl = self._i(sz), self._i(idx), self._r(cf), C.c_int(GUIDE), C.c_double(0.0)
+        self.lib.blas_calc_rk_(C.c_void_p(r.ptr), C.c_void_p(p.ptr), C.c_void_p(b.ptr), szp, idxp, C.byref(g), cfp,
+                               C.byref(fl))

@@ -1,0 +1,148 @@
+/*
+ * cz_hip.h -- C-ABI of the MI355X-native CubeZ hot path (libczhip_f32.so / libczhip_f64.so).
+ *
+ * Part 1 is the DROP-IN BOUNDARY: the same `extern "C" void name_(...)` symbols, argument order and
+ * by-pointer conventions as the reference's Fortran interface, /root/reference/src/cz_cpp/cz_Ffunc.h:16-578
+ * (the lines are cited per prototype).  The only change of contract: every 3-D array argument is a
+ * DEVICE pointer obtained from czhip_alloc_s3d() (the replacement of czAllocR_S3D, cz.h:209-232);
+ * sz/idx/g/cf/nID and all scalars stay HOST pointers, `res`/`flop` stay host in/out accumulators,
+ * the dot results stay host outputs.  Every part-1 call is complete (results visible on the host and
+ * in device memory) when it returns, like the Fortran it replaces.
+ *
+ * Part 2 is the runtime the reference does not need on a CPU (device selection, allocation, copies).
+ *
+ * Part 3 is the asynchronous, device-resident form of the same operations that the restated solver
+ * loops (part 4, replacing CZ::JACOBI / RBSOR / PBiCGSTAB of cz_Poisson.cpp) are built from: no host
+ * round trip per sweep, residual history and convergence flag kept on the device.
+ *
+ * Precision is a build-time switch exactly as in the reference (cz_Define.h:28-37,
+ * -D_REAL_IS_DOUBLE_): the f32 and f64 libraries export the same symbol names.
+ *
+ * Memory layout of every 3-D array (cz_solver.f90:29): dense (NK+2g, NI+2g, NJ+2g), K fastest,
+ * lower bound 1-g; linear index of 1-based (k,i,j) = (k+g-1) + (i+g-1)*(NK+2g) + (j+g-1)*(NK+2g)*(NI+2g).
+ */
+#ifndef CZ_HIP_H_
+#define CZ_HIP_H_
+
+#include <stddef.h>
+
+#ifdef CZ_REAL_IS_DOUBLE
+typedef double CZ_REAL;
+#else
+typedef float CZ_REAL;
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1 -- drop-in kernels (replace cz_solver.f90 / cz_blas.f90 behind cz_Ffunc.h)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* cz_Ffunc.h:20-25  <- cz_solver.f90:22-191.  Dirichlet faces where nID[face] < 0. */
+void bc_k_(int* sz, int* g, CZ_REAL* p, CZ_REAL* dh, CZ_REAL* org, int* nID);
+
+/* cz_Ffunc.h:27-36  <- cz_solver.f90:284-387.  One relaxed-Jacobi sweep; result in p AND wk2 (inner box),
+ * *res += sum dp^2, *flop += 18*npts. */
+void jacobi_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, CZ_REAL* omg, CZ_REAL* b, double* res,
+             CZ_REAL* wk2, double* flop);
+
+/* cz_Ffunc.h:48-58  <- cz_solver.f90:404-493.  One colour of red-black SOR, in place. */
+void psor2sma_core_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, int* ip, int* color, CZ_REAL* omg,
+                    CZ_REAL* b, double* res, double* flop);
+
+/* cz_Ffunc.h:448-450 <- cz_blas.f90:112-149 (whole array incl. guide cells) */
+void blas_clear_(CZ_REAL* x, int* sz, int* g);
+/* cz_Ffunc.h:452-455 <- cz_blas.f90:159-195 */
+void blas_copy_(CZ_REAL* dst, CZ_REAL* src, int* sz, int* g);
+/* cz_Ffunc.h:463-470 <- cz_blas.f90:255-308   z = a*x + y */
+void blas_triad_(CZ_REAL* z, CZ_REAL* x, CZ_REAL* y, CZ_REAL* a, int* sz, int* idx, int* g, double* flop);
+/* cz_Ffunc.h:472-477 <- cz_blas.f90:320-373   *r = sum p*p  (r overwritten) */
+void blas_dot1_(CZ_REAL* r, CZ_REAL* p, int* sz, int* idx, int* g, double* flop);
+/* cz_Ffunc.h:479-485 <- cz_blas.f90:386-437   *r = sum p*q */
+void blas_dot2_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* q, int* sz, int* idx, int* g, double* flop);
+/* cz_Ffunc.h:487-495 <- cz_blas.f90:452-502   p = r + beta*(p - omg*q) */
+void blas_bicg_1_(CZ_REAL* p, CZ_REAL* r, CZ_REAL* q, CZ_REAL* beta, CZ_REAL* omg, int* sz, int* idx, int* g,
+                  double* flop);
+/* cz_Ffunc.h:497-505 <- cz_blas.f90:517-566   z = a*x + b*y + z */
+void blas_bicg_2_(CZ_REAL* z, CZ_REAL* x, CZ_REAL* y, CZ_REAL* a, CZ_REAL* b, int* sz, int* idx, int* g,
+                  double* flop);
+/* cz_Ffunc.h:507-513 <- cz_blas.f90:579-644   ap = ss - dd*p */
+void blas_calc_ax_(CZ_REAL* ap, CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, double* flop);
+/* cz_Ffunc.h:515-522 <- cz_blas.f90:658-723   r = b - (ss - dd*p) */
+void blas_calc_rk_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g, CZ_REAL* cf, double* flop);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2 -- runtime
+ * ---------------------------------------------------------------------------------------------- */
+int czhip_real_bytes(void);              /* 4 or 8: which precision this library was built for */
+const char* czhip_arch(void);            /* "gfx950" */
+int czhip_init(int device);              /* bind the calling process to one GPU, create streams/workspace; 0 = ok.
+                                            Any HIP failure anywhere prints a message and exit(1)s: the
+                                            reference ABI has no error channel. */
+void czhip_finalize(void);
+CZ_REAL* czhip_alloc_s3d(const int* sz); /* czAllocR_S3D (cz.h:209-232): (NI+4)(NJ+4)(NK+4) zero-filled, on the device */
+void czhip_free(void* dptr);
+void czhip_h2d(void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
+void czhip_d2h(void* dst_host, const void* src_dev, size_t bytes); /* synchronous (drains the compute stream first) */
+void czhip_sync(void);                   /* drain all library streams */
+void* czhip_stream(void);                /* the hipStream_t every kernel of this library is launched on */
+
+/* Tuning of the stencil kernels (threads per block, vectors per thread, planes per j-chunk, prefetch
+ * depth).  0 keeps the current value.  Returns 0 if that instantiation exists. */
+int czhip_set_tuning(int threads, int vec_per_thread, int planes_per_chunk, int prefetch);
+void czhip_get_tuning(int* threads, int* vec_per_thread, int* planes_per_chunk, int* prefetch);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 3 -- asynchronous device-resident operations (stream-ordered, no host synchronisation)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* One Jacobi sweep p_in -> p_out (ping-pong; p_out's non-inner elements are left untouched), sum dp^2
+ * accumulated in double into res_dev[0] (device) when `accumulate` != 0, else stored.  If skip_flag_dev
+ * is non-NULL and *skip_flag_dev != 0 on the device the sweep is a no-op (convergence reached earlier). */
+void czhip_jacobi_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g,
+                        const CZ_REAL* cf, CZ_REAL omg, double* res_dev, int accumulate, const int* skip_flag_dev);
+
+/* One colour of RB-SOR in place; parity: points with (i+j+k+ofst+color) even relative to kst as in
+ * cz_solver.f90:466. */
+void czhip_rbsor_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf,
+                       int ofst, int color, CZ_REAL omg, double* res_dev, int accumulate, const int* skip_flag_dev);
+
+/* Convergence bookkeeping on the device (cz_Poisson.cpp:67-77): res = sqrt(res_dev[0]*res_normal);
+ * hist_dev[itr] = res; if (res < eps && !*flag) { *flag = 1; conv_itr_dev[0] = itr; }.  No-op when
+ * already converged. */
+void czhip_check_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev,
+                       int* flag_dev, int* conv_itr_dev);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 4 -- the restated driver (class CZ of cz.h / cz_Evaluate.cpp / cz_Poisson.cpp) behind a handle
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct cz_handle cz_handle;
+
+cz_handle* cz_create(void);
+void cz_destroy(cz_handle*);
+/* main.cpp:15-60 + CZ::Evaluate (cz_Evaluate.cpp:21-567): same argv as the reference CLI
+ *   cz gsz_x gsz_y gsz_z solver ItrMax coef [precond] [gdv_x gdv_y gdv_z]
+ * returns 1 on success, 0 on "Solver error" exactly like CZ::Evaluate. */
+int cz_evaluate(cz_handle*, int argc, char** argv);
+/* Split form used by bench.py / tests: setup (parse + allocate + boundary conditions), then solve. */
+int cz_setup(cz_handle*, int argc, char** argv);
+int cz_solve(cz_handle*);                      /* runs the selected solver to ItrMax / eps; returns Iter (0 = error) */
+int cz_sweeps(cz_handle*, int n);              /* bench leg: n more iterations of the selected stationary solver with the
+                                                  full per-iteration work (sweep + residual + convergence bookkeeping),
+                                                  never stopping early; returns n */
+int cz_result_iter(const cz_handle*);
+double cz_result_res(const cz_handle*);
+int cz_history(const cz_handle*, double* out, int cap); /* copies min(cap, n) residuals, returns n */
+void cz_field(const cz_handle*, CZ_REAL* host_out);    /* D2H of the solution P, dense (NK+4,NI+4,NJ+4) */
+void cz_local_size(const cz_handle*, int* size3, int* head3, int* nID6, int* inner6);
+double cz_error_max(cz_handle*, int* loc3);   /* debug epilogue, cz_Evaluate.cpp:550-563 (host-side restatement) */
+void cz_set_quiet(cz_handle*, int quiet);     /* suppress stdout / history file (tests, bench) */
+double cz_last_solve_seconds(const cz_handle*);
+double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CZ_HIP_H_ */

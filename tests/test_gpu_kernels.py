@@ -1,0 +1,235 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every drop-in kernel of libczhip, called through
+the C-ABI with the reference's argument conventions, against the CPU oracle on the same inputs.
+
+Bar (SURVEY.md 8c tolerance chain): fields BIT-EXACT (kernels are built with -ffp-contract=off and
+IEEE division); residuals / dot products are accumulated in double on the GPU in a fixed tree order,
+so they are compared with the oracle's double accumulation of the same REAL-rounded terms to
+1e-12 relative (pure summation-order noise in double), and with the reference's REAL-accumulated
+value to the order-of-summation tolerance of the precision (1e-3 FP32 / 1e-10 FP64)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cz_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+RTOL_WIDE = 1e-12
+
+
+def _beq(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def _hip(prec):
+    from cubez_amd import CzHip
+    return CzHip(prec)
+
+
+def _rel(a, b):
+    return abs(a - b) / max(abs(b), 1e-300)
+
+
+def _real_tol(prec):
+    return 1e-3 if prec == "f32" else 1e-10
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_golden_vectors(prec):
+    """the reference-generated vectors of tests/golden/kernels_*.npz through the HIP library."""
+    g = np.load(os.path.join(GOLDEN, f"kernels_{prec}.npz"))
+    h = _hip(prec)
+    sz, idx, cf, omg = list(g["sz"]), list(g["idx"]), g["cf"], float(g["omg"])
+    p, b, q, x, y, z = (g[n] for n in ("in_p", "in_b", "in_q", "in_x", "in_y", "in_z"))
+    dp, db, dq, dx, dy = (h.alloc(sz, a) for a in (p, b, q, x, y))
+
+    pj, wk = h.alloc(sz, p), h.alloc(sz, np.zeros_like(p))
+    res = h.jacobi(pj, sz, idx, cf, omg, db, wk, res=0.25)
+    assert _beq(pj.get(), g["jacobi_p"]) and _beq(wk.get(), g["jacobi_wk2"])
+    assert h.last_flop == float(g["jacobi_flop"])
+    assert _rel(res, float(g["jacobi_res"])) < _real_tol(prec)
+
+    for ofst in (0, 1):
+        ps, r = h.alloc(sz, p), 0.0
+        for color in (0, 1):
+            r = h.psor2sma_core(ps, sz, idx, cf, ofst, color, omg, db, res=r)
+            assert _beq(ps.get(), g[f"rb{ofst}_p_c{color}"])
+            assert _rel(r, float(g[f"rb{ofst}_res_c{color}"])) < _real_tol(prec)
+
+    out = h.alloc(sz, np.zeros_like(p))
+    h.blas_calc_ax(out, dp, sz, idx, cf)
+    assert _beq(out.get(), g["calc_ax"])
+    out.put(np.zeros_like(p))
+    h.blas_calc_rk(out, dp, db, sz, idx, cf)
+    assert _beq(out.get(), g["calc_rk"])
+    assert _rel(float(h.blas_dot1(dp, sz, idx)), float(g["dot1"])) < _real_tol(prec)
+    assert _rel(float(h.blas_dot2(dp, dq, sz, idx)), float(g["dot2"])) < _real_tol(prec)
+    zt = h.alloc(sz, z)
+    h.blas_triad(zt, dx, dy, -0.37, sz, idx)
+    assert _beq(zt.get(), g["triad"])
+    pb = h.alloc(sz, p)
+    h.blas_bicg_1(pb, dx, dq, 0.61, -1.3, sz, idx)
+    assert _beq(pb.get(), g["bicg_1"])
+    zb = h.alloc(sz, z)
+    h.blas_bicg_2(zb, dx, dy, 0.45, -0.77, sz, idx)
+    assert _beq(zb.get(), g["bicg_2"])
+    c = h.alloc(sz, p)
+    h.blas_clear(c, sz)
+    assert _beq(c.get(), g["clear"])
+    d = h.alloc(sz, np.zeros_like(p))
+    h.blas_copy(d, dp, sz)
+    assert _beq(d.get(), g["copy"])
+    for tag, nid, org in (("all", [-1] * 6, [0.0, 0.0, 0.0]), ("mix", [3, -1, -1, 5, -1, 2], [0.25, 0.5, 0.0])):
+        pc = h.alloc(sz, p)
+        h.bc_k(sz, pc, 1.0 / (sz[2] - 1), org, nid)
+        assert _beq(pc.get(), g[f"bc_{tag}"])
+
+
+# (NI, NJ, NK), idx or None for the single-domain inner box
+BOXES = [
+    ((5, 4, 6), None),               # tiny, V=1 path (NK+4 = 10)
+    ((9, 12, 7), None),              # odd sizes, V=1 (f32) path
+    ((16, 8, 32), None),             # NK+4 = 36: vector path, single segment
+    ((40, 36, 60), None),            # several segments and chunks
+    ((33, 70, 124), None),           # NK+4 = 128
+    ((24, 20, 28), (1, 24, 1, 20, 1, 28)),   # interior rank of a decomposition: box = all owned cells
+    ((24, 20, 28), (1, 23, 2, 20, 1, 27)),   # mixed physical / interior faces
+    ((12, 10, 20), (3, 2, 2, 9, 2, 19)),     # empty range (ied < ist): nothing may change
+    ((130, 20, 252), None),          # long rows: R = 64
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'+str(i)}" for i, b in enumerate(BOXES)])
+def test_random_boxes_vs_oracle(prec, box):
+    (ni, nj, nk), idx = box
+    sz = [ni, nj, nk]
+    if idx is None:
+        idx = [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    idx = list(idx)
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni * 10007 + nj * 101 + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    cf = rng.uniform(0.5, 1.5, 7).astype(R)
+    cf[6] = 6.2
+    p, b, q = (rng.uniform(-1, 1, shape).astype(R) for _ in range(3))
+    dp, db, dq = h.alloc(sz, p), h.alloc(sz, b), h.alloc(sz, q)
+    sentinel = rng.uniform(-1, 1, shape).astype(R)  # outputs must keep their non-inner elements
+
+    # jacobi (drop-in semantics: result in p and wk2, res accumulated)
+    a1, w1, wide = p.copy(), sentinel.copy(), np.zeros(1)
+    r1 = ko.jacobi(a1, sz, idx, cf, 0.9, b, w1, res=1.5, wide=wide)
+    a2, w2 = h.alloc(sz, p), h.alloc(sz, sentinel)
+    r2 = h.jacobi(a2, sz, idx, cf, 0.9, db, w2, res=1.5)
+    assert _beq(a2.get(), a1) and _beq(w2.get(), w1)
+    assert h.last_flop == ko.last_flop
+    if wide[0] > 0:
+        assert _rel(r2 - 1.5, wide[0]) < RTOL_WIDE * 10
+        assert _rel(r2, r1) < _real_tol(prec)
+    else:
+        assert r2 == 1.5
+
+    # red-black, both offsets, both colours
+    for ofst in (0, 1):
+        a1, a2, r1, r2, wide = p.copy(), h.alloc(sz, p), 0.0, 0.0, np.zeros(1)
+        for color in (0, 1):
+            r1 = ko.psor2sma_core(a1, sz, idx, cf, ofst, color, 1.3, b, res=r1, wide=wide)
+            r2 = h.psor2sma_core(a2, sz, idx, cf, ofst, color, 1.3, db, res=r2)
+            assert _beq(a2.get(), a1), (ofst, color)
+            if wide[0] > 0:
+                assert _rel(r2, wide[0]) < RTOL_WIDE * 10
+
+    # SpMV / residual
+    o1, o2 = sentinel.copy(), h.alloc(sz, sentinel)
+    ko.blas_calc_ax(o1, p, sz, idx, cf), h.blas_calc_ax(o2, dp, sz, idx, cf)
+    assert _beq(o2.get(), o1)
+    o1, o2 = sentinel.copy(), h.alloc(sz, sentinel)
+    ko.blas_calc_rk(o1, p, b, sz, idx, cf), h.blas_calc_rk(o2, dp, db, sz, idx, cf)
+    assert _beq(o2.get(), o1)
+
+    # dots: GPU accumulates in double, rounds once to REAL
+    wide = np.zeros(1)
+    d1 = ko.blas_dot1(p, sz, idx, wide=wide)
+    d2 = h.blas_dot1(dp, sz, idx)
+    assert d2 == R(wide[0]) or _rel(float(d2), wide[0]) < (1.3e-7 if prec == "f32" else 1e-15)
+    assert _rel(float(d2), float(d1)) < _real_tol(prec) or float(d1) == 0.0
+    wide = np.zeros(1)
+    d1 = ko.blas_dot2(p, q, sz, idx, wide=wide)
+    d2 = h.blas_dot2(dp, dq, sz, idx)
+    assert d2 == R(wide[0]) or abs(float(d2) - wide[0]) <= 1e-6 * max(1.0, abs(wide[0]))
+
+    # axpy family
+    o1, o2 = sentinel.copy(), h.alloc(sz, sentinel)
+    ko.blas_triad(o1, p, b, -0.3, sz, idx), h.blas_triad(o2, dp, db, -0.3, sz, idx)
+    assert _beq(o2.get(), o1)
+    o1, o2 = q.copy(), h.alloc(sz, q)
+    ko.blas_bicg_1(o1, p, b, 0.3, 0.7, sz, idx), h.blas_bicg_1(o2, dp, db, 0.3, 0.7, sz, idx)
+    assert _beq(o2.get(), o1)
+    ko.blas_bicg_2(o1, p, b, 0.3, 0.7, sz, idx), h.blas_bicg_2(o2, dp, db, 0.3, 0.7, sz, idx)
+    assert _beq(o2.get(), o1)
+
+    # boundary condition with a mixed neighbour table and non-zero origin
+    for nid in ([-1] * 6, [0, 1, -1, -1, 2, -1], [-1, 4, 2, -1, -1, 7]):
+        o1, o2 = p.copy(), h.alloc(sz, p)
+        ko.bc_k(sz, o1, 0.125, [0.1, 0.2, 0.3], nid), h.bc_k(sz, o2, 0.125, [0.1, 0.2, 0.3], nid)
+        assert _beq(o2.get(), o1)
+    for a in (dp, db, dq):
+        a.free()
+
+
+TUNINGS = [(256, 1, 0, 0), (256, 1, 3, 1), (256, 2, 0, 0), (256, 2, 5, 1), (256, 4, 0, 0), (256, 4, 2, 1),
+           (512, 1, 0, 1), (512, 2, 7, 0), (512, 4, 0, 1), (1024, 1, 0, 0), (1024, 2, 4, 1)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_all_tunings_bit_identical(prec):
+    """every compiled (threads, vectors/thread, chunk, prefetch) variant of the sweep gives the same bits."""
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    sz = [70, 45, 124]
+    idx = [2, 69, 2, 44, 2, 123]
+    rng = np.random.default_rng(99)
+    shape = (sz[1] + 4, sz[0] + 4, sz[2] + 4)
+    cf = np.array([1.1, 0.9, 1.05, 0.95, 1.2, 0.8, 6.3], dtype=R)
+    p, b = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    db = h.alloc(sz, b)
+    a1, w1, wide = p.copy(), np.zeros_like(p), np.zeros(1)
+    ko.jacobi(a1, sz, idx, cf, 0.8, b, w1, wide=wide)
+    s1 = p.copy()
+    for color in (0, 1):
+        ko.psor2sma_core(s1, sz, idx, cf, 0, color, 1.4, b)
+    try:
+        for (tb, m, tj, pf) in TUNINGS:
+            assert h.set_tuning(tb, m, tj, pf), (tb, m, tj, pf)
+            a2, w2 = h.alloc(sz, p), h.alloc(sz, np.zeros_like(p))
+            r2 = h.jacobi(a2, sz, idx, cf, 0.8, db, w2)
+            assert _beq(a2.get(), a1), (tb, m, tj, pf)
+            assert _rel(r2, wide[0]) < RTOL_WIDE * 10
+            s2 = h.alloc(sz, p)
+            for color in (0, 1):
+                h.psor2sma_core(s2, sz, idx, cf, 0, color, 1.4, db)
+            assert _beq(s2.get(), s1), (tb, m, tj, pf)
+            for a in (a2, w2, s2):
+                a.free()
+    finally:
+        h.set_tuning(256, 2, 0, 1)
+
+
+def test_residual_is_run_to_run_deterministic():
+    h = _hip("f32")
+    sz = [64, 64, 60]
+    idx = [2, 63, 2, 63, 2, 59]
+    rng = np.random.default_rng(5)
+    shape = (sz[1] + 4, sz[0] + 4, sz[2] + 4)
+    p, b = (rng.uniform(-1, 1, shape).astype(np.float32) for _ in range(2))
+    cf = np.array([1, 1, 1, 1, 1, 1, 6], dtype=np.float32)
+    db = h.alloc(sz, b)
+    vals = set()
+    for _ in range(5):
+        a, w = h.alloc(sz, p), h.alloc(sz, np.zeros_like(p))
+        vals.add(h.jacobi(a, sz, idx, cf, 0.8, db, w))
+        a.free(), w.free()
+    assert len(vals) == 1
