@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the CubeZ hot path on MI355X (contract: see the task statement / DESIGN.md 6).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one relaxed-Jacobi sweep of the FP32 cube with everything the reference's checked loop does per
+iteration (sweep, residual reduction, normalise + history + eps test; cz_Poisson.cpp:39-79), inputs resident in HBM.
+N=1: BASELINE.json configs[1], `cz 512 512 512 jacobi K 0.8`.  N>1: weak scaling, 512^3 cells per GPU
+(2: 1x2x1, 4: 2x2x1, 8: 2x2x2 = configs[4], the 1024^3 cube), halo exchange + residual all-reduce over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--steps", type=int, default=100)
+ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--n", type=int, default=512, help="cells per GPU and axis")
+ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma"])
+ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
+ap.add_argument("--no-cpu-baseline", action="store_true")
+ap.add_argument("--cpu-seconds", type=float, default=12.0)
+args = ap.parse_args()
+
+rank = int(os.environ.get("RANK", "0"))
+world = int(os.environ.get("WORLD_SIZE", "1"))
+local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+if world != args.gpus and world > 1:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+if args.gpus > 1 and world == 1:
+    raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N (one rank per GPU)")
+
+import torch  # noqa: E402  (plumbing only: rendezvous, barrier, max-reduce of the timings)
+import torch.distributed as dist  # noqa: E402
+
+from cubez_amd import CZ  # noqa: E402
+
+DIVS = {1: (1, 1, 1), 2: (1, 2, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+if world not in DIVS:
+    raise SystemExit("supported GPU counts: 1, 2, 4, 8")
+div = DIVS[world]
+n = args.n
+gsz = [n * div[0], n * div[1], n * div[2]]
+coef = 0.8 if args.solver == "jacobi" else 1.5
+
+cz = CZ(args.prec, quiet=True, device=local_rank)
+lib = cz.lib
+if world > 1:
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    nb = lib.cz_comm_unique_id_bytes()
+    buf = C.create_string_buffer(nb)
+    if rank == 0:
+        lib.cz_comm_get_unique_id(buf)
+    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    dist.broadcast(t, src=0)
+    lib.cz_comm_bootstrap(rank, world, bytes(t.numpy().tobytes()))
+
+argv = gsz + [args.solver, args.steps + args.warmup, coef]
+if world > 1:
+    argv += list(div)
+assert cz.setup(argv) == 1, "cz_setup failed"
+loc = cz.local()
+inner = loc["inner"]
+my_points = (inner[1] - inner[0] + 1) * (inner[3] - inner[2] + 1) * (inner[5] - inner[4] + 1)
+
+
+def barrier():
+    lib.czhip_sync()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+
+
+cz.sweeps(args.warmup)
+barrier()
+cz.timing(True)
+t0 = time.perf_counter()
+cz.sweeps(args.steps)
+barrier()
+dt = time.perf_counter() - t0
+nk, kern_ms = cz.timing_read("jacobi" if args.solver == "jacobi" else "rbsor")
+cz.timing(False)
+
+tot_points = float(my_points)
+if world > 1:
+    tt = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0])
+    tp = torch.tensor([tot_points], dtype=torch.float64)
+    dist.all_reduce(tp, op=dist.ReduceOp.SUM)
+    tot_points = float(tp[0])
+
+if rank == 0:
+    word = 4 if args.prec == "f32" else 8
+    # algorithmic bytes per lattice update: Jacobi reads p and b once, writes p' once = 3 words;
+    # one RB-SOR colour launch updates half the points of the box: 4 words per point and iteration = 2 per launch
+    launches_per_step = 1 if args.solver == "jacobi" else 2
+    alg_bytes_per_launch = my_points * word * (3 if args.solver == "jacobi" else 2)
+    kern_avg_s = (kern_ms / nk) * 1e-3 if nk else float("nan")
+    achieved = alg_bytes_per_launch / kern_avg_s / 1e9 if nk else None
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            rec = json.load(open(tfile))
+            key = f"{args.solver}_{n}_{args.prec}"
+            if key in rec:
+                traffic = rec[key]["bytes_per_launch"]
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "MLUPS (lattice updates/s), 512^3 FP32 Jacobi per GPU" if args.solver == "jacobi" and args.prec == "f32" and n == 512
+        else f"MLUPS (lattice updates/s), {n}^3 {args.prec} {args.solver} per GPU",
+        "value": tot_points * args.steps / dt / 1e6,
+        "unit": "MLUPS",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.prec,
+        "data": "synthetic (the reference problem: P=0, Dirichlet sin(pi x)sin(pi y) on z faces, RHS=0)",
+        "config": {"workload": f"cz {gsz[0]} {gsz[1]} {gsz[2]} {args.solver} {args.steps} {coef}" + (f" {div[0]} {div[1]} {div[2]}" if world > 1 else ""),
+                   "cells_per_gpu": f"{n}^3", "division": list(div), "global_grid": gsz,
+                   "step": "one sweep + residual reduction + convergence bookkeeping (cz_Poisson.cpp:39-79)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                     "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
+                     "kernel": "stencil_k<jacobi>" if args.solver == "jacobi" else "stencil_k<rbsor colour>",
+                     "kernel_avg_ms": kern_avg_s * 1e3, "kernel_launches_timed": nk,
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--n", str(n), "--solver", args.solver,
+                                "--prec", args.prec, "--seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)
+            out["cpu_baseline"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:  # the baseline is reporting only; never lose the GPU line over it
+            out["cpu_baseline"] = {"value": None, "unit": "MLUPS", "cores": None, "kind": "port", "sample": f"failed: {e}"}
+    print(json.dumps(out))
+
+cz.close()
+if world > 1:
+    lib.cz_comm_shutdown()
+    dist.destroy_process_group()

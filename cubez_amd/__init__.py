@@ -5,6 +5,7 @@ kernels behind the reference's own ``cz_Ffunc.h`` operator boundary plus the res
 loops.  This package is only the thin ctypes binding used by the tests, ``bench.py`` and the
 Python launcher; there is no CPU fallback -- loading fails loudly when the library is missing.
 """
+from .driver import CZ  # noqa: F401
 from .lib import CzHip, DeviceArray, GUIDE, lib_path, load  # noqa: F401
 
-__all__ = ["CzHip", "DeviceArray", "GUIDE", "lib_path", "load"]
+__all__ = ["CZ", "CzHip", "DeviceArray", "GUIDE", "lib_path", "load"]

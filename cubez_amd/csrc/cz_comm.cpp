@@ -1,0 +1,378 @@
+// cz_comm.cpp -- see cz_comm.h.  Face geometry (K-fastest layout, cz_solver.f90:29):
+//   J faces  are contiguous: rows i=1..NI of plane j  -> sent/received in place, no pack kernel
+//   I faces  are NJ runs of NK elements (one k-row per j)        -> packed [j][k]
+//   K faces  are fully strided (one element per (i,j))            -> packed [j][i]
+// Only owned cells travel (no edges/corners): the 7-point stencil never reads them.
+#include "cz_comm.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "cz_internal.h"
+
+#define NCCL_CHECK(expr)                                                                              \
+  do {                                                                                                \
+    ncclResult_t r_ = (expr);                                                                         \
+    if (r_ != ncclSuccess) {                                                                          \
+      fprintf(stderr, "czhip: RCCL error %d (%s) at %s:%d: %s\n", (int)r_, ncclGetErrorString(r_), __FILE__, \
+              __LINE__, #expr);                                                                       \
+      exit(1);                                                                                        \
+    }                                                                                                 \
+  } while (0)
+
+namespace {
+
+// ---- in-process world (LOCAL transport)
+struct LocalWorld {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  long generation = 0;
+  std::vector<CommCtx*> ranks;
+  std::vector<double> red;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long gen = generation;
+    if (++arrived == n) {
+      arrived = 0;
+      generation++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
+enum Transport { T_NONE = 0, T_RCCL = 1, T_LOCAL = 2 };
+
+struct Boot {
+  Transport tr = T_NONE;
+  int rank = 0, nproc = 1;
+  ncclComm_t nccl = nullptr;
+  LocalWorld* world = nullptr;
+};
+thread_local Boot boot;
+
+template <typename T>
+__global__ void pack_iface_k(T* __restrict__ buf, const T* __restrict__ X, int NK, int NJ, int nkp, int nip, int ii, int g,
+                             const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;  // 0..NK-1
+  const int j = blockIdx.y;                             // 0..NJ-1
+  if (k >= NK) return;
+  buf[(size_t)j * NK + k] = X[(size_t)(k + g) + (size_t)ii * nkp + (size_t)(j + g) * nkp * nip];
+}
+template <typename T>
+__global__ void unpack_iface_k(T* __restrict__ X, const T* __restrict__ buf, int NK, int NJ, int nkp, int nip, int ii, int g,
+                               const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (k >= NK) return;
+  X[(size_t)(k + g) + (size_t)ii * nkp + (size_t)(j + g) * nkp * nip] = buf[(size_t)j * NK + k];
+}
+template <typename T>
+__global__ void pack_kface_k(T* __restrict__ buf, const T* __restrict__ X, int NI, int NJ, int nkp, int nip, int kk, int g,
+                             const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i >= NI) return;
+  buf[(size_t)j * NI + i] = X[(size_t)kk + (size_t)(i + g) * nkp + (size_t)(j + g) * nkp * nip];
+}
+template <typename T>
+__global__ void unpack_kface_k(T* __restrict__ X, const T* __restrict__ buf, int NI, int NJ, int nkp, int nip, int kk, int g,
+                               const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (i >= NI) return;
+  X[(size_t)kk + (size_t)(i + g) * nkp + (size_t)(j + g) * nkp * nip] = buf[(size_t)j * NI + i];
+}
+
+}  // namespace
+
+struct CommCtx {
+  Transport tr;
+  int rank, nproc, eb;
+  int size[3], nID[6];
+  int g = 2;
+  size_t face_elems[6];
+  void* sendbuf[6] = {nullptr};
+  void* recvbuf[6] = {nullptr};
+  ncclComm_t nccl = nullptr;
+  LocalWorld* world = nullptr;
+  void* cur_X = nullptr;  // LOCAL: array being exchanged, published for the neighbours' J-face copies
+  double* h_red = nullptr;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+void comm_world(int* rank, int* nproc) {
+  *rank = boot.rank;
+  *nproc = boot.nproc;
+}
+
+void comm_auto_division(int nproc, const int G[3], int D[3]) {
+  double best = -1.0;
+  int bd[3] = {1, 1, nproc};
+  for (int di = 1; di <= nproc; di++) {
+    if (nproc % di) continue;
+    for (int dj = 1; dj <= nproc / di; dj++) {
+      if ((nproc / di) % dj) continue;
+      const int dk = nproc / di / dj;
+      if (di > G[0] / 2 || dj > G[1] / 2 || dk > G[2] / 2) continue;
+      // exchanged elements per brick (both directions folded): cut faces only; packed faces cost a little more
+      const double li = (double)G[0] / di, lj = (double)G[1] / dj, lk = (double)G[2] / dk;
+      double cost = 0.0;
+      if (dj > 1) cost += li * lk * 1.00;  // J face: contiguous
+      if (di > 1) cost += lj * lk * 1.02;  // I face: k-rows
+      if (dk > 1) cost += li * lj * 1.05;  // K face: strided
+      if (best < 0 || cost < best) {
+        best = cost;
+        bd[0] = di, bd[1] = dj, bd[2] = dk;
+      }
+    }
+  }
+  D[0] = bd[0], D[1] = bd[1], D[2] = bd[2];
+}
+
+bool comm_decompose(const int G[3], const int D[3], int nproc, int rank, int size[3], int head[3], int nID[6]) {
+  if (D[0] < 1 || D[1] < 1 || D[2] < 1 || D[0] * D[1] * D[2] != nproc || rank < 0 || rank >= nproc) return false;
+  int r[3] = {rank % D[0], (rank / D[0]) % D[1], rank / (D[0] * D[1])};
+  for (int a = 0; a < 3; a++) {
+    const int base = G[a] / D[a], rem = G[a] % D[a];
+    if (base < 2) return false;  // every brick needs an inner point next to each face
+    size[a] = base + (r[a] < rem ? 1 : 0);
+    head[a] = r[a] * base + std::min(r[a], rem) + 1;
+  }
+  auto rk = [&](int a, int b, int c) { return a + D[0] * (b + D[1] * c); };
+  nID[0] = r[0] > 0 ? rk(r[0] - 1, r[1], r[2]) : -1;
+  nID[1] = r[0] < D[0] - 1 ? rk(r[0] + 1, r[1], r[2]) : -1;
+  nID[2] = r[1] > 0 ? rk(r[0], r[1] - 1, r[2]) : -1;
+  nID[3] = r[1] < D[1] - 1 ? rk(r[0], r[1] + 1, r[2]) : -1;
+  nID[4] = r[2] > 0 ? rk(r[0], r[1], r[2] - 1) : -1;
+  nID[5] = r[2] < D[2] - 1 ? rk(r[0], r[1], r[2] + 1) : -1;
+  return true;
+}
+
+CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], int elem_bytes) {
+  if (boot.tr == T_NONE || boot.nproc != nproc) {
+    fprintf(stderr, "czhip: %d ranks requested but no communicator was bootstrapped (cz_comm_bootstrap*)\n", nproc);
+    return nullptr;
+  }
+  CommCtx* c = new CommCtx();
+  c->tr = boot.tr, c->rank = rank, c->nproc = nproc, c->eb = elem_bytes;
+  c->nccl = boot.nccl, c->world = boot.world;
+  for (int a = 0; a < 3; a++) c->size[a] = size[a];
+  for (int f = 0; f < 6; f++) c->nID[f] = nID[f];
+  const size_t NI = size[0], NJ = size[1], NK = size[2];
+  c->face_elems[0] = c->face_elems[1] = NJ * NK;
+  c->face_elems[2] = c->face_elems[3] = NI * (NK + 2 * c->g);  // in-place rows incl. k guide cells
+  c->face_elems[4] = c->face_elems[5] = NI * NJ;
+  for (int f = 0; f < 6; f++) {
+    if (nID[f] < 0 || f == 2 || f == 3) continue;
+    HIP_CHECK(hipMalloc(&c->sendbuf[f], c->face_elems[f] * elem_bytes));
+    HIP_CHECK(hipMalloc(&c->recvbuf[f], c->face_elems[f] * elem_bytes));
+  }
+  HIP_CHECK(hipHostMalloc(&c->h_red, 16 * sizeof(double), hipHostMallocDefault));
+  if (c->tr == T_LOCAL) {
+    std::lock_guard<std::mutex> lk(c->world->mu);
+    c->world->ranks[rank] = c;
+  }
+  return c;
+}
+
+void comm_destroy(CommCtx* c) {
+  if (!c) return;
+  for (int f = 0; f < 6; f++) {
+    if (c->sendbuf[f]) (void)hipFree(c->sendbuf[f]);
+    if (c->recvbuf[f]) (void)hipFree(c->recvbuf[f]);
+  }
+  (void)hipHostFree(c->h_red);
+  delete c;
+}
+
+namespace {
+template <typename T>
+void pack_faces(CommCtx* c, const T* X, const int* skip, hipStream_t st) {
+  const int NI = c->size[0], NJ = c->size[1], NK = c->size[2], g = c->g;
+  const int nkp = NK + 2 * g, nip = NI + 2 * g;
+  // owned boundary layers: i = 1 / NI, k = 1 / NK (1-based) -> padded index +g-1
+  if (c->nID[0] >= 0) hipLaunchKernelGGL(pack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[0], X, NK, NJ, nkp, nip, g, g, skip);
+  if (c->nID[1] >= 0) hipLaunchKernelGGL(pack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[1], X, NK, NJ, nkp, nip, NI + g - 1, g, skip);
+  if (c->nID[4] >= 0) hipLaunchKernelGGL(pack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[4], X, NI, NJ, nkp, nip, g, g, skip);
+  if (c->nID[5] >= 0) hipLaunchKernelGGL(pack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[5], X, NI, NJ, nkp, nip, NK + g - 1, g, skip);
+  HIP_CHECK(hipGetLastError());
+}
+template <typename T>
+void unpack_faces(CommCtx* c, T* X, const int* skip, hipStream_t st) {
+  const int NI = c->size[0], NJ = c->size[1], NK = c->size[2], g = c->g;
+  const int nkp = NK + 2 * g, nip = NI + 2 * g;
+  // ghost layers: i = 0 / NI+1, k = 0 / NK+1 (1-based) -> padded index g-1 / N+g
+  if (c->nID[0] >= 0) hipLaunchKernelGGL(unpack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[0], NK, NJ, nkp, nip, g - 1, g, skip);
+  if (c->nID[1] >= 0) hipLaunchKernelGGL(unpack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[1], NK, NJ, nkp, nip, NI + g, g, skip);
+  if (c->nID[4] >= 0) hipLaunchKernelGGL(unpack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[4], NI, NJ, nkp, nip, g - 1, g, skip);
+  if (c->nID[5] >= 0) hipLaunchKernelGGL(unpack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[5], NI, NJ, nkp, nip, NK + g, g, skip);
+  HIP_CHECK(hipGetLastError());
+}
+// J faces in place: element offset of row i=1 (1-based) of plane j (1-based), k from the first guide cell
+inline size_t jface_off(const CommCtx* c, int j1) {
+  const size_t nkp = c->size[2] + 2 * c->g, nip = c->size[0] + 2 * c->g;
+  return (size_t)(j1 + c->g - 1) * nkp * nip + (size_t)c->g * nkp;
+}
+}  // namespace
+
+bool comm_halo(CommCtx* c, void* X, const int* skip, hipStream_t st) {
+  if (!c) return true;
+  char* Xb = (char*)X;
+  const int NJ = c->size[1];
+  const int opp[6] = {1, 0, 3, 2, 5, 4};
+  if (c->eb == 4) pack_faces<float>(c, (const float*)X, skip, st);
+  else pack_faces<double>(c, (const double*)X, skip, st);
+
+  if (c->tr == T_RCCL) {
+    const ncclDataType_t dt = c->eb == 4 ? ncclFloat : ncclDouble;
+    NCCL_CHECK(ncclGroupStart());
+    for (int f = 0; f < 6; f++) {
+      if (c->nID[f] < 0) continue;
+      const void* sb;
+      void* rb;
+      if (f == 2) sb = Xb + jface_off(c, 1) * c->eb, rb = Xb + jface_off(c, 0) * c->eb;
+      else if (f == 3) sb = Xb + jface_off(c, NJ) * c->eb, rb = Xb + jface_off(c, NJ + 1) * c->eb;
+      else sb = c->sendbuf[f], rb = c->recvbuf[f];
+      NCCL_CHECK(ncclSend(sb, c->face_elems[f], dt, c->nID[f], c->nccl, st));
+      NCCL_CHECK(ncclRecv(rb, c->face_elems[f], dt, c->nID[f], c->nccl, st));
+    }
+    NCCL_CHECK(ncclGroupEnd());
+  } else {  // LOCAL
+    c->cur_X = X;
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->world->barrier();  // every rank has packed and published
+    for (int f = 0; f < 6; f++) {
+      if (c->nID[f] < 0) continue;
+      CommCtx* nb = c->world->ranks[c->nID[f]];
+      if (f == 2 || f == 3) {
+        // my ghost plane (j=0 / NJ+1) <- neighbour's owned plane (j=NJnb / 1)
+        char* nbX = (char*)nb->cur_X;
+        const size_t src = (f == 2) ? jface_off(nb, nb->size[1]) : jface_off(nb, 1);
+        const size_t dst = (f == 2) ? jface_off(c, 0) : jface_off(c, NJ + 1);
+        HIP_CHECK(hipMemcpyAsync(Xb + dst * c->eb, nbX + src * c->eb, c->face_elems[f] * c->eb, hipMemcpyDeviceToDevice, st));
+      } else {
+        HIP_CHECK(hipMemcpyAsync(c->recvbuf[f], nb->sendbuf[opp[f]], c->face_elems[f] * c->eb, hipMemcpyDeviceToDevice, st));
+      }
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->world->barrier();  // nobody repacks before everyone has copied
+  }
+
+  if (c->eb == 4) unpack_faces<float>(c, (float*)X, skip, st);
+  else unpack_faces<double>(c, (double*)X, skip, st);
+  return true;
+}
+
+bool comm_allreduce_sum(CommCtx* c, double* d_val, int count, hipStream_t st) {
+  if (!c) return true;
+  if (c->tr == T_RCCL) {
+    NCCL_CHECK(ncclAllReduce(d_val, d_val, count, ncclDouble, ncclSum, c->nccl, st));
+    return true;
+  }
+  LocalWorld* w = c->world;
+  HIP_CHECK(hipMemcpyAsync(c->h_red, d_val, count * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (int i = 0; i < count; i++) w->red[(size_t)c->rank * 16 + i] = c->h_red[i];
+  w->barrier();
+  for (int i = 0; i < count; i++) {
+    double s = 0.0;
+    for (int r = 0; r < w->n; r++) s += w->red[(size_t)r * 16 + i];
+    c->h_red[i] = s;
+  }
+  w->barrier();
+  HIP_CHECK(hipMemcpyAsync(d_val, c->h_red, count * sizeof(double), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  return true;
+}
+
+double comm_allreduce_max_host(CommCtx* c, double v) {
+  if (!c) return v;
+  if (c->tr == T_RCCL) {
+    double* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, sizeof(double)));
+    HIP_CHECK(hipMemcpy(d, &v, sizeof(double), hipMemcpyHostToDevice));
+    NCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclMax, c->nccl, czhip_internal::stream()));
+    HIP_CHECK(hipStreamSynchronize(czhip_internal::stream()));
+    HIP_CHECK(hipMemcpy(&v, d, sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return v;
+  }
+  LocalWorld* w = c->world;
+  w->red[(size_t)c->rank * 16] = v;
+  w->barrier();
+  double m = v;
+  for (int r = 0; r < w->n; r++) m = std::max(m, w->red[(size_t)r * 16]);
+  w->barrier();
+  return m;
+}
+
+// ============================================================================================================
+// C-ABI: bootstrap + host-only decomposition helpers (declared in include/cz_hip.h part 5)
+// ============================================================================================================
+extern "C" {
+
+int cz_comm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+// rank 0 of a multi-process job: create the RCCL id that the launcher broadcasts (torch.distributed / a file)
+int cz_comm_get_unique_id(char* out) {
+  ncclUniqueId id;
+  NCCL_CHECK(ncclGetUniqueId(&id));
+  memcpy(out, &id, sizeof(id));
+  return 0;
+}
+
+// every rank: join the communicator (one process per GPU; the device was bound by czhip_init)
+int cz_comm_bootstrap(int rank, int nranks, const char* id_bytes) {
+  if (nranks <= 1) {
+    boot = Boot();
+    return 0;
+  }
+  ncclUniqueId id;
+  memcpy(&id, id_bytes, sizeof(id));
+  ncclComm_t comm;
+  NCCL_CHECK(ncclCommInitRank(&comm, nranks, id, rank));
+  boot.tr = T_RCCL, boot.rank = rank, boot.nproc = nranks, boot.nccl = comm, boot.world = nullptr;
+  return 0;
+}
+
+void cz_comm_shutdown(void) {
+  if (boot.tr == T_RCCL && boot.nccl) NCCL_CHECK(ncclCommDestroy(boot.nccl));
+  boot = Boot();
+}
+
+// LOCAL transport: a world of n ranks living in n threads of this process
+void* cz_comm_local_world(int n) {
+  LocalWorld* w = new LocalWorld();
+  w->n = n;
+  w->ranks.assign(n, nullptr);
+  w->red.assign((size_t)n * 16, 0.0);
+  return w;
+}
+void cz_comm_local_world_free(void* w) { delete (LocalWorld*)w; }
+int cz_comm_bootstrap_local(void* world, int rank) {
+  LocalWorld* w = (LocalWorld*)world;
+  boot.tr = T_LOCAL, boot.rank = rank, boot.nproc = w->n, boot.nccl = nullptr, boot.world = w;
+  return 0;
+}
+
+void cz_comm_auto_division(int nproc, const int* G_size, int* G_div) { comm_auto_division(nproc, G_size, G_div); }
+int cz_comm_decompose(const int* G_size, const int* G_div, int nproc, int rank, int* size, int* head, int* nID) {
+  return comm_decompose(G_size, G_div, nproc, rank, size, head, nID) ? 1 : 0;
+}
+
+}  // extern "C"

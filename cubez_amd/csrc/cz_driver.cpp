@@ -1,0 +1,680 @@
+// cz_driver.cpp -- restatement of the reference's host driver for a GPU-resident solve.
+//
+//   CZ::Setup / Solve / Evaluate   <- src/cz_cpp/cz_Evaluate.cpp:21-567   (argv parsing, solver select, allocation,
+//                                      boundary conditions, dispatch, "Iter = .. Res = .." print, history file)
+//   CZ::JACOBI / RBSOR / PBiCGSTAB <- src/cz_cpp/cz_Poisson.cpp:30-82, 159-235, 332-504
+//   CZ::Fdot1/2, Preconditioner    <- cz_Poisson.cpp:239-270, 273-322
+//   CZ::range_inner_index          <- src/cz_cpp/cz_miscel.cpp:20-52
+//
+// What is different from the reference, and why (details in DESIGN.md):
+//   * all 3-D arrays live in HBM; the Fortran kernels are the HIP kernels of cz_kernels.hip.
+//   * JACOBI ping-pongs between X and WRK instead of sweeping into WRK and copying back (12 instead of 20 B/LUP).
+//   * the per-iteration "all-reduce, sqrt, history line, eps test" of cz_Poisson.cpp:67-77 runs on the device
+//     (czhip_check_async); sweeps queued after convergence turn into no-ops through a device flag, so the host never
+//     waits for the GPU inside the loop yet the iteration count, history and final field are exactly those of the
+//     sequential loop.
+//   * bc_k_ after each checked iteration (cz_Poisson.cpp:74) is skipped: sweeps write the inner box only, the
+//     Dirichlet faces set at start-up are never touched, so the call is an identity.
+//   * the CBrick/MPI domain decomposition is replaced by cell-ownership decomposition + RCCL (cz_comm.cpp).
+#include "cz_driver.h"
+
+#include <strings.h>
+
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "cz_comm.h"
+
+using namespace czhip_internal;
+
+#define Hostonly_ if (myRank == 0)
+
+namespace {
+const char* printMethod(int t) {
+  switch (t) {
+    case LS_JACOBI: return "JACOBI";
+    case LS_SOR2SMA: return "SOR2SMA";
+    case LS_BICGSTAB: return "PBiCGSTAB";
+    case LS_PSOR: return "PSOR";
+    default: return "NONE";
+  }
+}
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+constexpr int POLL_EVERY = 32;   // iterations between convergence polls of the host
+constexpr int POLL_SLOTS = 4;
+}  // namespace
+
+CZ::CZ() {
+  czhip_init(-1);
+  HIP_CHECK(hipMalloc(&d_res, 16 * sizeof(double)));
+  HIP_CHECK(hipMemset(d_res, 0, 16 * sizeof(double)));
+  HIP_CHECK(hipMalloc(&d_flag, (2 + 2 * POLL_SLOTS) * sizeof(int)));
+  HIP_CHECK(hipMemset(d_flag, 0, (2 + 2 * POLL_SLOTS) * sizeof(int)));
+  HIP_CHECK(hipHostMalloc(&h_scal, 16 * sizeof(double), hipHostMallocDefault));
+  HIP_CHECK(hipHostMalloc(&h_flag, 2 * POLL_SLOTS * sizeof(int), hipHostMallocDefault));
+}
+
+CZ::~CZ() {
+  czhip_sync();
+  REAL_TYPE* arrs[] = {WRK, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_};
+  for (REAL_TYPE* a : arrs)
+    if (a) czhip_free(a);
+  if (d_hist) (void)hipFree(d_hist);
+  (void)hipFree(d_res);
+  (void)hipFree(d_flag);
+  (void)hipHostFree(h_scal);
+  (void)hipHostFree(h_flag);
+  if (comm) comm_destroy(comm);
+  if (fph) fclose(fph);
+}
+
+double CZ::npts() const {
+  return (double)(innerFidx[I_plus] - innerFidx[I_minus] + 1) * (double)(innerFidx[J_plus] - innerFidx[J_minus] + 1) *
+         (double)(innerFidx[K_plus] - innerFidx[K_minus] + 1);
+}
+
+// cz_miscel.cpp:20-52.  The reference always starts at 2 because its CBrick "node" bricks share one layer with the
+// lower neighbour; this build's bricks own disjoint cells, so a face that borders another rank starts at 1 / ends at
+// size, a physical face at 2 / size-1 (identical to the reference when numProc == 1).
+double CZ::range_inner_index() {
+  int ist = (nID[I_minus] < 0) ? 2 : 1, jst = (nID[J_minus] < 0) ? 2 : 1, kst = (nID[K_minus] < 0) ? 2 : 1;
+  int ied = size[0], jed = size[1], ked = size[2];
+  if (nID[I_plus] < 0) ied = size[0] - 1;
+  if (nID[J_plus] < 0) jed = size[1] - 1;
+  if (nID[K_plus] < 0) ked = size[2] - 1;
+  innerFidx[I_minus] = ist, innerFidx[I_plus] = ied;
+  innerFidx[J_minus] = jst, innerFidx[J_plus] = jed;
+  innerFidx[K_minus] = kst, innerFidx[K_plus] = ked;
+  return (double)(ied - ist + 1) * (double)(jed - jst + 1) * (double)(ked - kst + 1);
+}
+
+// cz_Evaluate.cpp:571-581
+void CZ::setStrPre() {
+  if (!strcasecmp(precon.c_str(), "jacobi")) pc_type = LS_JACOBI;
+  else if (!strcasecmp(precon.c_str(), "sor2sma")) pc_type = LS_SOR2SMA;
+  else if (!strcasecmp(precon.c_str(), "none")) pc_type = LS_NONE;
+  else {
+    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | sor2sma)\n", precon.c_str());
+    exit(0);
+  }
+}
+
+// cz_Evaluate.cpp:684-803 (hot-path solvers only; see DESIGN.md "out of scope")
+void CZ::setLS(const char* q) {
+  if (!strcasecmp(q, "jacobi")) {
+    ls_type = LS_JACOBI;
+    hist_name = "jacobi.txt";
+  } else if (!strcasecmp(q, "sor2sma")) {
+    ls_type = LS_SOR2SMA;
+    hist_name = "sor2sma.txt";
+  } else if (!strcasecmp(q, "pbicgstab")) {
+    ls_type = LS_BICGSTAB;
+    hist_name = "pbicgstab.txt";
+    setStrPre();
+  } else {
+    printf("Invalid solver\n");  // :799-802
+    exit(0);
+  }
+}
+
+// Replaces CBrick's SubDomain (cz_Evaluate.cpp:103-159): Cartesian split of the G_size nodes into G_div bricks of
+// disjoint cells, rank = ri + div_i*(rj + div_j*rk).
+bool CZ::decompose(int div_type) {
+  if (numProc == 1) {
+    G_div[0] = G_div[1] = G_div[2] = 1;  // :162-176
+    for (int a = 0; a < 3; a++) size[a] = G_size[a], head[a] = 1, origin[a] = G_origin[a];
+    for (int f = 0; f < 6; f++) nID[f] = -1;
+    return true;
+  }
+  if (div_type == 0) comm_auto_division(numProc, G_size, G_div);
+  int sz3[3], hd3[3], nid6[6];
+  if (!comm_decompose(G_size, G_div, numProc, myRank, sz3, hd3, nid6)) return false;
+  for (int a = 0; a < 3; a++) {
+    size[a] = sz3[a], head[a] = hd3[a];
+    origin[a] = G_origin[a] + (REAL_TYPE)(head[a] - 1) * pitch[a];  // :136-138
+  }
+  for (int f = 0; f < 6; f++) nID[f] = nid6[f];
+  return true;
+}
+
+void CZ::ensure_hist(int n) {
+  if (n <= hist_cap) return;
+  if (d_hist) {
+    czhip_sync();
+    HIP_CHECK(hipFree(d_hist));
+  }
+  hist_cap = n + 1024;
+  HIP_CHECK(hipMalloc(&d_hist, (size_t)hist_cap * sizeof(double)));
+  HIP_CHECK(hipMemset(d_hist, 0, (size_t)hist_cap * sizeof(double)));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+int CZ::Setup(int argc, char** argv) {
+  int div_type = 0;
+  const int gc = GUIDE;
+  if (argc != 7 && argc != 8 && argc != 10 && argc != 11) return 0;  // main.cpp:19
+
+  comm_world(&myRank, &numProc);  // rank/size from the launcher environment (replaces MPI_Comm_rank/size, :44-50)
+
+  G_size[0] = atoi(argv[1]);
+  G_size[1] = atoi(argv[2]);
+  G_size[2] = atoi(argv[3]);
+  if (G_size[0] < 3 || G_size[1] < 3 || G_size[2] < 3) {
+    Hostonly_ printf("command line error : grid size must be >= 3\n");
+    return 0;
+  }
+
+  const char* q = argv[4];
+  if (!strcasecmp(q, "pbicgstab")) {  // :63-70
+    if (argc != 8 && argc != 11) {
+      Hostonly_ printf("command line error : pbicgstab\n");
+      exit(0);
+    }
+    precon = argv[7];
+  }
+  if (argc == 10) {  // :73-78
+    div_type = 1;
+    G_div[0] = atoi(argv[7]), G_div[1] = atoi(argv[8]), G_div[2] = atoi(argv[9]);
+  }
+  if (argc == 11) {  // :80-85
+    div_type = 1;
+    G_div[0] = atoi(argv[8]), G_div[1] = atoi(argv[9]), G_div[2] = atoi(argv[10]);
+  }
+
+  pitch[0] = pitch[1] = pitch[2] = 1.0 / (REAL_TYPE)(G_size[2] - 1);  // :88
+
+  if (div_type == 1 && G_div[0] * G_div[1] * G_div[2] != numProc) {  // :93-96
+    printf("\tThe number of proceees does not agree with the division size.\n");
+    return 0;
+  }
+  ac1 = atof(argv[6]);  // :99
+
+  if (!decompose(div_type)) return 0;
+  if (numProc > 1) {
+    comm = comm_create(myRank, numProc, size, nID, sizeof(REAL_TYPE));
+    if (!comm) return 0;
+  }
+
+  setLS(q);
+  if (!quiet) Hostonly_ {
+    printf("Iterative Mehtod = %s\n", printMethod(ls_type));  // :194 (sic)
+    if (ls_type == LS_BICGSTAB) printf("Preconditioner = %s\n", printMethod(pc_type));
+  }
+
+  if (!quiet) Hostonly_ {  // :210-218
+    if (!(fph = fopen(hist_name.c_str(), "w"))) {
+      printf("\tSorry, can't open file.\n");
+      exit(0);
+    }
+    fprintf(fph, "Itration      Residual\n");
+  }
+
+  double sum_r = range_inner_index();  // :222-224
+  if (!Comm_SUM_1(&sum_r)) return 0;
+  res_normal = 1.0 / (double)sum_r;
+
+  // :239-288 (only the arrays the hot path touches)
+  RHS = czhip_alloc_s3d(size);
+  P = czhip_alloc_s3d(size);
+  WRK = czhip_alloc_s3d(size);
+  if (ls_type == LS_BICGSTAB) {
+    pcg_p = czhip_alloc_s3d(size), pcg_p_ = czhip_alloc_s3d(size), pcg_r = czhip_alloc_s3d(size);
+    pcg_r0 = czhip_alloc_s3d(size), pcg_q = czhip_alloc_s3d(size), pcg_s = czhip_alloc_s3d(size);
+    pcg_s_ = czhip_alloc_s3d(size), pcg_t_ = czhip_alloc_s3d(size);
+  }
+  if (!quiet) Hostonly_ {
+    const double arr = (double)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
+    printf("\n----------\n\n\tDevice memory per rank : %.1f MiB in %d arrays of (%d+4)x(%d+4)x(%d+4) %s\n", arr *
+           (ls_type == LS_BICGSTAB ? 11 : 3) / 1048576.0, ls_type == LS_BICGSTAB ? 11 : 3, size[0], size[1], size[2],
+           sizeof(REAL_TYPE) == 4 ? "float" : "double");
+  }
+
+  ItrMax = atoi(argv[5]);  // :330
+
+  // :375-386  boundary values on P and RHS, ghost layers filled from the neighbours
+  bc_async(size, gc, P, pitch[0], origin, nID);
+  if (!Comm_S(P)) return 0;
+  bc_async(size, gc, RHS, pitch[0], origin, nID);
+  if (!Comm_S(RHS)) return 0;
+  czhip_sync();
+  set_up = true;
+  sweeps_done = 0;
+  return 1;
+}
+
+int CZ::Solve() {
+  if (!set_up) return 0;
+  double res = 0.0, flop = 0.0;
+  int itr = 0;
+  history.clear();
+  czhip_sync();
+  const double t0 = now_s();
+  switch (ls_type) {  // :415-488
+    case LS_JACOBI:
+      if (0 == (itr = JACOBI(res, P, RHS, ItrMax, flop, ls_type))) return 0;
+      break;
+    case LS_SOR2SMA:
+      if (0 == (itr = RBSOR(res, P, RHS, ItrMax, flop, ls_type))) return 0;
+      break;
+    case LS_BICGSTAB:
+      if (0 == (itr = PBiCGSTAB(res, P, RHS, flop, ls_type))) return 0;
+      break;
+    default:
+      break;
+  }
+  czhip_sync();
+  solve_seconds = now_s() - t0;
+  result_itr = itr;
+  result_res = res;
+
+  if (fph) {
+    for (size_t i = 0; i < history.size(); i++) fprintf(fph, "%6d, %13.6e\n", (int)i + 1, history[i]);  // cz_Poisson.cpp:71
+    fflush(fph);
+  }
+  if (!quiet) Hostonly_ {  // :492-496
+    printf("\n=================================\n");
+    printf("Iter = %d  Res = %e\n", itr, res);
+    printf("=================================\n");
+  }
+  return itr;
+}
+
+int CZ::Evaluate(int argc, char** argv) {
+  if (!Setup(argc, argv)) return 0;
+  if (!Solve()) return 0;
+  if (!quiet) Hostonly_ {
+    const double lups = 1.0 / res_normal * (double)(result_itr > ItrMax ? ItrMax : result_itr);
+    if (ls_type != LS_BICGSTAB)
+      printf("\n\tGPU time = %.6f s   %.1f MLUPS\n", solve_seconds, lups / solve_seconds * 1e-6);
+    else
+      printf("\n\tGPU time = %.6f s\n", solve_seconds);
+  }
+  if (debug_mode == 1) {  // :550-563
+    int loc[3];
+    double errmax = ErrorMax(loc);
+    if (!quiet) Hostonly_ printf("\nError max = %e at (%d %d %d)\n\n", errmax, loc[0], loc[1], loc[2]);
+  }
+  return 1;
+}
+
+// Bench leg: n more iterations of the stationary solver, with the complete per-iteration work of the checked loop
+// (sweep, residual reduction, convergence bookkeeping) but eps disabled so that nothing is skipped.
+int CZ::Sweeps(int n) {
+  if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA)) return 0;
+  const double keep = eps;
+  eps = -1.0;
+  double res = 0.0, flop = 0.0;
+  history.clear();
+  if (ls_type == LS_JACOBI) JACOBI(res, P, RHS, n, flop, ls_type);
+  else RBSOR(res, P, RHS, n, flop, ls_type);
+  eps = keep;
+  sweeps_done += n;
+  result_res = res;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// communication wrappers (cz_comm.cpp:23-38, 102-120 of the reference)
+bool CZ::Comm_S(REAL_TYPE* X, const int* skip_flag) {
+  if (numProc == 1) return true;
+  return comm_halo(comm, X, skip_flag, stream());
+}
+bool CZ::Comm_SUM_dev(double* d_val, int count, const int* skip_flag) {
+  if (numProc == 1) return true;
+  (void)skip_flag;  // all ranks see the same flag, so the collective is issued by all or by none
+  return comm_allreduce_sum(comm, d_val, count, stream());
+}
+bool CZ::Comm_SUM_1(double* host_val) {
+  if (numProc == 1) return true;
+  HIP_CHECK(hipMemcpyAsync(d_res + 8, host_val, sizeof(double), hipMemcpyHostToDevice, stream()));
+  if (!comm_allreduce_sum(comm, d_res + 8, 1, stream())) return false;
+  HIP_CHECK(hipMemcpyAsync(h_scal + 8, d_res + 8, sizeof(double), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  *host_val = h_scal[8];
+  return true;
+}
+
+// Drain the queue and turn the device-side bookkeeping into the loop's return values.
+int CZ::finish_stationary(int itr_max, int first_itr, bool converge_check, double& res) {
+  (void)first_itr;
+  if (!converge_check) {
+    czhip_sync();
+    return itr_max + 1;
+  }
+  HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  const bool conv = h_flag[0] != 0;
+  const int n_exec = conv ? h_flag[1] : itr_max;
+  const size_t base = history.size();
+  history.resize(base + n_exec);
+  if (n_exec > 0) {
+    HIP_CHECK(hipMemcpy(history.data() + base, d_hist + 1, (size_t)n_exec * sizeof(double), hipMemcpyDeviceToHost));
+    res = history.back();
+  }
+  return conv ? n_exec : itr_max + 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// cz_Poisson.cpp:30-82
+int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+  (void)s_type;
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  // ping-pong partner: same guide cells / Dirichlet faces as X
+  copy_shell_async(WRK, X, size, innerFidx, gc);
+  REAL_TYPE* buf[2] = {X, WRK};
+  const int* skip = nullptr;
+  if (converge_check) {
+    ensure_hist(itr_max + 2);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    skip = d_flag;
+  }
+  hipEvent_t ev[POLL_SLOTS];
+  int npoll = 0;
+  bool stop = false;
+  int itr;
+  for (itr = 1; itr <= itr_max && !stop; itr++) {
+    REAL_TYPE* src = buf[(itr - 1) & 1];
+    REAL_TYPE* dst = buf[itr & 1];
+    czhip_jacobi_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, 0, skip);  // :58
+    flop += 18.0 * npts();
+    if (!Comm_S(dst, skip)) return 0;  // :63
+    if (converge_check) {
+      if (!Comm_SUM_dev(d_res, 1, skip)) return 0;                                         // :67
+      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);          // :69-77
+      if (itr % POLL_EVERY == 0 && itr < itr_max) {
+        // lagging, non-blocking view of the flag: look at the copy issued two polls ago
+        const int slot = npoll % POLL_SLOTS;
+        if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
+        HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev[slot], st));
+        npoll++;
+        if (npoll >= 3) {
+          const int old = (npoll - 3) % POLL_SLOTS;
+          HIP_CHECK(hipEventSynchronize(ev[old]));
+          if (h_flag[2 * old] != 0) stop = true;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
+  const int ret = finish_stationary(itr_max, 1, converge_check, res);
+  const int n_exec = converge_check ? (ret > itr_max ? itr_max : ret) : itr_max;
+  if (n_exec & 1) {
+    // the last executed sweep wrote WRK.  The arrays are ours: swap the roles instead of copying back.
+    if (X == P) {
+      REAL_TYPE* t = P;
+      P = WRK;
+      WRK = t;
+    } else {
+      copy_inner_async(X, WRK, size, innerFidx, gc);
+    }
+  }
+  return ret;
+}
+
+// cz_Poisson.cpp:159-235
+int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+  (void)s_type;
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  const int* skip = nullptr;
+  if (converge_check) {
+    ensure_hist(itr_max + 2);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    skip = d_flag;
+  }
+  // :178-186.  ip makes colour 0 the points of even GLOBAL i+j+k; the kernel's parity is relative to kst
+  // (cz_solver.f90:466), which is 1 instead of 2 on a face that borders another rank.
+  int ip = 0;
+  if (numProc > 1) ip = (head[0] + head[1] + head[2] + 1 + innerFidx[K_minus]) % 2;
+  hipEvent_t ev[POLL_SLOTS];
+  int npoll = 0;
+  bool stop = false;
+  int itr;
+  for (itr = 1; itr <= itr_max && !stop; itr++) {
+    for (int color = 0; color < 2; color++) {  // :205-209
+      czhip_rbsor_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, color, skip);
+      flop += 9.0 * npts();
+      // the reference exchanges once per iteration (:215); exchanging after each colour makes the decomposed run
+      // identical to the single-domain one
+      if (!Comm_S(X, skip)) return 0;
+    }
+    if (converge_check) {
+      if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
+      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+      if (itr % POLL_EVERY == 0 && itr < itr_max) {
+        const int slot = npoll % POLL_SLOTS;
+        if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
+        HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev[slot], st));
+        npoll++;
+        if (npoll >= 3) {
+          const int old = (npoll - 3) % POLL_SLOTS;
+          HIP_CHECK(hipEventSynchronize(ev[old]));
+          if (h_flag[2 * old] != 0) stop = true;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
+  return finish_stationary(itr_max, 1, converge_check, res);
+}
+
+// cz_Poisson.cpp:239-270.  The reference reduces in REAL on every rank and all-reduces the REAL; here the double
+// partial sums are all-reduced and rounded to REAL once.
+REAL_TYPE CZ::Fdot1(REAL_TYPE* x, double& flop) {
+  dot1_async(x, size, innerFidx, GUIDE, d_res + 1);
+  flop += 2.0 * npts();
+  if (!Comm_SUM_dev(d_res + 1, 1)) exit(0);
+  HIP_CHECK(hipMemcpyAsync(h_scal + 1, d_res + 1, sizeof(double), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  return (REAL_TYPE)h_scal[1];
+}
+
+REAL_TYPE CZ::Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop) {
+  dot2_async(x, y, size, innerFidx, GUIDE, d_res + 1);
+  flop += 2.0 * npts();
+  if (!Comm_SUM_dev(d_res + 1, 1)) exit(0);
+  HIP_CHECK(hipMemcpyAsync(h_scal + 1, d_res + 1, sizeof(double), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  return (REAL_TYPE)h_scal[1];
+}
+
+// cz_Poisson.cpp:273-322
+void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) {
+  double res = 0.0;
+  const int lc_max = 8;  // :280
+  switch (s_type) {
+    case LS_JACOBI:
+      JACOBI(res, xx, bb, lc_max, flop, s_type, false);
+      break;
+    case LS_SOR2SMA:
+      RBSOR(res, xx, bb, lc_max, flop, s_type, false);
+      break;
+    default: {
+      const size_t n = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE);
+      HIP_CHECK(hipMemcpyAsync(xx, bb, n * sizeof(REAL_TYPE), hipMemcpyDeviceToDevice, stream()));  // blas_copy_
+    }
+  }
+}
+
+// cz_Poisson.cpp:332-504
+int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_type) {
+  (void)s_type;
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  const size_t nbytes = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
+  int itr;
+  double flop_count = 0.0;
+  res = 0.0;
+
+  HIP_CHECK(hipMemsetAsync(pcg_q, 0, nbytes, st));                       // :344 blas_clear_
+  calc_rk_async(pcg_r, X, B, size, innerFidx, gc, cf);                  // :356
+  flop += 14.0 * npts();
+  if (!Comm_S(pcg_r)) return 0;                                         // :362
+  HIP_CHECK(hipMemcpyAsync(pcg_r0, pcg_r, nbytes, hipMemcpyDeviceToDevice, st));  // :365 blas_copy_
+
+  REAL_TYPE rho_old = 1.0, alpha = 0.0, omega = 1.0, r_omega = -omega;  // :368-371
+
+  for (itr = 1; itr < ItrMax; itr++) {  // :373
+    flop_count = 0.0;
+    REAL_TYPE rho = Fdot2(pcg_r, pcg_r0, flop_count);  // :376
+    flop += flop_count;
+    if (fabs(rho) < FLT_MIN) {  // :379-383
+      itr = 0;
+      break;
+    }
+    if (itr == 1) {
+      HIP_CHECK(hipMemcpyAsync(pcg_p, pcg_r, nbytes, hipMemcpyDeviceToDevice, st));  // :387
+    } else {
+      REAL_TYPE beta = rho / rho_old * alpha / omega;  // :394
+      bicg1_async(pcg_p, pcg_r, pcg_q, beta, omega, size, innerFidx, gc);  // :398
+      flop += 4.0 * npts();
+    }
+    if (!Comm_S(pcg_p)) return 0;                    // :402
+    HIP_CHECK(hipMemsetAsync(pcg_p_, 0, nbytes, st));  // :405
+    flop_count = 0.0;
+    Preconditioner(pcg_p_, pcg_p, flop_count, pc_type);  // :409
+    flop += flop_count;
+
+    calc_ax_async(pcg_q, pcg_p_, size, innerFidx, gc, cf);  // :421
+    flop += 13.0 * npts();
+
+    flop_count = 0.0;
+    alpha = rho / Fdot2(pcg_q, pcg_r0, flop_count);  // :427
+    flop += flop_count;
+
+    REAL_TYPE r_alpha = -alpha;
+    triad_async(pcg_s, pcg_q, pcg_r, r_alpha, size, innerFidx, gc);  // :434
+    flop += 2.0 * npts();
+    if (!Comm_S(pcg_s)) return 0;  // :438
+
+    HIP_CHECK(hipMemsetAsync(pcg_s_, 0, nbytes, st));  // :441
+    flop_count = 0.0;
+    Preconditioner(pcg_s_, pcg_s, flop_count, pc_type);  // :445
+    flop += flop_count;
+
+    calc_ax_async(pcg_t_, pcg_s_, size, innerFidx, gc, cf);  // :457
+    flop += 13.0 * npts();
+
+    flop_count = 0.0;
+    const REAL_TYPE ts = Fdot2(pcg_t_, pcg_s, flop_count);
+    const REAL_TYPE tt = Fdot1(pcg_t_, flop_count);
+    omega = ts / tt;  // :464
+    r_omega = -omega;
+    flop += flop_count;
+
+    bicg2_async(X, pcg_p_, pcg_s_, alpha, omega, size, innerFidx, gc);  // :470
+    flop += 4.0 * npts();
+    triad_async(pcg_r, pcg_t_, pcg_s, r_omega, size, innerFidx, gc);  // :476
+    flop += 2.0 * npts();
+
+    flop_count = 0.0;
+    res = Fdot1(pcg_r, flop_count);  // :481
+    flop += flop_count;
+
+    if (!Comm_S(X)) return 0;  // :486
+    // :488 all-reduces `res` a second time although Fdot1 already did (an MPI-only double count in the reference,
+    // a no-op in its serial build); dropped here.
+    res *= res_normal;  // :490
+    res = sqrt(res);
+    history.push_back(res);  // :492
+    // :495 bc_k_(X): identity, X's faces are never written (see file header)
+    if (res < eps) break;  // :498
+    rho_old = rho;
+  }
+  return itr;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+void CZ::Field(REAL_TYPE* host) const {
+  const size_t n = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE);
+  czhip_d2h(host, P, n * sizeof(REAL_TYPE));
+}
+
+// Debug epilogue (cz_Evaluate.cpp:550-563): exact_t_ + err_t_ of cz_utility.f90:52-129 restated on the host
+// (out of the hot path; the field comes back over PCIe once).
+double CZ::ErrorMax(int loc[3]) {
+  const int g = GUIDE;
+  const size_t nk = size[2] + 2 * g, ni = size[0] + 2 * g, nj = size[1] + 2 * g;
+  std::vector<REAL_TYPE> p(nk * ni * nj);
+  Field(p.data());
+  volatile REAL_TYPE one = 1.0, two = 2.0;
+#ifdef CZ_REAL_IS_DOUBLE
+  const REAL_TYPE r2 = sqrt(two), pi = 2.0 * asin(one);
+#define CZ_SIN sin
+#define CZ_SINH sinh
+#else
+  const REAL_TYPE r2 = sqrtf(two), pi = 2.0f * asinf(one);
+#define CZ_SIN sinf
+#define CZ_SINH sinhf
+#endif
+  const REAL_TYPE dh = pitch[0];
+  double d = 0.0;
+  loc[0] = loc[1] = loc[2] = -1;
+  for (int j = innerFidx[J_minus]; j <= innerFidx[J_plus]; j++)
+    for (int i = innerFidx[I_minus]; i <= innerFidx[I_plus]; i++)
+      for (int k = innerFidx[K_minus]; k <= innerFidx[K_plus]; k++) {
+        const REAL_TYPE x = origin[0] + dh * (REAL_TYPE)(i - 1);
+        const REAL_TYPE y = origin[1] + dh * (REAL_TYPE)(j - 1);
+        const REAL_TYPE z = origin[2] + dh * (REAL_TYPE)(k - 1);
+        const REAL_TYPE e = CZ_SIN(pi * x) * CZ_SIN(pi * y) / CZ_SINH(r2 * pi) *
+                            (CZ_SINH(r2 * pi * z) - CZ_SINH(r2 * pi * (z - (REAL_TYPE)1.0)));  // cz_utility.f90:75
+        const REAL_TYPE r = p[(size_t)(k + g - 1) + (size_t)(i + g - 1) * nk + (size_t)(j + g - 1) * nk * ni] - e;
+        const double qq = fabs((double)r);
+        if (d < qq) {
+          d = qq;
+          loc[0] = i, loc[1] = j, loc[2] = k;
+        }
+      }
+  if (numProc > 1) {
+    // Comm_MAX_1 (cz_Evaluate.cpp:558): the maximum over ranks; location stays the local one as in the reference
+    d = comm_allreduce_max_host(comm, d);
+  }
+  return d;
+}
+
+// ============================================================================================================
+// Part 4 of include/cz_hip.h
+// ============================================================================================================
+struct cz_handle {
+  CZ cz;
+};
+
+extern "C" {
+cz_handle* cz_create(void) { return new cz_handle(); }
+void cz_destroy(cz_handle* h) { delete h; }
+int cz_evaluate(cz_handle* h, int argc, char** argv) { return h->cz.Evaluate(argc, argv); }
+int cz_setup(cz_handle* h, int argc, char** argv) { return h->cz.Setup(argc, argv); }
+int cz_solve(cz_handle* h) { return h->cz.Solve(); }
+int cz_sweeps(cz_handle* h, int n) { return h->cz.Sweeps(n); }
+int cz_result_iter(const cz_handle* h) { return h->cz.result_itr; }
+double cz_result_res(const cz_handle* h) { return h->cz.result_res; }
+int cz_history(const cz_handle* h, double* out, int cap) {
+  const int n = (int)h->cz.history.size();
+  for (int i = 0; i < n && i < cap; i++) out[i] = h->cz.history[i];
+  return n;
+}
+void cz_field(const cz_handle* h, CZ_REAL* host_out) { h->cz.Field(host_out); }
+void cz_local_size(const cz_handle* h, int* size3, int* head3, int* nID6, int* inner6) {
+  for (int a = 0; a < 3; a++) size3[a] = h->cz.size[a], head3[a] = h->cz.head[a];
+  for (int f = 0; f < 6; f++) nID6[f] = h->cz.nID[f], inner6[f] = h->cz.innerFidx[f];
+}
+double cz_error_max(cz_handle* h, int* loc3) { return h->cz.ErrorMax(loc3); }
+void cz_set_quiet(cz_handle* h, int q) { h->cz.quiet = q != 0; }
+void cz_set_debug(cz_handle* h, int m) { h->cz.debug_mode = m; }
+double cz_last_solve_seconds(const cz_handle* h) { return h->cz.solve_seconds; }
+double cz_kernel_ms(const cz_handle* h, const char* label) {
+  (void)h;
+  double tot = 0.0;
+  const int n = czhip_timing_read(label, &tot);
+  return n > 0 ? tot / n : 0.0;
+}
+}  // extern "C"

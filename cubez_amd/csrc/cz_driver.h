@@ -1,0 +1,105 @@
+// cz_driver.h -- the restated host driver: class CZ of the reference (src/cz_cpp/cz.h:84-181, DomainInfo.h:30-49)
+// with every 3-D array resident in HBM and the solver loops (cz_Poisson.cpp) rebuilt around asynchronous launches.
+#ifndef CZ_DRIVER_H_
+#define CZ_DRIVER_H_
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "cz_internal.h"
+
+typedef CZ_REAL REAL_TYPE;  // cz_Define.h:28-37
+#define GUIDE 2             // cz_Define.h:40
+
+// cz_Define.h:68-89 (only the solvers of the hot path are accepted; the others are rejected by setLS)
+enum LinearSolver { LS_NONE = 0, LS_PSOR = 1, LS_SOR2SMA, LS_BICGSTAB, LS_JACOBI };
+
+// CB_Define_stub.h:64-70 / cz_fparam.fi:10-16
+enum { I_minus = 0, I_plus, J_minus, J_plus, K_minus, K_plus };
+
+struct CommCtx;  // cz_comm.cpp (RCCL halo exchange / all-reduce); nullptr when numProc == 1
+
+class CZ {
+ public:
+  // ---- DomainInfo (DomainInfo.h:30-49)
+  int myRank = 0, numProc = 1;
+  int nID[6] = {-1, -1, -1, -1, -1, -1};
+  int head[3] = {1, 1, 1};
+  int G_div[3] = {1, 1, 1};
+  REAL_TYPE pitch[3] = {0, 0, 0};
+  int size[3] = {0, 0, 0};
+  REAL_TYPE origin[3] = {0, 0, 0};
+  int G_size[3] = {0, 0, 0};
+  REAL_TYPE G_origin[3] = {0, 0, 0};
+  int innerFidx[6] = {0, 0, 0, 0, 0, 0};
+
+  // ---- CZ (cz.h:84-133, 154-181)
+  int debug_mode = 0;
+  int ItrMax = 0;
+  int ls_type = LS_NONE, pc_type = LS_NONE;
+  double eps = 1.0e-5;
+  REAL_TYPE ac1 = 0;
+  double res_normal = 0.0;
+  REAL_TYPE cf[7] = {1, 1, 1, 1, 1, 1, 6};
+  std::string precon;
+  FILE* fph = nullptr;
+  std::string hist_name;
+
+  REAL_TYPE *WRK = nullptr, *P = nullptr, *RHS = nullptr;
+  REAL_TYPE *pcg_p = nullptr, *pcg_p_ = nullptr, *pcg_r = nullptr, *pcg_r0 = nullptr, *pcg_q = nullptr, *pcg_s = nullptr,
+            *pcg_s_ = nullptr, *pcg_t_ = nullptr;
+
+  // ---- build-specific state
+  bool quiet = false;
+  bool set_up = false;
+  int result_itr = 0;
+  double result_res = 0.0;
+  std::vector<double> history;   // residual of iteration 1..n (index 0 = iteration 1)
+  double solve_seconds = 0.0;
+  int sweeps_done = 0;           // stationary-solver iterations executed so far (bench leg)
+  CommCtx* comm = nullptr;
+
+  // device-side convergence bookkeeping (cz_Poisson.cpp:67-77 moved to the GPU)
+  double* d_res = nullptr;       // [0] sum dp^2 of the current iteration, [1..7] dot products
+  double* d_hist = nullptr;      // residual history, index = iteration
+  int hist_cap = 0;
+  int* d_flag = nullptr;         // [0] converged flag, [1] iteration at which it was set
+  double* h_scal = nullptr;      // pinned: mirrors of d_res
+  int* h_flag = nullptr;         // pinned
+
+  CZ();
+  ~CZ();
+
+  int Evaluate(int argc, char** argv);  // cz_Evaluate.cpp:21-567
+  int Setup(int argc, char** argv);     //   :21-391
+  int Solve();                          //   :397-496
+  int Sweeps(int n);
+  double ErrorMax(int loc[3]);          //   :550-563
+  void Field(REAL_TYPE* host) const;
+
+ private:
+  void setLS(const char* q);                                   // cz_Evaluate.cpp:684-803
+  void setStrPre();                                            // :571-681
+  double range_inner_index();                                  // cz_miscel.cpp:20-52
+  bool decompose(int div_type);                                // replaces CBrick SubDomain (cz_Evaluate.cpp:103-159)
+  void ensure_hist(int n);
+
+  // cz_Poisson.cpp
+  int JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
+  int RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
+  REAL_TYPE Fdot1(REAL_TYPE* x, double& flop);
+  REAL_TYPE Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop);
+  void Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type);
+  int PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_type);
+
+  // cz_comm.cpp replacements (no-ops when numProc == 1, like cz_comm.cpp:25,76,104)
+  bool Comm_S(REAL_TYPE* X, const int* skip_flag = nullptr);
+  bool Comm_SUM_dev(double* d_val, int count, const int* skip_flag = nullptr);
+  bool Comm_SUM_1(double* host_val);
+
+  int finish_stationary(int itr_max, int first_itr, bool converge_check, double& res);
+  double npts() const;
+};
+
+#endif

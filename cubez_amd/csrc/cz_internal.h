@@ -29,6 +29,8 @@ void calc_ax_async(CZ_REAL* ap, const CZ_REAL* p, const int* sz, const int* idx,
 void calc_rk_async(CZ_REAL* r, const CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf);
 void dot1_async(const CZ_REAL* p, const int* sz, const int* idx, int g, double* dst_dev);
 void dot2_async(const CZ_REAL* p, const CZ_REAL* q, const int* sz, const int* idx, int g, double* dst_dev);
+void copy_shell_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
+void copy_inner_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
 void bc_async(const int* sz, int g, CZ_REAL* p, CZ_REAL dh, const CZ_REAL* org, const int* nID);
 }  // namespace czhip_internal
 

@@ -436,6 +436,25 @@ __global__ void bc_jface_k(REAL* p, int ix, int kx, int jface, int g, int nkp, i
   p[(size_t)(k + g - 1) + (size_t)(i + g - 1) * nkp + (size_t)(jface + g - 1) * nkp * nip] = (REAL)0;
 }
 
+// copy every element OUTSIDE the inner box (guide cells, Dirichlet faces) from src to dst: one wave per k-row.
+// Used to give the ping-pong partner buffer of a Jacobi solve the same boundary data as the solution array.
+__global__ void __launch_bounds__(256)
+copy_shell_k(REAL* __restrict__ dst, const REAL* __restrict__ src, int nkp, int nip, int njp, int kk0, int kk1, int ii0, int ii1,
+             int jj0, int jj1) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)nip * njp) return;
+  const int lane = threadIdx.x & 63;
+  const int jj = (int)(row / nip), ii = (int)(row - (long long)jj * nip);
+  const bool inner_row = ii >= ii0 && ii <= ii1 && jj >= jj0 && jj <= jj1;
+  const size_t base = (size_t)row * nkp;
+  if (inner_row) {
+    for (int kk = lane; kk < kk0; kk += 64) dst[base + kk] = src[base + kk];
+    for (int kk = kk1 + 1 + lane; kk < nkp; kk += 64) dst[base + kk] = src[base + kk];
+  } else {
+    for (int kk = lane; kk < nkp; kk += 64) dst[base + kk] = src[base + kk];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
@@ -454,8 +473,37 @@ struct Ctx {
   Tuning tune;
   std::map<std::vector<double>, REAL*> bc_tabs;  // key: ix, jx, dh, org0, org1
   int num_cu = 256;
+  // optional per-launch HIP-event timing of the labelled kernels (bench.py roofline leg)
+  bool timing = false;
+  struct Ev { hipEvent_t a, b; int label; };
+  std::vector<Ev> ev_used, ev_free;
 };
-Ctx ctx;
+thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
+
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_COUNT };
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot"};
+
+struct ScopedTimer {
+  bool on;
+  Ctx::Ev ev;
+  explicit ScopedTimer(int label) : on(ctx.timing) {
+    if (!on) return;
+    if (!ctx.ev_free.empty()) {
+      ev = ctx.ev_free.back();
+      ctx.ev_free.pop_back();
+    } else {
+      HIP_CHECK(hipEventCreate(&ev.a));
+      HIP_CHECK(hipEventCreate(&ev.b));
+    }
+    ev.label = label;
+    HIP_CHECK(hipEventRecord(ev.a, ctx.stream));
+  }
+  ~ScopedTimer() {
+    if (!on) return;
+    HIP_CHECK(hipEventRecord(ev.b, ctx.stream));
+    ctx.ev_used.push_back(ev);
+  }
+};
 
 void ensure_init() {
   if (!ctx.ready) czhip_init(-1);
@@ -556,8 +604,11 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((stencil_k<V, TB, M, PF, MODE>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, P, B, OUT, c, g, par,
-                     ctx.partials, skip);
+  {
+    ScopedTimer tm(MODE == MODE_JACOBI ? LBL_JACOBI : MODE == MODE_RB ? LBL_RBSOR : MODE == MODE_AX ? LBL_AX : LBL_RK);
+    hipLaunchKernelGGL((stencil_k<V, TB, M, PF, MODE>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, P, B, OUT, c, g, par,
+                       ctx.partials, skip);
+  }
   HIP_CHECK(hipGetLastError());
   if (nblk_out) *nblk_out = (int)nblk;
 }
@@ -585,6 +636,7 @@ void launch_stencil(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, cons
 }
 
 void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
+  ScopedTimer tm(LBL_REDUCE);
   hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(1024), 0, ctx.stream, ctx.partials, n, dst, accumulate, skip);
   HIP_CHECK(hipGetLastError());
 }
@@ -598,6 +650,7 @@ Coef make_coef(const REAL* cf, REAL omg) {
 template <int OP>
 void launch_ewise(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL bcoef, const Box& b) {
   if (b.empty) return;
+  ScopedTimer tm(LBL_EWISE);
   const int nplanes = b.jj1 - b.jj0 + 1;
   if (vec_ok(b, {Z, X, Y})) {
     EGeom e = make_egeom<VW>(b);
@@ -620,6 +673,8 @@ void launch_dot(const REAL* X, const REAL* Y, const Box& b, double* dst) {
   }
   const int nplanes = b.jj1 - b.jj0 + 1;
   size_t nblk;
+  {
+  ScopedTimer tm(LBL_DOT);
   if (vec_ok(b, {X, Y})) {
     EGeom e = make_egeom<VW>(b);
     dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
@@ -632,6 +687,7 @@ void launch_dot(const REAL* X, const REAL* Y, const Box& b, double* dst) {
     nblk = (size_t)grid.x * grid.y;
     ensure_partials(nblk);
     hipLaunchKernelGGL((dot_k<1, TWO>), grid, dim3(256), 0, ctx.stream, X, Y, e, ctx.partials);
+  }
   }
   HIP_CHECK(hipGetLastError());
   reduce_partials((int)nblk, dst, 0, nullptr);
@@ -783,6 +839,33 @@ int czhip_set_tuning(int threads, int m, int tj, int pf) {
 
 void czhip_get_tuning(int* threads, int* m, int* tj, int* pf) {
   *threads = ctx.tune.threads, *m = ctx.tune.m, *tj = ctx.tune.tj, *pf = ctx.tune.pf;
+}
+
+void czhip_timing(int enable) {
+  ensure_init();
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  for (auto& e : ctx.ev_used) ctx.ev_free.push_back(e);
+  ctx.ev_used.clear();
+  ctx.timing = enable != 0;
+}
+
+int czhip_timing_read(const char* label, double* total_ms) {
+  ensure_init();
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  int want = -1;
+  for (int l = 0; l < LBL_COUNT; l++)
+    if (!strcmp(kLabelNames[l], label)) want = l;
+  double tot = 0.0;
+  int n = 0;
+  for (auto& e : ctx.ev_used) {
+    if (e.label != want) continue;
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+    tot += ms;
+    n++;
+  }
+  if (total_ms) *total_ms = tot;
+  return n;
 }
 
 // ============================================================================================================
@@ -970,6 +1053,17 @@ void dot1_async(const REAL* p, const int* sz, const int* idx, int g, double* dst
 }
 void dot2_async(const REAL* p, const REAL* q, const int* sz, const int* idx, int g, double* dst_dev) {
   launch_dot<1>(p, q, make_box(sz, idx, g), dst_dev);
+}
+void copy_shell_async(REAL* dst, const REAL* src, const int* sz, const int* idx, int g) {
+  ensure_init();
+  const int nkp = sz[2] + 2 * g, nip = sz[0] + 2 * g, njp = sz[1] + 2 * g;
+  const long long rows = (long long)nip * njp;
+  hipLaunchKernelGGL(copy_shell_k, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx.stream, dst, src, nkp, nip, njp,
+                     idx[4] + g - 1, idx[5] + g - 1, idx[0] + g - 1, idx[1] + g - 1, idx[2] + g - 1, idx[3] + g - 1);
+  HIP_CHECK(hipGetLastError());
+}
+void copy_inner_async(REAL* dst, const REAL* src, const int* sz, const int* idx, int g) {
+  launch_ewise<OP_COPY>(dst, src, nullptr, (REAL)0, (REAL)0, make_box(sz, idx, g));
 }
 void bc_async(const int* sz, int g, REAL* p, REAL dh, const REAL* org, const int* nID) {
   // same launches as bc_k_ without the trailing synchronisation

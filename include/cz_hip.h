@@ -94,6 +94,12 @@ void* czhip_stream(void);                /* the hipStream_t every kernel of this
 int czhip_set_tuning(int threads, int vec_per_thread, int planes_per_chunk, int prefetch);
 void czhip_get_tuning(int* threads, int* vec_per_thread, int* planes_per_chunk, int* prefetch);
 
+/* Per-launch HIP-event timing on the library's stream (bench.py's roofline leg): enable(1) starts a fresh
+ * collection, enable(0) stops it; czhip_timing_read returns the number of launches recorded under `label`
+ * ("jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot") and their summed duration in ms. */
+void czhip_timing(int enable);
+int czhip_timing_read(const char* label, double* total_ms);
+
 /* ------------------------------------------------------------------------------------------------
  * Part 3 -- asynchronous device-resident operations (stream-ordered, no host synchronisation)
  * ---------------------------------------------------------------------------------------------- */
@@ -141,6 +147,27 @@ double cz_error_max(cz_handle*, int* loc3);   /* debug epilogue, cz_Evaluate.cpp
 void cz_set_quiet(cz_handle*, int quiet);     /* suppress stdout / history file (tests, bench) */
 double cz_last_solve_seconds(const cz_handle*);
 double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
+
+void cz_set_debug(cz_handle*, int mode);      /* main.cpp:38-42: 1 = run the analytic-error epilogue in cz_evaluate */
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 5 -- multi-GPU bootstrap (replaces MPI_Init / CBrick set-up, main.cpp:33-35, cz_Evaluate.cpp:103-159).
+ * One process per GPU.  Rank 0 creates the RCCL unique id, the launcher (torch.distributed in bench.py, a shared
+ * file for the `cz` binary) hands the bytes to every rank, every rank joins BEFORE cz_setup(); cz_setup then takes
+ * rank / size from the communicator and decomposes the cube.  Nothing to call for a single-GPU run.
+ * ---------------------------------------------------------------------------------------------- */
+int cz_comm_unique_id_bytes(void);
+int cz_comm_get_unique_id(char* out_bytes);
+int cz_comm_bootstrap(int rank, int nranks, const char* id_bytes);
+void cz_comm_shutdown(void);
+/* Host-only decomposition helpers (no GPU needed): automatic division and the brick of one rank
+ * (local size, 1-based global head index, neighbour table I-,I+,J-,J+,K-,K+ with -1 = physical boundary). */
+void cz_comm_auto_division(int nproc, const int* G_size, int* G_div);
+int cz_comm_decompose(const int* G_size, const int* G_div, int nproc, int rank, int* size, int* head, int* nID);
+/* Test transport: n ranks as n host threads of one process on one GPU (device-to-device copies instead of RCCL). */
+void* cz_comm_local_world(int n);
+void cz_comm_local_world_free(void* world);
+int cz_comm_bootstrap_local(void* world, int rank);
 
 #ifdef __cplusplus
 }

@@ -220,8 +220,11 @@ class Result:
 class CZ:
     """Single-domain restatement of class CZ's solve path (cz.h:84-181)."""
 
-    def __init__(self, kernels: Kernels):
+    def __init__(self, kernels: Kernels, wide: bool = False):
+        """wide=True: residuals and dot products come from the double accumulation of the same REAL-rounded
+        terms (oracle back-end only) -- the mode the GPU path is compared with (SURVEY.md 8c tolerance chain)."""
         self.k = kernels
+        self.wide = wide
         R = kernels.real
         self.R = R
         self.cf = np.array([1, 1, 1, 1, 1, 1, 6], dtype=R)  # cz.h:169-172
@@ -247,7 +250,12 @@ class CZ:
     def JACOBI(self, X, B, itr_max, converge_check=True):
         k, res, itr = self.k, 0.0, 1
         while itr <= itr_max:
-            res = k.jacobi(X, self.size, self.idx, self.cf, self.ac1, B, self.WRK, res=0.0)
+            if self.wide:
+                w = np.zeros(1)
+                k.jacobi(X, self.size, self.idx, self.cf, self.ac1, B, self.WRK, res=0.0, wide=w)
+                res = float(w[0])
+            else:
+                res = k.jacobi(X, self.size, self.idx, self.cf, self.ac1, B, self.WRK, res=0.0)
             if converge_check:
                 res = math.sqrt(res * self.res_normal)
                 self.history.append((itr, res))
@@ -263,8 +271,11 @@ class CZ:
         ip = 0  # numProc == 1 (:183-186)
         while itr <= itr_max:
             res = 0.0
+            w = np.zeros(1) if self.wide else None
             for color in (0, 1):
-                res = k.psor2sma_core(X, self.size, self.idx, self.cf, ip, color, self.ac1, B, res=res)
+                res = k.psor2sma_core(X, self.size, self.idx, self.cf, ip, color, self.ac1, B, res=res, wide=w)
+            if self.wide:
+                res = float(w[0])
             if converge_check:
                 res = math.sqrt(res * self.res_normal)
                 self.history.append((itr, res))
@@ -286,6 +297,22 @@ class CZ:
     # cz_Poisson.cpp:332-504
     def PBiCGSTAB(self, X, B, ItrMax, pc):
         k, R, sz, idx = self.k, self.R, self.size, self.idx
+        if self.wide:
+            def dot1(x):
+                w = np.zeros(1)
+                k.blas_dot1(x, sz, idx, wide=w)
+                return R(w[0])
+
+            def dot2(x, y):
+                w = np.zeros(1)
+                k.blas_dot2(x, y, sz, idx, wide=w)
+                return R(w[0])
+        else:
+            def dot1(x):
+                return k.blas_dot1(x, sz, idx)
+
+            def dot2(x, y):
+                return k.blas_dot2(x, y, sz, idx)
         a = {n: k.alloc(sz) for n in ("p", "p_", "r", "r0", "q", "s", "s_", "t_")}
         res = 0.0
         k.blas_clear(a["q"], sz)
@@ -294,7 +321,7 @@ class CZ:
         rho_old, alpha, omega = R(1.0), R(0.0), R(1.0)
         itr = 1
         while itr < ItrMax:  # strict '<' (:373)
-            rho = k.blas_dot2(a["r"], a["r0"], sz, idx)
+            rho = dot2(a["r"], a["r0"])
             if abs(float(rho)) < FLT_MIN:
                 itr = 0
                 break
@@ -306,15 +333,15 @@ class CZ:
             k.blas_clear(a["p_"], sz)
             self.Preconditioner(a["p_"], a["p"], pc)
             k.blas_calc_ax(a["q"], a["p_"], sz, idx, self.cf)
-            alpha = R(rho / k.blas_dot2(a["q"], a["r0"], sz, idx))  # :427
+            alpha = R(rho / dot2(a["q"], a["r0"]))  # :427
             k.blas_triad(a["s"], a["q"], a["r"], R(-alpha), sz, idx)
             k.blas_clear(a["s_"], sz)
             self.Preconditioner(a["s_"], a["s"], pc)
             k.blas_calc_ax(a["t_"], a["s_"], sz, idx, self.cf)
-            omega = R(k.blas_dot2(a["t_"], a["s"], sz, idx) / k.blas_dot1(a["t_"], sz, idx))  # :464
+            omega = R(dot2(a["t_"], a["s"]) / dot1(a["t_"]))  # :464
             k.blas_bicg_2(X, a["p_"], a["s_"], alpha, omega, sz, idx)
             k.blas_triad(a["r"], a["t_"], a["s"], R(-omega), sz, idx)
-            res = float(k.blas_dot1(a["r"], sz, idx))
+            res = float(dot1(a["r"]))
             res = math.sqrt(res * self.res_normal)
             self.history.append((itr, res))
             k.bc_k(sz, X, self.pitch, self.origin, self.nID)
@@ -331,9 +358,9 @@ class CZ:
         return self.k.err_t(self.size, self.idx, self.P, e)
 
 
-def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", with_error=False) -> Result:
+def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", with_error=False, wide=False) -> Result:
     """``cz gsz_x gsz_y gsz_z solver ItrMax coef [precond]`` on the chosen back-end, one thread semantics."""
-    cz = CZ(Kernels(kind, prec))
+    cz = CZ(Kernels(kind, prec), wide=wide)
     cz.setup(gsz, coef)
     if solver == "jacobi":
         itr, res = cz.JACOBI(cz.P, cz.RHS, itr_max)

@@ -1,0 +1,105 @@
+"""GPU test (-m gpu) of the decomposed solver path on ONE GPU: the ranks of a Cartesian division run as host threads
+of this process and exchange faces through the LOCAL transport of cz_comm.cpp (device-to-device copies in place of
+RCCL send/recv; same pack/unpack kernels, same decomposition, same inner ranges, same colouring).
+
+Contract: decomposed run == single-domain run, field bit-for-bit (Jacobi, RB-SOR), iteration count
+equal, residual to summation-order tolerance; BiCGSTAB to 1e-9."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _single(prec, gsz, solver, itmax, coef, pc=None):
+    from cubez_amd import CZ
+    cz = CZ(prec, quiet=True)
+    a = list(gsz) + [solver, itmax, coef] + ([pc] if pc else [])
+    assert cz.setup(a) == 1
+    itr = cz.solve()
+    out = (itr, cz.res, cz.history(), cz.field())
+    cz.close()
+    return out
+
+
+def _decomposed(prec, gsz, solver, itmax, coef, div, pc=None):
+    from cubez_amd import CZ, load
+    lib = load(prec)
+    import ctypes as C
+    lib.cz_comm_local_world.restype = C.c_void_p
+    lib.cz_comm_bootstrap_local.argtypes = [C.c_void_p, C.c_int]
+    lib.cz_comm_local_world_free.argtypes = [C.c_void_p]
+    n = div[0] * div[1] * div[2]
+    world = lib.cz_comm_local_world(n)
+    results, errors = [None] * n, []
+
+    def work(r):
+        try:
+            lib.cz_comm_bootstrap_local(world, r)
+            cz = CZ(prec, quiet=True)
+            a = list(gsz) + [solver, itmax, coef] + ([pc] if pc else []) + list(div)
+            assert cz.setup(a) == 1
+            itr = cz.solve()
+            results[r] = (itr, cz.res, cz.history(), cz.field(), cz.local())
+            cz.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    lib.cz_comm_local_world_free(world)
+    # assemble the global field from the owned cells of every brick
+    g = 2
+    real = results[0][3].dtype
+    G = np.zeros((gsz[1] + 4, gsz[0] + 4, gsz[2] + 4), dtype=real)
+    for itr, res, hist, P, loc in results:
+        (ni, nj, nk), (hi, hj, hk) = loc["size"], loc["head"]
+        G[g + hj - 1:g + hj - 1 + nj, g + hi - 1:g + hi - 1 + ni, g + hk - 1:g + hk - 1 + nk] = P[g:g + nj, g:g + ni, g:g + nk]
+    return results, G
+
+
+CASES = [
+    ("f32", (40, 36, 44), "jacobi", 25, 0.8, (1, 2, 1)),
+    ("f32", (40, 36, 44), "jacobi", 25, 0.8, (2, 1, 1)),
+    ("f32", (40, 36, 44), "jacobi", 24, 0.8, (1, 1, 2)),
+    ("f32", (41, 37, 45), "jacobi", 17, 0.8, (2, 2, 2)),     # uneven bricks, odd sizes (scalar path)
+    ("f64", (36, 40, 44), "jacobi", 20, 0.9, (2, 2, 1)),
+    ("f32", (40, 36, 44), "sor2sma", 20, 1.5, (1, 2, 1)),
+    ("f32", (41, 37, 45), "sor2sma", 15, 1.5, (2, 2, 2)),    # odd heads: colour offset per brick
+    ("f64", (36, 40, 44), "sor2sma", 20, 1.4, (2, 1, 2)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[2]}_{c[0]}_{'x'.join(map(str, c[5]))}" for c in CASES])
+def test_decomposed_equals_single_domain(case):
+    prec, gsz, solver, itmax, coef, div = case
+    itr1, res1, hist1, P1 = _single(prec, gsz, solver, itmax, coef)
+    results, G = _decomposed(prec, gsz, solver, itmax, coef, div)
+    g = 2
+    inner = (slice(g, -g),) * 3
+    assert G[inner].tobytes() == P1[inner].tobytes()
+    for itr, res, hist, P, loc in results:
+        assert itr == itr1
+        assert np.allclose(hist, hist1, rtol=1e-12, atol=0)
+
+
+def test_decomposed_converges_at_the_same_iteration():
+    prec, gsz = "f64", (32, 32, 32)
+    itr1, res1, hist1, P1 = _single(prec, gsz, "sor2sma", 100000, 1.5)
+    results, G = _decomposed(prec, gsz, "sor2sma", 100000, 1.5, (2, 2, 1))
+    assert all(r[0] == itr1 for r in results)
+    assert G[2:-2, 2:-2, 2:-2].tobytes() == P1[2:-2, 2:-2, 2:-2].tobytes()
+
+
+@pytest.mark.parametrize("pc", ["jacobi", "sor2sma"])
+def test_decomposed_bicgstab(pc):
+    prec, gsz = "f64", (32, 36, 40)
+    itr1, res1, hist1, P1 = _single(prec, gsz, "pbicgstab", 200, 0.8 if pc == "jacobi" else 1.5, pc)
+    results, G = _decomposed(prec, gsz, "pbicgstab", 200, 0.8 if pc == "jacobi" else 1.5, (2, 1, 2), pc)
+    assert all(r[0] == itr1 for r in results)
+    assert np.allclose(results[0][2], hist1, rtol=1e-6, atol=0)
+    assert np.abs(G[2:-2, 2:-2, 2:-2] - P1[2:-2, 2:-2, 2:-2]).max() < 1e-9

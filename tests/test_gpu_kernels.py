@@ -154,12 +154,12 @@ def test_random_boxes_vs_oracle(prec, box):
     wide = np.zeros(1)
     d1 = ko.blas_dot1(p, sz, idx, wide=wide)
     d2 = h.blas_dot1(dp, sz, idx)
-    assert d2 == R(wide[0]) or _rel(float(d2), wide[0]) < (1.3e-7 if prec == "f32" else 1e-15)
+    assert d2 == R(wide[0]) or _rel(float(d2), wide[0]) < (1.3e-7 if prec == "f32" else RTOL_WIDE * 10)
     assert _rel(float(d2), float(d1)) < _real_tol(prec) or float(d1) == 0.0
     wide = np.zeros(1)
     d1 = ko.blas_dot2(p, q, sz, idx, wide=wide)
     d2 = h.blas_dot2(dp, dq, sz, idx)
-    assert d2 == R(wide[0]) or abs(float(d2) - wide[0]) <= 1e-6 * max(1.0, abs(wide[0]))
+    assert d2 == R(wide[0]) or abs(float(d2) - wide[0]) <= (1e-6 if prec == "f32" else 1e-11) * max(1.0, abs(wide[0]))
 
     # axpy family
     o1, o2 = sentinel.copy(), h.alloc(sz, sentinel)
