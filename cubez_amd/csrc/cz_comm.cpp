@@ -132,9 +132,10 @@ void comm_auto_division(int nproc, const int G[3], int D[3]) {
       // exchanged elements per brick (both directions folded): cut faces only; packed faces cost a little more
       const double li = (double)G[0] / di, lj = (double)G[1] / dj, lk = (double)G[2] / dk;
       double cost = 0.0;
-      if (dj > 1) cost += li * lk * 1.00;  // J face: contiguous
-      if (di > 1) cost += lj * lk * 1.02;  // I face: k-rows
-      if (dk > 1) cost += li * lj * 1.05;  // K face: strided
+      // the busiest brick has min(2, d-1) cut faces per axis
+      cost += std::min(2, dj - 1) * li * lk * 1.00;  // J face: contiguous
+      cost += std::min(2, di - 1) * lj * lk * 1.02;  // I face: k-rows
+      cost += std::min(2, dk - 1) * li * lj * 1.05;  // K face: strided
       if (best < 0 || cost < best) {
         best = cost;
         bd[0] = di, bd[1] = dj, bd[2] = dk;

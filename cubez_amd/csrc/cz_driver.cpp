@@ -236,9 +236,10 @@ int CZ::Setup(int argc, char** argv) {
   ItrMax = atoi(argv[5]);  // :330
 
   // :375-386  boundary values on P and RHS, ghost layers filled from the neighbours
-  bc_async(size, gc, P, pitch[0], origin, nID);
+  // (global origin + integer brick offset instead of the brick origin: bit-identical faces on every decomposition)
+  bc_async(size, gc, P, pitch[0], G_origin, nID, head[0] - 1, head[1] - 1);
   if (!Comm_S(P)) return 0;
-  bc_async(size, gc, RHS, pitch[0], origin, nID);
+  bc_async(size, gc, RHS, pitch[0], G_origin, nID, head[0] - 1, head[1] - 1);
   if (!Comm_S(RHS)) return 0;
   czhip_sync();
   set_up = true;
@@ -622,9 +623,9 @@ double CZ::ErrorMax(int loc[3]) {
   for (int j = innerFidx[J_minus]; j <= innerFidx[J_plus]; j++)
     for (int i = innerFidx[I_minus]; i <= innerFidx[I_plus]; i++)
       for (int k = innerFidx[K_minus]; k <= innerFidx[K_plus]; k++) {
-        const REAL_TYPE x = origin[0] + dh * (REAL_TYPE)(i - 1);
-        const REAL_TYPE y = origin[1] + dh * (REAL_TYPE)(j - 1);
-        const REAL_TYPE z = origin[2] + dh * (REAL_TYPE)(k - 1);
+        const REAL_TYPE x = G_origin[0] + dh * (REAL_TYPE)(head[0] - 1 + i - 1);
+        const REAL_TYPE y = G_origin[1] + dh * (REAL_TYPE)(head[1] - 1 + j - 1);
+        const REAL_TYPE z = G_origin[2] + dh * (REAL_TYPE)(head[2] - 1 + k - 1);
         const REAL_TYPE e = CZ_SIN(pi * x) * CZ_SIN(pi * y) / CZ_SINH(r2 * pi) *
                             (CZ_SINH(r2 * pi * z) - CZ_SINH(r2 * pi * (z - (REAL_TYPE)1.0)));  // cz_utility.f90:75
         const REAL_TYPE r = p[(size_t)(k + g - 1) + (size_t)(i + g - 1) * nk + (size_t)(j + g - 1) * nk * ni] - e;

@@ -31,7 +31,7 @@ void dot1_async(const CZ_REAL* p, const int* sz, const int* idx, int g, double* 
 void dot2_async(const CZ_REAL* p, const CZ_REAL* q, const int* sz, const int* idx, int g, double* dst_dev);
 void copy_shell_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
 void copy_inner_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
-void bc_async(const int* sz, int g, CZ_REAL* p, CZ_REAL dh, const CZ_REAL* org, const int* nID);
+void bc_async(const int* sz, int g, CZ_REAL* p, CZ_REAL dh, const CZ_REAL* org, const int* nID, int ioff = 0, int joff = 0);
 }  // namespace czhip_internal
 
 #endif

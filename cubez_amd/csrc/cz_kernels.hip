@@ -704,8 +704,12 @@ inline double npts(const int* idx) {
 }
 
 // Host evaluation of the Dirichlet table sin(pi*x)*sin(pi*y), cz_solver.f90:36,52-58.
-REAL* bc_table(int ix, int jx, REAL dh, const REAL* org) {
-  std::vector<double> key = {(double)ix, (double)jx, (double)dh, (double)org[0], (double)org[1]};
+// ioff/joff: brick offset in global cells (head-1).  The reference evaluates x = org + dh*real(i-1) with the BRICK
+// origin org = G_origin + (head-1)*dh (cz_Evaluate.cpp:136-138), which rounds differently from the single-domain
+// x = G_origin + dh*real(i_global-1); the driver passes the global origin plus an integer offset instead so that a
+// decomposed run carries bit-identical Dirichlet data (ioff = joff = 0 reproduces the reference expression exactly).
+REAL* bc_table(int ix, int jx, REAL dh, const REAL* org, int ioff = 0, int joff = 0) {
+  std::vector<double> key = {(double)ix, (double)jx, (double)dh, (double)org[0], (double)org[1], (double)ioff, (double)joff};
   auto it = ctx.bc_tabs.find(key);
   if (it != ctx.bc_tabs.end()) return it->second;
   std::vector<REAL> tab((size_t)ix * jx);
@@ -717,8 +721,8 @@ REAL* bc_table(int ix, int jx, REAL dh, const REAL* org) {
 #endif
   for (int j = 1; j <= jx; j++)
     for (int i = 1; i <= ix; i++) {
-      const REAL x = org[0] + dh * (REAL)(i - 1);
-      const REAL y = org[1] + dh * (REAL)(j - 1);
+      const REAL x = org[0] + dh * (REAL)(ioff + i - 1);
+      const REAL y = org[1] + dh * (REAL)(joff + j - 1);
 #ifdef CZ_REAL_IS_DOUBLE
       tab[(size_t)(j - 1) * ix + (i - 1)] = sin(pi * x) * sin(pi * y);
 #else
@@ -1065,12 +1069,13 @@ void copy_shell_async(REAL* dst, const REAL* src, const int* sz, const int* idx,
 void copy_inner_async(REAL* dst, const REAL* src, const int* sz, const int* idx, int g) {
   launch_ewise<OP_COPY>(dst, src, nullptr, (REAL)0, (REAL)0, make_box(sz, idx, g));
 }
-void bc_async(const int* sz, int g, REAL* p, REAL dh, const REAL* org, const int* nID) {
+void bc_async(const int* sz, int g, REAL* p, REAL dh, const REAL* org, const int* nID, int ioff, int joff) {
   // same launches as bc_k_ without the trailing synchronisation
+  ensure_init();
   const int ix = sz[0], jx = sz[1], kx = sz[2];
   const int nkp = kx + 2 * g, nip = ix + 2 * g;
   if (nID[4] < 0 || nID[5] < 0) {
-    const REAL* tab = bc_table(ix, jx, dh, org);
+    const REAL* tab = bc_table(ix, jx, dh, org, ioff, joff);
     dim3 grid((ix + 127) / 128, jx);
     if (nID[4] < 0) hipLaunchKernelGGL(bc_kface_k, grid, dim3(128), 0, ctx.stream, p, tab, ix, jx, 1, g, nkp, nip);
     if (nID[5] < 0) hipLaunchKernelGGL(bc_kface_k, grid, dim3(128), 0, ctx.stream, p, tab, ix, jx, kx, g, nkp, nip);
