@@ -381,12 +381,19 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
   for (itr = 1; itr <= itr_max && !stop; itr++) {
     REAL_TYPE* src = buf[(itr - 1) & 1];
     REAL_TYPE* dst = buf[itr & 1];
-    czhip_jacobi_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, 0, skip);  // :58
+    const bool fused_check = converge_check && numProc == 1;  // no all-reduce between sweep and test: one launch
+    if (fused_check)
+      czhip_jacobi_checked_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, res_normal, eps, itr, d_hist, d_flag,
+                                 d_flag + 1);  // :58 + :67-77
+    else
+      czhip_jacobi_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, 0, skip);  // :58
     flop += 18.0 * npts();
     if (!Comm_S(dst, skip)) return 0;  // :63
     if (converge_check) {
-      if (!Comm_SUM_dev(d_res, 1, skip)) return 0;                                         // :67
-      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);          // :69-77
+      if (!fused_check) {
+        if (!Comm_SUM_dev(d_res, 1, skip)) return 0;                                         // :67
+        czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);          // :69-77
+      }
       if (itr % POLL_EVERY == 0 && itr < itr_max) {
         // lagging, non-blocking view of the flag: look at the copy issued two polls ago
         const int slot = npoll % POLL_SLOTS;
@@ -439,16 +446,23 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   bool stop = false;
   int itr;
   for (itr = 1; itr <= itr_max && !stop; itr++) {
+    const bool fused_check = converge_check && numProc == 1;
     for (int color = 0; color < 2; color++) {  // :205-209
-      czhip_rbsor_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, color, skip);
+      if (fused_check && color == 1)
+        czhip_rbsor_checked_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, 1, res_normal, eps, itr, d_hist,
+                                  d_flag, d_flag + 1);
+      else
+        czhip_rbsor_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, color, skip);
       flop += 9.0 * npts();
       // the reference exchanges once per iteration (:215); exchanging after each colour makes the decomposed run
       // identical to the single-domain one
       if (!Comm_S(X, skip)) return 0;
     }
     if (converge_check) {
-      if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
-      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+      if (!fused_check) {
+        if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
+        czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+      }
       if (itr % POLL_EVERY == 0 && itr < itr_max) {
         const int slot = npoll % POLL_SLOTS;
         if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));

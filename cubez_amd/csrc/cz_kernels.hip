@@ -59,13 +59,45 @@ struct Geom {
 
 enum { MODE_JACOBI = 0, MODE_RB = 1, MODE_AX = 2, MODE_RK = 3 };
 
+// In-kernel finalisation of the residual: the workgroup that arrives last sums the per-workgroup partials in a fixed
+// order (deterministic) and, if asked, performs the convergence bookkeeping of cz_Poisson.cpp:67-77 -- no extra
+// launches per sweep.  Hand-off follows cdna_hip_programming.md Guideline 16 (release -> ticket -> acquire).
+struct Fin {
+  double* dst = nullptr;  // device double receiving sum dp^2 (nullptr: leave the partials for a separate reduce launch)
+  int accumulate = 0;     // dst += instead of dst =
+  int do_check = 0;       // also: res = sqrt(dst*res_normal); hist[itr] = res; eps test -> flag/conv_itr
+  int itr = 0;
+  double res_normal = 0.0, eps = 0.0;
+  double* hist = nullptr;
+  int* flag = nullptr;
+  int* conv_itr = nullptr;
+  unsigned* counter = nullptr;  // arrival ticket, zero before every launch (the last workgroup resets it)
+};
+
+// 16-byte global accesses go through a native vector type so that hipcc emits one global_load/store_dwordx4
+// (a struct copy was split into dwordx3 + dword stores).
+template <int V>
+struct NatVec {
+  typedef REAL type __attribute__((ext_vector_type(V)));
+};
+template <>
+struct NatVec<1> {
+  typedef REAL type;
+};
 template <int V>
 __device__ __forceinline__ Vec<V> ldv(const REAL* base, long long vec_index) {
-  return *reinterpret_cast<const Vec<V>*>(base + vec_index * V);
+  typedef typename NatVec<V>::type nv;
+  const nv x = *reinterpret_cast<const nv*>(base + vec_index * V);
+  Vec<V> r;
+  __builtin_memcpy(&r, &x, sizeof(r));
+  return r;
 }
 template <int V>
 __device__ __forceinline__ void stv(REAL* base, long long vec_index, const Vec<V>& x) {
-  *reinterpret_cast<Vec<V>*>(base + vec_index * V) = x;
+  typedef typename NatVec<V>::type nv;
+  nv y;
+  __builtin_memcpy(&y, &x, sizeof(y));
+  *reinterpret_cast<nv*>(base + vec_index * V) = y;
 }
 template <int V>
 __device__ __forceinline__ Vec<V> zerov() {
@@ -102,8 +134,8 @@ __device__ __forceinline__ double block_sum(double x, double* wsum /* TB/64 doub
 // ------------------------------------------------------------------------------------------------------------
 template <int V, int TB, int M, int PF, int MODE>
 __global__ void __launch_bounds__(TB)
-stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, double* __restrict__ partials,
-          const int* __restrict__ skip) {
+stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, double* partials,
+          const int* __restrict__ skip, Fin fin) {
   if (skip != nullptr && *skip != 0) return;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,7 +348,44 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
   if (MODE == MODE_JACOBI || MODE == MODE_RB) {
     __syncthreads();
     const double s = block_sum<TB>(acc, wsum);
-    if (t == 0) partials[lb] = s;
+    if (fin.dst == nullptr) {
+      if (t == 0) partials[lb] = s;
+    } else {
+      int* last_flag = reinterpret_cast<int*>(wsum + 16);
+      if (t == 0) {
+        partials[lb] = s;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (ticket == (unsigned)nblk - 1u);
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *last_flag = last;
+      }
+      __syncthreads();
+      if (*last_flag) {
+        double x = 0.0;
+        for (int i = t; i < nblk; i += TB) x += partials[i];
+        __syncthreads();
+        const double tot = block_sum<TB>(x, wsum);
+        if (t == 0) {
+          double r = fin.accumulate ? fin.dst[0] + tot : tot;
+          fin.dst[0] = r;
+          if (fin.do_check) {  // cz_Poisson.cpp:69-77
+            r *= fin.res_normal;
+            r = sqrt(r);
+            fin.hist[fin.itr] = r;
+            if (r < fin.eps) {
+              *fin.flag = 1;
+              *fin.conv_itr = fin.itr;
+            }
+          }
+          *fin.counter = 0u;
+        }
+      }
+    }
   }
 }
 
@@ -459,7 +528,8 @@ copy_shell_k(REAL* __restrict__ dst, const REAL* __restrict__ src, int nkp, int 
 // host side
 // ------------------------------------------------------------------------------------------------------------
 struct Tuning {
-  int threads = 256, m = 2, tj = 0 /* 0 = auto */, pf = 1;
+  int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
+  int fuse_fin = 1;  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
 
 struct Ctx {
@@ -468,6 +538,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   double* partials = nullptr;   // device
   size_t partials_cap = 0;
+  unsigned* counter = nullptr;  // arrival ticket of the in-kernel finalisation
   double* scal_dev = nullptr;   // a few device doubles for the synchronous entry points
   double* scal_host = nullptr;  // pinned
   Tuning tune;
@@ -564,7 +635,7 @@ EGeom make_egeom(const Box& b) {
 
 template <int V, int TB, int M, int PF, int MODE>
 void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, const Box& b, int par, int tj_req,
-                         const int* skip, int* nblk_out) {
+                         const int* skip, int* nblk_out, const Fin& fin) {
   Geom g;
   g.R = b.nkp / V;
   g.PSV = (long long)g.R * b.nip;
@@ -592,7 +663,7 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
   // pad the chunk count to a multiple of 8 when that costs nothing but empty workgroups (keeps the remap on)
   if (((long long)nchunk * g.nseg) % 8 != 0 && nchunk >= 8) nchunk = ((nchunk + 7) / 8) * 8;
   const long long nblk = (long long)nchunk * g.nseg;
-  const size_t lds = (size_t)2 * (g.S + 2 * g.R) * sizeof(Vec<V>) + 16 * sizeof(double);
+  const size_t lds = (size_t)2 * (g.S + 2 * g.R) * sizeof(Vec<V>) + 18 * sizeof(double);
   if (lds > 160 * 1024) {
     fprintf(stderr, "czhip: k-row of %d elements needs %zu bytes of LDS (>160 KiB)\n", b.nkp, lds);
     exit(1);
@@ -607,7 +678,7 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
   {
     ScopedTimer tm(MODE == MODE_JACOBI ? LBL_JACOBI : MODE == MODE_RB ? LBL_RBSOR : MODE == MODE_AX ? LBL_AX : LBL_RK);
     hipLaunchKernelGGL((stencil_k<V, TB, M, PF, MODE>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, P, B, OUT, c, g, par,
-                       ctx.partials, skip);
+                       ctx.partials, skip, fin);
   }
   HIP_CHECK(hipGetLastError());
   if (nblk_out) *nblk_out = (int)nblk;
@@ -615,15 +686,15 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
 
 template <int MODE>
 void launch_stencil(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, const Box& b, int par, const int* skip,
-                    int* nblk_out) {
+                    int* nblk_out, const Fin& fin = Fin()) {
   const Tuning& tu = ctx.tune;
   if (!vec_ok(b, {P, B, OUT})) {
-    launch_stencil_inst<1, 256, 2, 0, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out);
+    launch_stencil_inst<1, 256, 2, 0, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out, fin);
     return;
   }
 #define CZ_INST(TB_, M_, PF_)                                                                      \
   if (tu.threads == TB_ && tu.m == M_ && tu.pf == PF_) {                                           \
-    launch_stencil_inst<VW, TB_, M_, PF_, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out);      \
+    launch_stencil_inst<VW, TB_, M_, PF_, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out, fin); \
     return;                                                                                        \
   }
   if (MODE == MODE_JACOBI || MODE == MODE_RB) {
@@ -632,7 +703,7 @@ void launch_stencil(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, cons
     CZ_INST(1024, 1, 0) CZ_INST(1024, 1, 1) CZ_INST(1024, 2, 0) CZ_INST(1024, 2, 1)
   }
 #undef CZ_INST
-  launch_stencil_inst<VW, 256, 2, 1, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out);
+  launch_stencil_inst<VW, 512, 2, 0, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out, fin);
 }
 
 void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
@@ -738,6 +809,38 @@ REAL* bc_table(int ix, int jx, REAL dh, const REAL* org, int ioff = 0, int joff 
 
 }  // namespace
 
+namespace {
+struct CheckArgs {
+  int enabled = 0, itr = 0;
+  double res_normal = 0.0, eps = 0.0;
+  double* hist = nullptr;
+  int* flag = nullptr;
+  int* conv_itr = nullptr;
+};
+template <int MODE>
+void sweep_async(const REAL* p_in, REAL* p_out, const REAL* b, const Box& bx, const Coef& cf, int par, double* res_dev,
+                 int accumulate, const int* skip, const CheckArgs& ck) {
+  int nblk = 0;
+  if (ctx.tune.fuse_fin) {
+    Fin fin;
+    fin.dst = res_dev, fin.accumulate = accumulate, fin.counter = ctx.counter;
+    fin.do_check = ck.enabled, fin.itr = ck.itr, fin.res_normal = ck.res_normal, fin.eps = ck.eps;
+    fin.hist = ck.hist, fin.flag = ck.flag, fin.conv_itr = ck.conv_itr;
+    launch_stencil<MODE>(p_in, b, p_out, cf, bx, par, skip, &nblk, fin);
+  } else {
+    launch_stencil<MODE>(p_in, b, p_out, cf, bx, par, skip, &nblk);
+    reduce_partials(nblk, res_dev, accumulate, skip);
+    if (ck.enabled) czhip_check_async(res_dev, ck.res_normal, ck.eps, ck.itr, ck.hist, ck.flag, ck.conv_itr);
+  }
+}
+}  // namespace
+
+static inline int rb_parity(int g, const int* idx, int ofst, int color) {
+  // cz_solver.f90:466  k = kst + mod(i+j+kp,2), step 2  <=>  (k + i + j + kst + kp) even  (1-based)
+  // padded 0-based indices shift each of k,i,j by g-1
+  return (3 * (g - 1) + idx[4] + ofst + color) & 1;
+}
+
 // ============================================================================================================
 // Part 2: runtime
 // ============================================================================================================
@@ -767,8 +870,11 @@ int czhip_init(int device) {
   HIP_CHECK(hipMalloc(&ctx.scal_dev, 16 * sizeof(double)));
   HIP_CHECK(hipMemset(ctx.scal_dev, 0, 16 * sizeof(double)));
   HIP_CHECK(hipHostMalloc(&ctx.scal_host, 16 * sizeof(double), hipHostMallocDefault));
+  HIP_CHECK(hipMalloc(&ctx.counter, 64));
+  HIP_CHECK(hipMemset(ctx.counter, 0, 64));
   ctx.ready = true;
   ensure_partials(65536);
+  if (const char* ff = getenv("CZHIP_FUSE_FIN")) ctx.tune.fuse_fin = atoi(ff);
   const char* tu = getenv("CZHIP_TUNING");  // "threads,m,tj,pf"
   if (tu) {
     int a = 0, b = 0, c = 0, d = -1;
@@ -883,9 +989,22 @@ void czhip_jacobi_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, c
     if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
     return;
   }
-  int nblk = 0;
-  launch_stencil<MODE_JACOBI>(p_in, b, p_out, make_coef(cf, omg), bx, 0, skip, &nblk);
-  reduce_partials(nblk, res_dev, accumulate, skip);
+  sweep_async<MODE_JACOBI>(p_in, p_out, b, bx, make_coef(cf, omg), 0, res_dev, accumulate, skip, CheckArgs());
+}
+
+void czhip_jacobi_checked_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g,
+                                const CZ_REAL* cf, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr,
+                                double* hist_dev, int* flag_dev, int* conv_itr_dev) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, g);
+  CheckArgs ck;
+  ck.enabled = 1, ck.itr = itr, ck.res_normal = res_normal, ck.eps = eps, ck.hist = hist_dev, ck.flag = flag_dev, ck.conv_itr = conv_itr_dev;
+  if (bx.empty) {
+    HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    czhip_check_async(res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+    return;
+  }
+  sweep_async<MODE_JACOBI>(p_in, p_out, b, bx, make_coef(cf, omg), 0, res_dev, 0, flag_dev, ck);
 }
 
 void czhip_rbsor_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf, int ofst,
@@ -896,12 +1015,22 @@ void czhip_rbsor_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* i
     if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
     return;
   }
-  // cz_solver.f90:466  k = kst + mod(i+j+kp,2), step 2  <=>  (k + i + j + kst + kp) even  (1-based)
-  // padded 0-based indices shift each of k,i,j by g-1
-  const int par = (3 * (g - 1) + idx[4] + ofst + color) & 1;
-  int nblk = 0;
-  launch_stencil<MODE_RB>(p, b, p, make_coef(cf, omg), bx, par, skip, &nblk);
-  reduce_partials(nblk, res_dev, accumulate, skip);
+  sweep_async<MODE_RB>(p, p, b, bx, make_coef(cf, omg), rb_parity(g, idx, ofst, color), res_dev, accumulate, skip, CheckArgs());
+}
+
+void czhip_rbsor_checked_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf, int ofst,
+                               int color, CZ_REAL omg, double* res_dev, int accumulate, double res_normal, double eps, int itr,
+                               double* hist_dev, int* flag_dev, int* conv_itr_dev) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, g);
+  CheckArgs ck;
+  ck.enabled = 1, ck.itr = itr, ck.res_normal = res_normal, ck.eps = eps, ck.hist = hist_dev, ck.flag = flag_dev, ck.conv_itr = conv_itr_dev;
+  if (bx.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    czhip_check_async(res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+    return;
+  }
+  sweep_async<MODE_RB>(p, p, b, bx, make_coef(cf, omg), rb_parity(g, idx, ofst, color), res_dev, accumulate, flag_dev, ck);
 }
 
 void czhip_check_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,

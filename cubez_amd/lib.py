@@ -16,7 +16,8 @@ ABI_SYMBOLS = [
     "blas_bicg_1_", "blas_bicg_2_", "blas_calc_ax_", "blas_calc_rk_",
     "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
     "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
-    "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async",
+    "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async", "czhip_jacobi_checked_async",
+    "czhip_rbsor_checked_async",
     "cz_create", "cz_destroy", "cz_evaluate", "cz_setup", "cz_solve", "cz_sweeps", "cz_result_iter", "cz_result_res",
     "cz_history", "cz_field", "cz_local_size", "cz_error_max", "cz_set_quiet", "cz_last_solve_seconds", "cz_kernel_ms",
     "cz_set_debug", "czhip_timing", "czhip_timing_read",

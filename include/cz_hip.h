@@ -115,6 +115,16 @@ void czhip_jacobi_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, c
 void czhip_rbsor_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf,
                        int ofst, int color, CZ_REAL omg, double* res_dev, int accumulate, const int* skip_flag_dev);
 
+/* The same sweeps with the convergence bookkeeping of czhip_check_async folded into the sweep kernel (performed by
+ * its last workgroup): one launch per Jacobi iteration, two per RB-SOR iteration (pass the check arguments with the
+ * second colour, accumulate = 1).  flag_dev doubles as the skip flag. */
+void czhip_jacobi_checked_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g,
+                                const CZ_REAL* cf, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr,
+                                double* hist_dev, int* flag_dev, int* conv_itr_dev);
+void czhip_rbsor_checked_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf,
+                               int ofst, int color, CZ_REAL omg, double* res_dev, int accumulate, double res_normal,
+                               double eps, int itr, double* hist_dev, int* flag_dev, int* conv_itr_dev);
+
 /* Convergence bookkeeping on the device (cz_Poisson.cpp:67-77): res = sqrt(res_dev[0]*res_normal);
  * hist_dev[itr] = res; if (res < eps && !*flag) { *flag = 1; conv_itr_dev[0] = itr; }.  No-op when
  * already converged. */

@@ -22,7 +22,8 @@ ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--threads", type=int, default=0)
 args = ap.parse_args()
 
-cores = args.threads or len(os.sched_getaffinity(0))
+# default: the CPU share of a one-GPU box (16) or what the affinity mask allows, whichever is smaller
+cores = args.threads or min(16, len(os.sched_getaffinity(0)))
 os.environ["OMP_NUM_THREADS"] = str(cores)
 os.environ.setdefault("OMP_PROC_BIND", "close")
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
