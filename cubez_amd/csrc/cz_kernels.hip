@@ -61,7 +61,8 @@ enum { MODE_JACOBI = 0, MODE_RB = 1, MODE_AX = 2, MODE_RK = 3 };
 
 // In-kernel finalisation of the residual: the workgroup that arrives last sums the per-workgroup partials in a fixed
 // order (deterministic) and, if asked, performs the convergence bookkeeping of cz_Poisson.cpp:67-77 -- no extra
-// launches per sweep.  Hand-off follows cdna_hip_programming.md Guideline 16 (release -> ticket -> acquire).
+// launches per sweep.  Hand-off follows cdna_hip_programming.md Guideline 16 in its write-through form: sc1 store of
+// the partial -> s_waitcnt vmcnt(0) -> agent-scope ticket add; the last arriver reads every partial with sc1 loads.
 struct Fin {
   double* dst = nullptr;  // device double receiving sum dp^2 (nullptr: leave the partials for a separate reduce launch)
   int accumulate = 0;     // dst += instead of dst =
@@ -353,21 +354,18 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
     } else {
       int* last_flag = reinterpret_cast<int*>(wsum + 16);
       if (t == 0) {
-        partials[lb] = s;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // write-through (sc1) store of the partial, drained, then the ticket: no L2 write-back fence per workgroup
+        // (a release fence here flushes the XCD's dirty p' lines and cost +27 % on the whole sweep, profiles/README.md)
+        __hip_atomic_store(&partials[lb], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (ticket == (unsigned)nblk - 1u);
-        if (last) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        *last_flag = last;
+        *last_flag = (ticket == (unsigned)nblk - 1u);
       }
       __syncthreads();
       if (*last_flag) {
         double x = 0.0;
-        for (int i = t; i < nblk; i += TB) x += partials[i];
+        // every load of the handed-off partials is an sc1 (agent-scope) load
+        for (int i = t; i < nblk; i += TB) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const double tot = block_sum<TB>(x, wsum);
         if (t == 0) {
