@@ -24,6 +24,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include "cz_comm.h"
 
@@ -370,51 +371,86 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
   REAL_TYPE* buf[2] = {X, WRK};
   const int* skip = nullptr;
   if (converge_check) {
-    ensure_hist(itr_max + 2);
+    ensure_hist(itr_max + 3);
     HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
     skip = d_flag;
   }
+  // Single-domain runs apply the sweeps two at a time (czhip_jacobi2_async: temporal blocking, the intermediate field
+  // stays on chip).  Every launch is remembered so that the state at the converged iteration can be produced exactly.
+  struct Launch {
+    int first_itr, nsweep, src;
+  };
+  std::vector<Launch> launches;
+  bool can_pair = (numProc == 1) && czhip_use_t2() != 0;
   hipEvent_t ev[POLL_SLOTS];
-  int npoll = 0;
+  int npoll = 0, cur = 0;
   bool stop = false;
-  int itr;
-  for (itr = 1; itr <= itr_max && !stop; itr++) {
-    REAL_TYPE* src = buf[(itr - 1) & 1];
-    REAL_TYPE* dst = buf[itr & 1];
-    const bool fused_check = converge_check && numProc == 1;  // no all-reduce between sweep and test: one launch
-    if (fused_check)
-      czhip_jacobi_checked_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, res_normal, eps, itr, d_hist, d_flag,
-                                 d_flag + 1);  // :58 + :67-77
-    else
-      czhip_jacobi_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, 0, skip);  // :58
-    flop += 18.0 * npts();
-    if (!Comm_S(dst, skip)) return 0;  // :63
-    if (converge_check) {
-      if (!fused_check) {
-        if (!Comm_SUM_dev(d_res, 1, skip)) return 0;                                         // :67
-        czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);          // :69-77
+  int itr = 1;
+  while (itr <= itr_max && !stop) {
+    REAL_TYPE* src = buf[cur];
+    REAL_TYPE* dst = buf[cur ^ 1];
+    int done = 0;
+    if (can_pair && itr + 1 <= itr_max) {
+      done = 2 * czhip_jacobi2_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, res_normal, eps, itr,
+                                     converge_check ? d_hist : nullptr, d_flag, d_flag + 1);  // :58 + :67-77, twice
+      if (!done) can_pair = false;
+    }
+    if (!done) {
+      const bool fused_check = converge_check && numProc == 1;  // no all-reduce between sweep and test: one launch
+      if (fused_check)
+        czhip_jacobi_checked_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, res_normal, eps, itr, d_hist, d_flag,
+                                   d_flag + 1);  // :58 + :67-77
+      else
+        czhip_jacobi_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, 0, skip);  // :58
+      if (!Comm_S(dst, skip)) return 0;  // :63
+      if (converge_check && !fused_check) {
+        if (!Comm_SUM_dev(d_res, 1, skip)) return 0;                                 // :67
+        czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);  // :69-77
       }
-      if (itr % POLL_EVERY == 0 && itr < itr_max) {
-        // lagging, non-blocking view of the flag: look at the copy issued two polls ago
-        const int slot = npoll % POLL_SLOTS;
-        if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
-        HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(ev[slot], st));
-        npoll++;
-        if (npoll >= 3) {
-          const int old = (npoll - 3) % POLL_SLOTS;
-          HIP_CHECK(hipEventSynchronize(ev[old]));
-          if (h_flag[2 * old] != 0) stop = true;
-        }
+      done = 1;
+    }
+    flop += 18.0 * npts() * done;
+    launches.push_back({itr, done, cur});
+    itr += done;
+    cur ^= 1;
+    if (converge_check && launches.size() % (POLL_EVERY / 2) == 0 && itr <= itr_max) {
+      // lagging, non-blocking view of the flag: look at the copy issued two polls ago
+      const int slot = npoll % POLL_SLOTS;
+      if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
+      HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(ev[slot], st));
+      npoll++;
+      if (npoll >= 3) {
+        const int old = (npoll - 3) % POLL_SLOTS;
+        HIP_CHECK(hipEventSynchronize(ev[old]));
+        if (h_flag[2 * old] != 0) stop = true;
       }
     }
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
-  const int n_exec = converge_check ? (ret > itr_max ? itr_max : ret) : itr_max;
-  if (n_exec & 1) {
-    // the last executed sweep wrote WRK.  The arrays are ours: swap the roles instead of copying back.
+
+  // which buffer holds the iterate of the last executed sweep?
+  int final_buf = 0;
+  if (!launches.empty()) {
+    const Launch* last = &launches.back();
+    if (converge_check && ret <= itr_max) {  // converged at iteration `ret`: find the launch that contains it
+      for (const Launch& l : launches)
+        if (ret >= l.first_itr && ret < l.first_itr + l.nsweep) {
+          last = &l;
+          break;
+        }
+      if (last->nsweep == 2 && ret == last->first_itr) {
+        // the first sweep of a fused pair converged: the pair wrote time n+2 into its destination; its source is
+        // untouched, so one plain sweep reproduces the converged iterate (exactly what the sequential loop holds)
+        czhip_jacobi_async(buf[last->src], buf[last->src ^ 1], B, size, innerFidx, gc, cf, ac1, d_res + 4, 0, nullptr);
+      }
+    }
+    final_buf = last->src ^ 1;
+  }
+  if (final_buf == 1) {
+    // the result is in WRK.  The arrays are ours: swap the roles instead of copying back.
     if (X == P) {
       REAL_TYPE* t = P;
       P = WRK;

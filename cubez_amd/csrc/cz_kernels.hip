@@ -387,6 +387,278 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// TWO relaxed-Jacobi sweeps per pass over memory (temporal blocking, single-domain runs).
+//
+// Each sweep of cz_solver.f90:334-351 is HBM bound at 12 B per update and stencil_k already moves within 5 % of the
+// ideal bytes (profiles/r01), so the only way past the streaming ceiling is to apply sweep n+1 and sweep n+2 while
+// the data are on chip.  Same 2.5-D march as stencil_k, two stages deep:
+//     stage 1 at plane q   : v(q)   = relax(u(q-1), u(q), u(q+1))     on E1 = own segment +- one k-row (R vectors)
+//     stage 2 at plane q-1 : w(q-1) = relax(v(q-2), v(q-1), v(q))     on the own segment
+// u = input field (time n), v = time n+1 (never leaves the CU: registers + LDS), w = output (time n+2).
+// Register queues hold u(q-1..q+1) and v(q-2..q) of the thread's vectors; LDS holds the centre planes u(q) (own
+// segment +- 2 rows) and v(q-1) (own +- 1 row) for the i+-1 / k+-1 neighbours, double-buffered, one barrier per plane.
+// The halo rows of v and the first/last plane of a chunk are recomputed by the neighbouring workgroups (redundant
+// arithmetic, (S+2R)/S in i and (TJ+2)/TJ in j) instead of being exchanged.  Points outside the inner box pass
+// through unchanged (v = u), exactly what a separate first sweep would have left in memory, and the per-point
+// arithmetic is the same un-fused float sequence, so the result is bit-identical to two launches of stencil_k.
+// Both residuals (sum dp^2 of sweep n+1 and of sweep n+2) are produced; each point is counted by the one workgroup
+// that owns it.
+// ------------------------------------------------------------------------------------------------------------
+struct Geom2 {
+  int R;
+  long long PSV;
+  int kk0, kk1, jj0, jj1;
+  long long F0, Fend;
+  int nseg, TJ, S;  // S = TB*MV - 2R
+};
+
+struct Fin2 {
+  double* dst = nullptr;   // [0] <- sum of sweep n+1, [1] <- sum of sweep n+2
+  int do_check = 0, itr = 0;  // itr = iteration number of sweep n+1
+  double res_normal = 0.0, eps = 0.0;
+  double* hist = nullptr;
+  int* flag = nullptr;
+  int* conv_itr = nullptr;
+  unsigned* counter = nullptr;
+};
+
+template <int V>
+__device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
+                                            const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c,
+                                            unsigned mask, unsigned count_mask, double& acc) {
+  Vec<V> o;
+#pragma unroll
+  for (int cc = 0; cc < V; cc++) {
+    const REAL pp = pc.v[cc];
+    const REAL km1 = (cc == 0) ? kl : pc.v[cc > 0 ? cc - 1 : 0];
+    const REAL kp1 = (cc == V - 1) ? kr : pc.v[cc < V - 1 ? cc + 1 : V - 1];
+    const REAL ss = c.c1 * ip.v[cc] + c.c2 * im.v[cc] + c.c3 * pn.v[cc] + c.c4 * pm.v[cc] + c.c5 * kp1 + c.c6 * km1;
+    const REAL dp = ((ss - bb.v[cc]) / c.dd - pp) * c.omg;
+    const REAL d2 = dp * dp;
+    o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;
+    if (count_mask & (1u << cc)) acc += (double)d2;
+  }
+  return o;
+}
+
+template <int V, int TB, int MV>
+__global__ void __launch_bounds__(TB)
+jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
+          const int* __restrict__ skip, Fin2 fin) {
+  if (skip != nullptr && *skip != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int R = g.R;
+  const int LU = g.S + 4 * R, LV = g.S + 2 * R;
+  Vec<V>* ldsU = reinterpret_cast<Vec<V>*>(smem);                 // 2 buffers of LU vectors
+  Vec<V>* ldsV = ldsU + (size_t)2 * LU;                            // 2 buffers of LV vectors
+  double* wsum = reinterpret_cast<double*>(ldsV + (size_t)2 * LV);  // 16 doubles + flag
+
+  int lb = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) lb = (lb & 7) * (nblk >> 3) + (lb >> 3);
+  const int seg = lb % g.nseg;
+  const int chunk = lb / g.nseg;
+  const long long fb = g.F0 + (long long)seg * g.S;
+  const int ja = g.jj0 + chunk * g.TJ;
+  int jb = ja + g.TJ - 1;
+  if (jb > g.jj1) jb = g.jj1;
+
+  double acc1 = 0.0, acc2 = 0.0;
+
+  if (ja <= jb && fb < g.Fend) {
+    const long long e1_0 = fb - R;       // first vector of E1
+    const long long e2_0 = fb - 2 * R;   // first vector of E2
+    long long f[MV];
+    unsigned kb[MV];     // inner-k bits of the vector (0 when its row is not an inner row)
+    unsigned own[MV];    // kb if this workgroup owns the vector (stage 2, stores, residual counts), else 0
+    bool ld[MV];
+#pragma unroll
+    for (int m = 0; m < MV; m++) {
+      const int e = t + m * TB;
+      f[m] = e1_0 + e;
+      ld[m] = (e < LV) && (f[m] < g.PSV);
+      const long long row = f[m] / R;
+      const int kv = (int)(f[m] - row * R);
+      unsigned bits = 0;
+      if (e < LV && f[m] >= g.F0 && f[m] < g.Fend) {
+#pragma unroll
+        for (int cc = 0; cc < V; cc++) {
+          const int kk = kv * V + cc;
+          if (kk >= g.kk0 && kk <= g.kk1) bits |= 1u << cc;
+        }
+      }
+      kb[m] = bits;
+      own[m] = (e >= R && e < R + g.S) ? bits : 0u;
+    }
+
+    Vec<V> ua[MV], ub[MV], uc[MV], b1[MV], b2[MV], va[MV], vb[MV], vc[MV];
+    // prologue: u(ja-2), u(ja-1); LDS_U[0] = u(ja-1) on E2
+    {
+      const REAL* Ua = U + (long long)(ja - 2) * g.PSV * V;
+      const REAL* Ub = U + (long long)(ja - 1) * g.PSV * V;
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        ua[m] = ld[m] ? ldv<V>(Ua, f[m]) : zerov<V>();
+        ub[m] = ld[m] ? ldv<V>(Ub, f[m]) : zerov<V>();
+        b2[m] = zerov<V>();
+        va[m] = zerov<V>();
+        vb[m] = zerov<V>();
+      }
+#pragma unroll
+      for (int m = 0; m < MV; m++)
+        if (t + m * TB < LV) ldsU[R + t + m * TB] = ub[m];
+      if (t < R) {
+        ldsU[t] = ldv<V>(Ub, e2_0 + t);
+        const long long fh = fb + g.S + R + t;
+        ldsU[R + LV + t] = (fh < g.PSV) ? ldv<V>(Ub, fh) : zerov<V>();
+      }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int q = ja - 1; q <= jb + 1; q++) {
+      const bool more = q <= jb;
+      const bool plane_inner = (q >= g.jj0 && q <= g.jj1);
+      const bool count1 = (q >= ja && q <= jb);
+      const bool do2 = (q - 1 >= ja);
+      // ---- loads of this step: u(q+1) and b(q) on E1, outer halo rows of u(q+1)
+      const REAL* Uc = U + (long long)(q + 1) * g.PSV * V;
+      const REAL* Bq = B + (long long)q * g.PSV * V;
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        uc[m] = ld[m] ? ldv<V>(Uc, f[m]) : zerov<V>();
+        b1[m] = (kb[m] != 0 && plane_inner) ? ldv<V>(Bq, f[m]) : zerov<V>();
+      }
+      Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
+      if (more && t < R) {
+        hlo = ldv<V>(Uc, e2_0 + t);
+        const long long fh = fb + g.S + R + t;
+        if (fh < g.PSV) hhi = ldv<V>(Uc, fh);
+      }
+
+      // ---- stage 1: v(q) on E1
+      const Vec<V>* bufU = ldsU + (size_t)cur * LU;
+      const REAL* bufUf = reinterpret_cast<const REAL*>(bufU);
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        const int e = t + m * TB;
+        if (e >= LV) continue;
+        const unsigned msk = plane_inner ? kb[m] : 0u;
+        if (msk == 0) {
+          vc[m] = ub[m];  // outside the inner box: the first sweep leaves the value alone
+        } else {
+          const int x = e + R;
+          const Vec<V> im = bufU[x - R];
+          const Vec<V> ip = bufU[x + R];
+          const REAL kl = bufUf[x * V - 1];
+          const REAL kr = bufUf[x * V + V];
+          vc[m] = relax_vec<V>(ub[m], im, ip, ua[m], uc[m], kl, kr, b1[m], c, msk, count1 ? own[m] : 0u, acc1);
+        }
+      }
+      // ---- publish v(q) for the next step's stage 2
+      {
+        Vec<V>* nV = ldsV + (size_t)(cur ^ 1) * LV;
+#pragma unroll
+        for (int m = 0; m < MV; m++)
+          if (t + m * TB < LV) nV[t + m * TB] = vc[m];
+      }
+      // ---- stage 2: w(q-1) on the own segment
+      if (do2) {
+        const Vec<V>* bufV = ldsV + (size_t)cur * LV;
+        const REAL* bufVf = reinterpret_cast<const REAL*>(bufV);
+        REAL* Wq = W + (long long)(q - 1) * g.PSV * V;
+#pragma unroll
+        for (int m = 0; m < MV; m++) {
+          if (own[m] == 0) continue;
+          const int e = t + m * TB;
+          const Vec<V> im = bufV[e - R];
+          const Vec<V> ip = bufV[e + R];
+          const REAL kl = bufVf[e * V - 1];
+          const REAL kr = bufVf[e * V + V];
+          const Vec<V> o = relax_vec<V>(vb[m], im, ip, va[m], vc[m], kl, kr, b2[m], c, own[m], own[m], acc2);
+          if (own[m] == (1u << V) - 1) {
+            stv<V>(Wq, f[m], o);
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < V; cc++)
+              if (own[m] & (1u << cc)) Wq[f[m] * V + cc] = o.v[cc];
+          }
+        }
+      }
+      // ---- stage the next u centre plane, rotate
+      if (more) {
+        Vec<V>* nU = ldsU + (size_t)(cur ^ 1) * LU;
+#pragma unroll
+        for (int m = 0; m < MV; m++)
+          if (t + m * TB < LV) nU[R + t + m * TB] = uc[m];
+        if (t < R) {
+          nU[t] = hlo;
+          nU[R + LV + t] = hhi;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        ua[m] = ub[m];
+        ub[m] = uc[m];
+        b2[m] = b1[m];
+        va[m] = vb[m];
+        vb[m] = vc[m];
+      }
+      cur ^= 1;
+    }
+  }
+
+  // ---- residuals: per-workgroup partials, finalised by the last workgroup (write-through hand-off, see stencil_k)
+  __syncthreads();
+  const double s1 = block_sum<TB>(acc1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<TB>(acc2, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  if (t == 0) {
+    __hip_atomic_store(&partials[lb], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[nblk + lb], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x1 = 0.0, x2 = 0.0;
+    for (int i = t; i < nblk; i += TB) {
+      x1 += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      x2 += __hip_atomic_load(&partials[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const double t1 = block_sum<TB>(x1, wsum);
+    __syncthreads();
+    const double t2 = block_sum<TB>(x2, wsum);
+    if (t == 0) {
+      fin.dst[0] = t1;
+      fin.dst[1] = t2;
+      if (fin.do_check) {  // cz_Poisson.cpp:69-77 for iteration itr, then itr+1
+        double r = sqrt(t1 * fin.res_normal);
+        fin.hist[fin.itr] = r;
+        if (r < fin.eps) {
+          *fin.flag = 1;
+          *fin.conv_itr = fin.itr;
+        } else {
+          r = sqrt(t2 * fin.res_normal);
+          fin.hist[fin.itr + 1] = r;
+          if (r < fin.eps) {
+            *fin.flag = 1;
+            *fin.conv_itr = fin.itr + 1;
+          }
+        }
+      }
+      *fin.counter = 0u;
+    }
+  }
+}
+
 // sum of n partials in a fixed order -> dst[0] (= or +=).  One workgroup: deterministic.
 __global__ void __launch_bounds__(1024)
 reduce_partials_k(const double* __restrict__ partials, int n, double* __restrict__ dst, int accumulate,
@@ -527,7 +799,9 @@ copy_shell_k(REAL* __restrict__ dst, const REAL* __restrict__ src, int nkp, int 
 // ------------------------------------------------------------------------------------------------------------
 struct Tuning {
   int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
-  int fuse_fin = 1;  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
+  int fuse_fin = 1;
+  int t2_threads = 512, t2_mv = 3, t2_tj = 32;  // two-sweep kernel: threads, vectors/thread, planes/chunk
+  int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
 
 struct Ctx {
@@ -549,8 +823,8 @@ struct Ctx {
 };
 thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
 
-enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_COUNT };
-const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot"};
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_COUNT };
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2"};
 
 struct ScopedTimer {
   bool on;
@@ -708,6 +982,61 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
   ScopedTimer tm(LBL_REDUCE);
   hipLaunchKernelGGL(reduce_partials_k, dim3(1), dim3(1024), 0, ctx.stream, ctx.partials, n, dst, accumulate, skip);
   HIP_CHECK(hipGetLastError());
+}
+
+
+// two fused sweeps; returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
+template <int TB, int MV>
+bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, int tj_req, const int* skip,
+                         const Fin2& fin_in) {
+  constexpr int V = VW;
+  Geom2 g;
+  g.R = b.nkp / V;
+  if (2 * g.R >= TB * MV / 2 || g.R > TB) return false;  // halo rows would dominate / do not fit the loader
+  g.PSV = (long long)g.R * b.nip;
+  g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
+  g.F0 = (long long)b.ii0 * g.R;
+  g.Fend = (long long)(b.ii1 + 1) * g.R;
+  g.S = TB * MV - 2 * g.R;
+  const long long nf = g.Fend - g.F0;
+  g.nseg = (int)((nf + g.S - 1) / g.S);
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  int tj = tj_req;
+  if (tj <= 0) tj = 32;
+  if (tj > nplanes) tj = nplanes;
+  g.TJ = tj;
+  int nchunk = (nplanes + tj - 1) / tj;
+  if (((long long)nchunk * g.nseg) % 8 != 0 && nchunk >= 8) nchunk = ((nchunk + 7) / 8) * 8;
+  const long long nblk = (long long)nchunk * g.nseg;
+  const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double);
+  if (lds > 160 * 1024) return false;
+  ensure_partials((size_t)2 * nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2_k<V, TB, MV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+    attr_set = true;
+  }
+  Fin2 fin = fin_in;
+  fin.counter = ctx.counter;
+  {
+    ScopedTimer tm(LBL_JACOBI2);
+    hipLaunchKernelGGL((jacobi2_k<V, TB, MV>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
+  }
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const int* skip, const Fin2& fin) {
+  if (!vec_ok(b, {U, B, W})) return false;
+  // the two-stage march reads two layers around the box
+  if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
+  const Tuning& tu = ctx.tune;
+#define CZ_INST2(TB_, MV_) \
+  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_>(U, B, W, c, b, tu.t2_tj, skip, fin);
+  CZ_INST2(256, 4) CZ_INST2(256, 6) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(512, 4) CZ_INST2(1024, 2)
+#undef CZ_INST2
+  return launch_jacobi2_inst<512, 3>(U, B, W, c, b, tu.t2_tj, skip, fin);
 }
 
 Coef make_coef(const REAL* cf, REAL omg) {
@@ -873,6 +1202,11 @@ int czhip_init(int device) {
   ctx.ready = true;
   ensure_partials(65536);
   if (const char* ff = getenv("CZHIP_FUSE_FIN")) ctx.tune.fuse_fin = atoi(ff);
+  if (const char* t2 = getenv("CZHIP_T2")) {  // "enable[,threads,mv,tj]"
+    int en = 1, a = 0, b2 = 0, c2 = -1;
+    const int n = sscanf(t2, "%d,%d,%d,%d", &en, &a, &b2, &c2);
+    if (n >= 1) czhip_set_tuning2(n >= 2 ? a : 0, n >= 3 ? b2 : 0, n >= 4 ? c2 : -1, en);
+  }
   const char* tu = getenv("CZHIP_TUNING");  // "threads,m,tj,pf"
   if (tu) {
     int a = 0, b = 0, c = 0, d = -1;
@@ -1030,6 +1364,40 @@ void czhip_rbsor_checked_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, cons
   }
   sweep_async<MODE_RB>(p, p, b, bx, make_coef(cf, omg), rb_parity(g, idx, ofst, color), res_dev, accumulate, flag_dev, ck);
 }
+
+// Two fused Jacobi sweeps u -> w (time n -> n+2).  res_dev[0], res_dev[1] receive sum dp^2 of sweep n+1 / n+2.
+// With check arguments (hist_dev != NULL) the last workgroup also performs the bookkeeping of cz_Poisson.cpp:67-77 for
+// iterations itr and itr+1 in order; a converged first sweep leaves the flag set with conv_itr = itr (the caller then
+// recomputes that single sweep from u, which this kernel never modifies).  Returns 1 if launched, 0 if the geometry
+// is not supported (caller falls back to two single sweeps).
+int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf,
+                        CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
+                        int* conv_itr_dev) {
+  ensure_init();
+  if (!ctx.tune.fuse_fin) return 0;
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty || g < 2) return 0;
+  Fin2 fin;
+  fin.dst = res_dev;
+  if (hist_dev) {
+    fin.do_check = 1, fin.itr = itr, fin.res_normal = res_normal, fin.eps = eps;
+    fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
+  }
+  return launch_jacobi2(u, b, w, make_coef(cf, omg), bx, hist_dev ? flag_dev : nullptr, fin) ? 1 : 0;
+}
+
+int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable) {
+  Tuning t = ctx.tune;
+  if (threads > 0) t.t2_threads = threads;
+  if (vec_per_thread > 0) t.t2_mv = vec_per_thread;
+  if (planes_per_chunk >= 0) t.t2_tj = planes_per_chunk;
+  if (enable >= 0) t.use_t2 = enable;
+  const int k = t.t2_threads * 100 + t.t2_mv;
+  if (k != 25604 && k != 25606 && k != 51202 && k != 51203 && k != 51204 && k != 102402) return 1;
+  ctx.tune = t;
+  return 0;
+}
+int czhip_use_t2(void) { return ctx.tune.use_t2; }
 
 void czhip_check_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                        int* conv_itr_dev) {

@@ -125,6 +125,18 @@ void czhip_rbsor_checked_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, cons
                                int ofst, int color, CZ_REAL omg, double* res_dev, int accumulate, double res_normal,
                                double eps, int itr, double* hist_dev, int* flag_dev, int* conv_itr_dev);
 
+/* TWO Jacobi sweeps per pass over memory (temporal blocking; single-domain, g >= 2): u -> w = two applications of
+ * cz_solver.f90:334-351, bit-identical to two czhip_jacobi_async calls, the intermediate field never leaves the chip.
+ * res_dev[0] / res_dev[1] = sum dp^2 of the first / second sweep.  hist_dev != NULL adds the convergence bookkeeping for
+ * iterations itr and itr+1 (in order; flag_dev doubles as skip flag).  If the FIRST sweep converges, flag is set with
+ * conv_itr = itr and w holds time n+2: the caller re-runs one single sweep from u (never modified).  Returns 1 when
+ * launched, 0 when the geometry is unsupported (caller falls back to single sweeps). */
+int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf,
+                        CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
+                        int* conv_itr_dev);
+int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable); /* 0 / -1 keep; returns 0 if ok */
+int czhip_use_t2(void);
+
 /* Convergence bookkeeping on the device (cz_Poisson.cpp:67-77): res = sqrt(res_dev[0]*res_normal);
  * hist_dev[itr] = res; if (res < eps && !*flag) { *flag = 1; conv_itr_dev[0] = itr; }.  No-op when
  * already converged. */

@@ -233,3 +233,46 @@ def test_residual_is_run_to_run_deterministic():
         vals.add(h.jacobi(a, sz, idx, cf, 0.8, db, w))
         a.free(), w.free()
     assert len(vals) == 1
+
+
+T2_BOXES = [((40, 36, 60), None), ((33, 70, 124), None), ((130, 20, 252), None), ((70, 45, 124), None),
+            ((24, 20, 28), (1, 24, 1, 20, 1, 28)), ((64, 9, 60), None), ((96, 40, 508), None)]
+T2_TUNINGS = [(512, 3, 32), (512, 3, 5), (512, 2, 7), (512, 4, 16), (256, 4, 3), (256, 6, 16), (1024, 2, 11)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", T2_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in T2_BOXES])
+def test_two_fused_sweeps_equal_two_oracle_sweeps(prec, box):
+    """czhip_jacobi2_async (temporal blocking) == two applications of the oracle's jacobi, bit for bit; both residuals."""
+    (ni, nj, nk), idx = box
+    sz = [ni, nj, nk]
+    idx = list(idx) if idx else [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 7 * nj + 13 * nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    cf = rng.uniform(0.5, 1.5, 7).astype(R)
+    cf[6] = 6.2
+    p, b = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    a1, w1, r = p.copy(), np.zeros_like(p), []
+    for _ in range(2):
+        wide = np.zeros(1)
+        ko.jacobi(a1, sz, idx, cf, 0.9, b, w1, wide=wide)
+        r.append(wide[0])
+    du, db = h.alloc(sz, p), h.alloc(sz, b)
+    launched = 0
+    try:
+        for (tb, mv, tj) in T2_TUNINGS:
+            assert h.set_tuning2(tb, mv, tj, 1)
+            dw = h.alloc(sz, p)  # ping-pong partner: same non-inner elements as the input
+            ok, r1, r2 = h.jacobi2(du, dw, db, sz, idx, cf, 0.9)
+            if ok:
+                launched += 1
+                assert _beq(dw.get(), a1), (tb, mv, tj)
+                assert _beq(du.get(), p)  # the input is never modified
+                assert _rel(r1, r[0]) < RTOL_WIDE * 10 and _rel(r2, r[1]) < RTOL_WIDE * 10, (tb, mv, tj)
+            dw.free()
+    finally:
+        h.set_tuning2(512, 3, 32, 1)
+    if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:
+        assert launched > 0
