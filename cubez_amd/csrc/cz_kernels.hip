@@ -800,7 +800,7 @@ copy_shell_k(REAL* __restrict__ dst, const REAL* __restrict__ src, int nkp, int 
 struct Tuning {
   int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
   int fuse_fin = 1;
-  int t2_threads = 512, t2_mv = 3, t2_tj = 32;  // two-sweep kernel: threads, vectors/thread, planes/chunk
+  int t2_threads = 512, t2_mv = 2, t2_tj = 16;  // two-sweep kernel: threads, vectors/thread, planes/chunk
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
 
@@ -1002,7 +1002,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   g.nseg = (int)((nf + g.S - 1) / g.S);
   const int nplanes = b.jj1 - b.jj0 + 1;
   int tj = tj_req;
-  if (tj <= 0) tj = 32;
+  if (tj <= 0) tj = 16;
   if (tj > nplanes) tj = nplanes;
   g.TJ = tj;
   int nchunk = (nplanes + tj - 1) / tj;
@@ -1036,7 +1036,7 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_>(U, B, W, c, b, tu.t2_tj, skip, fin);
   CZ_INST2(256, 4) CZ_INST2(256, 6) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(512, 4) CZ_INST2(1024, 2)
 #undef CZ_INST2
-  return launch_jacobi2_inst<512, 3>(U, B, W, c, b, tu.t2_tj, skip, fin);
+  return launch_jacobi2_inst<512, 2>(U, B, W, c, b, tu.t2_tj, skip, fin);
 }
 
 Coef make_coef(const REAL* cf, REAL omg) {
