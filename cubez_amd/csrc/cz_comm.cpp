@@ -98,6 +98,41 @@ __global__ void unpack_kface_k(T* __restrict__ X, const T* __restrict__ buf, int
   X[(size_t)kk + (size_t)(i + g) * nkp + (size_t)(j + g) * nkp * nip] = buf[(size_t)j * NI + i];
 }
 
+// ---- depth-2 exchange (two ghost layers, edges included) for the two-sweep kernel --------------------------------
+template <typename T>
+__global__ void pack_i2_k(T* __restrict__ buf, const T* __restrict__ X, int NK, int NJ, int nkp, int nip, int ii0, int g,
+                          const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, l = blockIdx.z;
+  if (k >= NK) return;
+  buf[((size_t)l * NJ + j) * NK + k] = X[(size_t)(k + g) + (size_t)(ii0 + l) * nkp + (size_t)(j + g) * nkp * nip];
+}
+template <typename T>
+__global__ void unpack_i2_k(T* __restrict__ X, const T* __restrict__ buf, int NK, int NJ, int nkp, int nip, int ii0, int g,
+                            const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, l = blockIdx.z;
+  if (k >= NK) return;
+  X[(size_t)(k + g) + (size_t)(ii0 + l) * nkp + (size_t)(j + g) * nkp * nip] = buf[((size_t)l * NJ + j) * NK + k];
+}
+// K layers over the WHOLE padded (i,j) extent: carries the i/j ghost values received in the earlier phases (edges)
+template <typename T>
+__global__ void pack_k2_k(T* __restrict__ buf, const T* __restrict__ X, int nkp, int nip, int njp, int kk0,
+                          const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int ii = blockIdx.x * blockDim.x + threadIdx.x, jj = blockIdx.y, l = blockIdx.z;
+  if (ii >= nip) return;
+  buf[((size_t)l * njp + jj) * nip + ii] = X[(size_t)(kk0 + l) + (size_t)ii * nkp + (size_t)jj * nkp * nip];
+}
+template <typename T>
+__global__ void unpack_k2_k(T* __restrict__ X, const T* __restrict__ buf, int nkp, int nip, int njp, int kk0,
+                            const int* __restrict__ skip) {
+  if (skip && *skip) return;
+  const int ii = blockIdx.x * blockDim.x + threadIdx.x, jj = blockIdx.y, l = blockIdx.z;
+  if (ii >= nip) return;
+  X[(size_t)(kk0 + l) + (size_t)ii * nkp + (size_t)jj * nkp * nip] = buf[((size_t)l * njp + jj) * nip + ii];
+}
+
 }  // namespace
 
 struct CommCtx {
@@ -112,6 +147,10 @@ struct CommCtx {
   LocalWorld* world = nullptr;
   void* cur_X = nullptr;  // LOCAL: array being exchanged, published for the neighbours' J-face copies
   double* h_red = nullptr;
+  // depth-2 exchange buffers (allocated on first use): [face] for I-,I+,K-,K+ (J faces travel in place)
+  void* send2[6] = {nullptr};
+  void* recv2[6] = {nullptr};
+  size_t elems2[6] = {0};
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -197,6 +236,10 @@ void comm_destroy(CommCtx* c) {
     if (c->sendbuf[f]) (void)hipFree(c->sendbuf[f]);
     if (c->recvbuf[f]) (void)hipFree(c->recvbuf[f]);
   }
+  for (int f = 0; f < 6; f++) {
+    if (c->send2[f]) (void)hipFree(c->send2[f]);
+    if (c->recv2[f]) (void)hipFree(c->recv2[f]);
+  }
   (void)hipHostFree(c->h_red);
   delete c;
 }
@@ -277,6 +320,106 @@ bool comm_halo(CommCtx* c, void* X, const int* skip, hipStream_t st) {
   if (c->eb == 4) unpack_faces<float>(c, (float*)X, skip, st);
   else unpack_faces<double>(c, (double*)X, skip, st);
   return true;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Depth-2 exchange in three dependent phases I -> J -> K.  Each later phase sends the ghost cells the earlier ones
+// received, so the edge cells the first sweep of a fused pair needs (ghost layer 1 in two directions) arrive after
+// two hops; no diagonal messages.
+//   I: layers i = 1,2 / NI-1,NI of the owned (j,k) extent, packed [layer][j][k]
+//   J: planes j = 1,2 / NJ-1,NJ, whole padded planes, in place (contiguous)
+//   K: layers k = 1,2 / NK-1,NK of the whole padded (i,j) extent, packed [layer][jj][ii]
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+bool halo2_impl(CommCtx* c, T* X, const int* skip, hipStream_t st) {
+  const int NI = c->size[0], NJ = c->size[1], NK = c->size[2], g = c->g;
+  const int nkp = NK + 2 * g, nip = NI + 2 * g, njp = NJ + 2 * g;
+  const size_t PS = (size_t)nkp * nip;
+  const int opp[6] = {1, 0, 3, 2, 5, 4};
+  if (!c->elems2[0]) {
+    c->elems2[0] = c->elems2[1] = (size_t)2 * NJ * NK;
+    c->elems2[2] = c->elems2[3] = (size_t)2 * PS;
+    c->elems2[4] = c->elems2[5] = (size_t)2 * nip * njp;
+    for (int f : {0, 1, 4, 5}) {
+      if (c->nID[f] < 0) continue;
+      HIP_CHECK(hipMalloc(&c->send2[f], c->elems2[f] * sizeof(T)));
+      HIP_CHECK(hipMalloc(&c->recv2[f], c->elems2[f] * sizeof(T)));
+    }
+  }
+  const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
+  auto exchange = [&](int f0, const void* sb0, void* rb0, const void* sb1, void* rb1) {
+    // faces f0 (minus) and f0+1 (plus) of one axis
+    const void* sb[2] = {sb0, sb1};
+    void* rb[2] = {rb0, rb1};
+    if (c->tr == T_RCCL) {
+      if (c->nID[f0] < 0 && c->nID[f0 + 1] < 0) return;
+      NCCL_CHECK(ncclGroupStart());
+      for (int s = 0; s < 2; s++) {
+        const int f = f0 + s;
+        if (c->nID[f] < 0) continue;
+        NCCL_CHECK(ncclSend(sb[s], c->elems2[f], dt, c->nID[f], c->nccl, st));
+        NCCL_CHECK(ncclRecv(rb[s], c->elems2[f], dt, c->nID[f], c->nccl, st));
+      }
+      NCCL_CHECK(ncclGroupEnd());
+    } else {
+      // LOCAL: publish my send pointers, then copy from the neighbours'
+      c->send2[f0 + 0] = const_cast<void*>(sb0);  // (for J these are array regions, for I/K the pack buffers)
+      c->send2[f0 + 1] = const_cast<void*>(sb1);
+      HIP_CHECK(hipStreamSynchronize(st));
+      c->world->barrier();
+      for (int s = 0; s < 2; s++) {
+        const int f = f0 + s;
+        if (c->nID[f] < 0) continue;
+        CommCtx* nb = c->world->ranks[c->nID[f]];
+        HIP_CHECK(hipMemcpyAsync(rb[s], nb->send2[opp[f]], c->elems2[f] * sizeof(T), hipMemcpyDeviceToDevice, st));
+      }
+      HIP_CHECK(hipStreamSynchronize(st));
+      c->world->barrier();
+    }
+  };
+
+  // ---- phase I
+  {
+    dim3 grid((NK + 127) / 128, NJ, 2);
+    void* s0 = c->send2[0];
+    void* s1 = c->send2[1];
+    if (c->nID[0] >= 0) hipLaunchKernelGGL(pack_i2_k<T>, grid, dim3(128), 0, st, (T*)s0, X, NK, NJ, nkp, nip, g, g, skip);
+    if (c->nID[1] >= 0) hipLaunchKernelGGL(pack_i2_k<T>, grid, dim3(128), 0, st, (T*)s1, X, NK, NJ, nkp, nip, NI + g - 2, g, skip);
+    exchange(0, s0, c->recv2[0], s1, c->recv2[1]);
+    c->send2[0] = s0, c->send2[1] = s1;
+    if (c->nID[0] >= 0) hipLaunchKernelGGL(unpack_i2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[0], NK, NJ, nkp, nip, 0, g, skip);
+    if (c->nID[1] >= 0) hipLaunchKernelGGL(unpack_i2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[1], NK, NJ, nkp, nip, NI + g, g, skip);
+  }
+  // ---- phase J (in place: two whole padded planes)
+  {
+    void* keep0 = c->send2[2];
+    void* keep1 = c->send2[3];
+    exchange(2, X + (size_t)g * PS, X, X + (size_t)(NJ + g - 2) * PS, X + (size_t)(NJ + g) * PS);
+    c->send2[2] = keep0, c->send2[3] = keep1;
+  }
+  // ---- phase K
+  {
+    dim3 grid((nip + 127) / 128, njp, 2);
+    void* s0 = c->send2[4];
+    void* s1 = c->send2[5];
+    if (c->nID[4] >= 0) hipLaunchKernelGGL(pack_k2_k<T>, grid, dim3(128), 0, st, (T*)s0, X, nkp, nip, njp, g, skip);
+    if (c->nID[5] >= 0) hipLaunchKernelGGL(pack_k2_k<T>, grid, dim3(128), 0, st, (T*)s1, X, nkp, nip, njp, NK + g - 2, skip);
+    exchange(4, s0, c->recv2[4], s1, c->recv2[5]);
+    c->send2[4] = s0, c->send2[5] = s1;
+    if (c->nID[4] >= 0) hipLaunchKernelGGL(unpack_k2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[4], nkp, nip, njp, 0, skip);
+    if (c->nID[5] >= 0) hipLaunchKernelGGL(unpack_k2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[5], nkp, nip, njp, NK + g, skip);
+  }
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+}  // namespace
+
+bool comm_halo2(CommCtx* c, void* X, const int* skip, hipStream_t st) {
+  if (!c) return true;
+  if (c->g != 2) return false;
+  return c->eb == 4 ? halo2_impl<float>(c, (float*)X, skip, st) : halo2_impl<double>(c, (double*)X, skip, st);
 }
 
 bool comm_allreduce_sum(CommCtx* c, double* d_val, int count, hipStream_t st) {

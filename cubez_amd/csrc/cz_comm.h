@@ -24,6 +24,8 @@ CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], i
 void comm_destroy(CommCtx*);
 // one-layer exchange of the six faces of X (device pointer), stream-ordered on `st`
 bool comm_halo(CommCtx*, void* X, const int* skip_flag_dev, hipStream_t st);
+// two-layer exchange incl. edges (three dependent phases I, J, K); needs g == 2
+bool comm_halo2(CommCtx*, void* X, const int* skip_flag_dev, hipStream_t st);
 bool comm_allreduce_sum(CommCtx*, double* d_val, int count, hipStream_t st);
 double comm_allreduce_max_host(CommCtx*, double v);
 

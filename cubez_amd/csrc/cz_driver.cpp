@@ -238,10 +238,11 @@ int CZ::Setup(int argc, char** argv) {
 
   // :375-386  boundary values on P and RHS, ghost layers filled from the neighbours
   // (global origin + integer brick offset instead of the brick origin: bit-identical faces on every decomposition)
+  // (two ghost layers incl. edges: what a fused pair of Jacobi sweeps reads; a superset of Comm_S(X, 1))
   bc_async(size, gc, P, pitch[0], G_origin, nID, head[0] - 1, head[1] - 1);
-  if (!Comm_S(P)) return 0;
+  if (!Comm_S2(P)) return 0;
   bc_async(size, gc, RHS, pitch[0], G_origin, nID, head[0] - 1, head[1] - 1);
-  if (!Comm_S(RHS)) return 0;
+  if (!Comm_S2(RHS)) return 0;
   czhip_sync();
   set_up = true;
   sweeps_done = 0;
@@ -325,6 +326,10 @@ bool CZ::Comm_S(REAL_TYPE* X, const int* skip_flag) {
   if (numProc == 1) return true;
   return comm_halo(comm, X, skip_flag, stream());
 }
+bool CZ::Comm_S2(REAL_TYPE* X, const int* skip_flag) {
+  if (numProc == 1) return true;
+  return comm_halo2(comm, X, skip_flag, stream());
+}
 bool CZ::Comm_SUM_dev(double* d_val, int count, const int* skip_flag) {
   if (numProc == 1) return true;
   (void)skip_flag;  // all ranks see the same flag, so the collective is issued by all or by none
@@ -381,7 +386,14 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     int first_itr, nsweep, src;
   };
   std::vector<Launch> launches;
-  bool can_pair = (numProc == 1) && czhip_use_t2() != 0;
+  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2;
+  int idx1[6];  // index range of the first sweep of a pair: one layer into the ghost cells across rank-internal faces
+  for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
+  if (can_pair && numProc > 1) {
+    // the pair reads two ghost layers (and the edge cells) of X and one of B
+    if (!Comm_S2(X) || !Comm_S2(B)) return 0;
+    copy_shell_async(WRK, X, size, innerFidx, gc);
+  }
   hipEvent_t ev[POLL_SLOTS];
   int npoll = 0, cur = 0;
   bool stop = false;
@@ -391,9 +403,18 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     REAL_TYPE* dst = buf[cur ^ 1];
     int done = 0;
     if (can_pair && itr + 1 <= itr_max) {
-      done = 2 * czhip_jacobi2_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, res_normal, eps, itr,
-                                     converge_check ? d_hist : nullptr, d_flag, d_flag + 1);  // :58 + :67-77, twice
-      if (!done) can_pair = false;
+      const bool in_kernel_check = converge_check && numProc == 1;
+      done = 2 * czhip_jacobi2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res, res_normal, eps, itr,
+                                     in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :58 + :67-77, twice
+      if (!done) {
+        can_pair = false;
+      } else if (numProc > 1) {
+        if (!Comm_S2(dst, skip)) return 0;  // :63, two layers once per pair
+        if (converge_check) {
+          if (!Comm_SUM_dev(d_res, 2, skip)) return 0;  // :67 for both sweeps in one all-reduce
+          czhip_check2_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+        }
+      }
     }
     if (!done) {
       const bool fused_check = converge_check && numProc == 1;  // no all-reduce between sweep and test: one launch

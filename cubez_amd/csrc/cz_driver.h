@@ -95,6 +95,7 @@ class CZ {
 
   // cz_comm.cpp replacements (no-ops when numProc == 1, like cz_comm.cpp:25,76,104)
   bool Comm_S(REAL_TYPE* X, const int* skip_flag = nullptr);
+  bool Comm_S2(REAL_TYPE* X, const int* skip_flag = nullptr);  // two layers + edges (fused Jacobi pairs)
   bool Comm_SUM_dev(double* d_val, int count, const int* skip_flag = nullptr);
   bool Comm_SUM_1(double* host_val);
 

@@ -409,8 +409,12 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
 struct Geom2 {
   int R;
   long long PSV;
-  int kk0, kk1, jj0, jj1;
+  int kk0, kk1, jj0, jj1;      // stage-2 (output) box = the inner box
   long long F0, Fend;
+  // stage-1 box: the inner box, grown by one layer across rank-internal faces of a decomposed run (the first sweep
+  // must also be applied to the ghost layer the second sweep reads; two ghost layers are exchanged per pair)
+  int kk0a, kk1a, jj0a, jj1a;
+  long long F0a, Fenda;
   int nseg, TJ, S;  // S = TB*MV - 2R
 };
 
@@ -472,8 +476,8 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
     const long long e1_0 = fb - R;       // first vector of E1
     const long long e2_0 = fb - 2 * R;   // first vector of E2
     long long f[MV];
-    unsigned kb[MV];     // inner-k bits of the vector (0 when its row is not an inner row)
-    unsigned own[MV];    // kb if this workgroup owns the vector (stage 2, stores, residual counts), else 0
+    unsigned ka[MV];     // stage-1 bits: components of the vector inside the stage-1 box (0 when the row is outside)
+    unsigned own[MV];    // stage-2 bits if this workgroup owns the vector (stores, residual counts), else 0
     bool ld[MV];
 #pragma unroll
     for (int m = 0; m < MV; m++) {
@@ -482,16 +486,15 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
       ld[m] = (e < LV) && (f[m] < g.PSV);
       const long long row = f[m] / R;
       const int kv = (int)(f[m] - row * R);
-      unsigned bits = 0;
-      if (e < LV && f[m] >= g.F0 && f[m] < g.Fend) {
+      unsigned bits1 = 0, bits2 = 0;
 #pragma unroll
-        for (int cc = 0; cc < V; cc++) {
-          const int kk = kv * V + cc;
-          if (kk >= g.kk0 && kk <= g.kk1) bits |= 1u << cc;
-        }
+      for (int cc = 0; cc < V; cc++) {
+        const int kk = kv * V + cc;
+        if (kk >= g.kk0a && kk <= g.kk1a) bits1 |= 1u << cc;
+        if (kk >= g.kk0 && kk <= g.kk1) bits2 |= 1u << cc;
       }
-      kb[m] = bits;
-      own[m] = (e >= R && e < R + g.S) ? bits : 0u;
+      ka[m] = (e < LV && f[m] >= g.F0a && f[m] < g.Fenda) ? bits1 : 0u;
+      own[m] = (e >= R && e < R + g.S && f[m] >= g.F0 && f[m] < g.Fend) ? bits2 : 0u;
     }
 
     Vec<V> ua[MV], ub[MV], uc[MV], b1[MV], b2[MV], va[MV], vb[MV], vc[MV];
@@ -521,7 +524,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
     int cur = 0;
     for (int q = ja - 1; q <= jb + 1; q++) {
       const bool more = q <= jb;
-      const bool plane_inner = (q >= g.jj0 && q <= g.jj1);
+      const bool plane_inner = (q >= g.jj0a && q <= g.jj1a);
       const bool count1 = (q >= ja && q <= jb);
       const bool do2 = (q - 1 >= ja);
       // ---- loads of this step: u(q+1) and b(q) on E1, outer halo rows of u(q+1)
@@ -530,7 +533,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
 #pragma unroll
       for (int m = 0; m < MV; m++) {
         uc[m] = ld[m] ? ldv<V>(Uc, f[m]) : zerov<V>();
-        b1[m] = (kb[m] != 0 && plane_inner) ? ldv<V>(Bq, f[m]) : zerov<V>();
+        b1[m] = (ka[m] != 0 && plane_inner) ? ldv<V>(Bq, f[m]) : zerov<V>();
       }
       Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
       if (more && t < R) {
@@ -546,7 +549,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
       for (int m = 0; m < MV; m++) {
         const int e = t + m * TB;
         if (e >= LV) continue;
-        const unsigned msk = plane_inner ? kb[m] : 0u;
+        const unsigned msk = plane_inner ? ka[m] : 0u;
         if (msk == 0) {
           vc[m] = ub[m];  // outside the inner box: the first sweep leaves the value alone
         } else {
@@ -682,6 +685,25 @@ __global__ void check_k(const double* res_dev, double res_normal, double eps, in
   if (r < eps) {
     *flag = 1;
     *conv_itr = itr;
+  }
+}
+
+// the same bookkeeping for a fused pair (iterations itr, itr+1) whose two sums were all-reduced first
+__global__ void check2_k(const double* res_dev, double res_normal, double eps, int itr, double* hist, int* flag,
+                         int* conv_itr) {
+  if (*flag != 0) return;
+  double r = sqrt(res_dev[0] * res_normal);
+  hist[itr] = r;
+  if (r < eps) {
+    *flag = 1;
+    *conv_itr = itr;
+    return;
+  }
+  r = sqrt(res_dev[1] * res_normal);
+  hist[itr + 1] = r;
+  if (r < eps) {
+    *flag = 1;
+    *conv_itr = itr + 1;
   }
 }
 
@@ -987,8 +1009,8 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 
 // two fused sweeps; returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
 template <int TB, int MV>
-bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, int tj_req, const int* skip,
-                         const Fin2& fin_in) {
+bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
+                         const int* skip, const Fin2& fin_in) {
   constexpr int V = VW;
   Geom2 g;
   g.R = b.nkp / V;
@@ -997,6 +1019,9 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
   g.F0 = (long long)b.ii0 * g.R;
   g.Fend = (long long)(b.ii1 + 1) * g.R;
+  g.kk0a = ba.kk0, g.kk1a = ba.kk1, g.jj0a = ba.jj0, g.jj1a = ba.jj1;
+  g.F0a = (long long)ba.ii0 * g.R;
+  g.Fenda = (long long)(ba.ii1 + 1) * g.R;
   g.S = TB * MV - 2 * g.R;
   const long long nf = g.Fend - g.F0;
   g.nseg = (int)((nf + g.S - 1) / g.S);
@@ -1027,16 +1052,21 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   return true;
 }
 
-bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const int* skip, const Fin2& fin) {
+bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
+                    const Fin2& fin) {
   if (!vec_ok(b, {U, B, W})) return false;
+  // the stage-1 box may exceed the output box by at most one layer per side
+  if (ba.ii0 < b.ii0 - 1 || ba.ii0 > b.ii0 || ba.ii1 > b.ii1 + 1 || ba.ii1 < b.ii1 || ba.jj0 < b.jj0 - 1 || ba.jj0 > b.jj0 ||
+      ba.jj1 > b.jj1 + 1 || ba.jj1 < b.jj1 || ba.kk0 < b.kk0 - 1 || ba.kk0 > b.kk0 || ba.kk1 > b.kk1 + 1 || ba.kk1 < b.kk1)
+    return false;
   // the two-stage march reads two layers around the box
   if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
   const Tuning& tu = ctx.tune;
 #define CZ_INST2(TB_, MV_) \
-  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_>(U, B, W, c, b, tu.t2_tj, skip, fin);
+  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_>(U, B, W, c, b, ba, tu.t2_tj, skip, fin);
   CZ_INST2(256, 4) CZ_INST2(256, 6) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(512, 4) CZ_INST2(1024, 2)
 #undef CZ_INST2
-  return launch_jacobi2_inst<512, 2>(U, B, W, c, b, tu.t2_tj, skip, fin);
+  return launch_jacobi2_inst<512, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin);
 }
 
 Coef make_coef(const REAL* cf, REAL omg) {
@@ -1370,20 +1400,21 @@ void czhip_rbsor_checked_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, cons
 // iterations itr and itr+1 in order; a converged first sweep leaves the flag set with conv_itr = itr (the caller then
 // recomputes that single sweep from u, which this kernel never modifies).  Returns 1 if launched, 0 if the geometry
 // is not supported (caller falls back to two single sweeps).
-int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf,
-                        CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
-                        int* conv_itr_dev) {
+int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
+                        const CZ_REAL* cf, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev,
+                        int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev) {
   ensure_init();
   if (!ctx.tune.fuse_fin) return 0;
   const Box bx = make_box(sz, idx, g);
   if (bx.empty || g < 2) return 0;
+  const Box ba = idx1 ? make_box(sz, idx1, g) : bx;
   Fin2 fin;
   fin.dst = res_dev;
   if (hist_dev) {
     fin.do_check = 1, fin.itr = itr, fin.res_normal = res_normal, fin.eps = eps;
     fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
   }
-  return launch_jacobi2(u, b, w, make_coef(cf, omg), bx, hist_dev ? flag_dev : nullptr, fin) ? 1 : 0;
+  return launch_jacobi2(u, b, w, make_coef(cf, omg), bx, ba, hist_dev ? flag_dev : skip_flag_dev, fin) ? 1 : 0;
 }
 
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable) {
@@ -1398,6 +1429,13 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
   return 0;
 }
 int czhip_use_t2(void) { return ctx.tune.use_t2; }
+
+void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
+                        int* conv_itr_dev) {
+  ensure_init();
+  hipLaunchKernelGGL(check2_k, dim3(1), dim3(1), 0, ctx.stream, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+  HIP_CHECK(hipGetLastError());
+}
 
 void czhip_check_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                        int* conv_itr_dev) {

@@ -130,9 +130,15 @@ void czhip_rbsor_checked_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, cons
  * res_dev[0] / res_dev[1] = sum dp^2 of the first / second sweep.  hist_dev != NULL adds the convergence bookkeeping for
  * iterations itr and itr+1 (in order; flag_dev doubles as skip flag).  If the FIRST sweep converges, flag is set with
  * conv_itr = itr and w holds time n+2: the caller re-runs one single sweep from u (never modified).  Returns 1 when
- * launched, 0 when the geometry is unsupported (caller falls back to single sweeps). */
-int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf,
-                        CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
+ * launched, 0 when the geometry is unsupported (caller falls back to single sweeps).
+ * idx1 (NULL = idx): index range of the FIRST sweep; a decomposed run grows it by one layer across rank-internal faces
+ * (the second sweep reads the first one's result on the ghost layer; two ghost layers are exchanged per pair).
+ * skip_flag_dev is used when hist_dev is NULL (multi-rank runs do the bookkeeping after the all-reduce). */
+int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
+                        const CZ_REAL* cf, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev,
+                        int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev);
+/* The same bookkeeping for a pair whose two sums were all-reduced first (decomposed runs). */
+void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable); /* 0 / -1 keep; returns 0 if ok */
 int czhip_use_t2(void);
