@@ -20,6 +20,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before HIP starts
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
@@ -56,7 +57,6 @@ coef = 0.8 if args.solver == "jacobi" else 1.5
 cz = CZ(args.prec, quiet=True, device=local_rank)
 lib = cz.lib
 if world > 1:
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     nb = lib.cz_comm_unique_id_bytes()
     buf = C.create_string_buffer(nb)

@@ -514,6 +514,36 @@ int cz_comm_bootstrap_local(void* world, int rank) {
   return 0;
 }
 
+// One-rank RCCL smoke test (a one-GPU box cannot host two ranks): communicator creation from a unique id, all-reduce of
+// a device double and a grouped send/recv to self on the library stream.  Returns 0 when every result is right.
+int cz_comm_selftest(void) {
+  ncclUniqueId id;
+  NCCL_CHECK(ncclGetUniqueId(&id));
+  ncclComm_t comm;
+  NCCL_CHECK(ncclCommInitRank(&comm, 1, id, 0));
+  hipStream_t st = czhip_internal::stream();
+  double* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, 64 * sizeof(double)));
+  double h[64];
+  for (int i = 0; i < 64; i++) h[i] = 1.5 * i;
+  HIP_CHECK(hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice));
+  NCCL_CHECK(ncclAllReduce(d, d, 2, ncclDouble, ncclSum, comm, st));
+  NCCL_CHECK(ncclGroupStart());
+  NCCL_CHECK(ncclSend(d + 8, 8, ncclDouble, 0, comm, st));
+  NCCL_CHECK(ncclRecv(d + 32, 8, ncclDouble, 0, comm, st));
+  NCCL_CHECK(ncclGroupEnd());
+  HIP_CHECK(hipStreamSynchronize(st));
+  double r[64];
+  HIP_CHECK(hipMemcpy(r, d, sizeof(r), hipMemcpyDeviceToHost));
+  int bad = 0;
+  if (r[0] != 0.0 || r[1] != 1.5) bad++;
+  for (int i = 0; i < 8; i++)
+    if (r[32 + i] != 1.5 * (8 + i)) bad++;
+  (void)hipFree(d);
+  NCCL_CHECK(ncclCommDestroy(comm));
+  return bad;
+}
+
 void cz_comm_auto_division(int nproc, const int* G_size, int* G_div) { comm_auto_division(nproc, G_size, G_div); }
 int cz_comm_decompose(const int* G_size, const int* G_div, int nproc, int rank, int* size, int* head, int* nID) {
   return comm_decompose(G_size, G_div, nproc, rank, size, head, nID) ? 1 : 0;

@@ -188,6 +188,7 @@ int cz_comm_unique_id_bytes(void);
 int cz_comm_get_unique_id(char* out_bytes);
 int cz_comm_bootstrap(int rank, int nranks, const char* id_bytes);
 void cz_comm_shutdown(void);
+int cz_comm_selftest(void); /* one-rank RCCL smoke test: init, all-reduce, grouped send/recv to self; 0 = ok */
 /* Host-only decomposition helpers (no GPU needed): automatic division and the brick of one rank
  * (local size, 1-based global head index, neighbour table I-,I+,J-,J+,K-,K+ with -1 = physical boundary). */
 void cz_comm_auto_division(int nproc, const int* G_size, int* G_div);

@@ -40,8 +40,12 @@ def _decomposed(prec, gsz, solver, itmax, coef, div, pc=None):
             cz = CZ(prec, quiet=True)
             a = list(gsz) + [solver, itmax, coef] + ([pc] if pc else []) + list(div)
             assert cz.setup(a) == 1
+            cz.timing(True)
             itr = cz.solve()
-            results[r] = (itr, cz.res, cz.history(), cz.field(), cz.local())
+            loc = cz.local()
+            loc["fused_pairs"] = cz.timing_read("jacobi2")[0]
+            cz.timing(False)
+            results[r] = (itr, cz.res, cz.history(), cz.field(), loc)
             cz.close()
         except BaseException as e:  # noqa: BLE001
             errors.append((r, repr(e)))
@@ -85,6 +89,17 @@ def test_decomposed_equals_single_domain(case):
     for itr, res, hist, P, loc in results:
         assert itr == itr1
         assert np.allclose(hist, hist1, rtol=1e-12, atol=0)
+        if solver == "jacobi" and (loc["size"][2] + 4) % (4 if prec == "f32" else 2) == 0:
+            # aligned bricks take the two-sweeps-per-pass kernel with the two-layer exchange
+            assert loc["fused_pairs"] == itmax // 2, loc
+
+
+def test_rccl_one_rank_selftest():
+    """RCCL plumbing on the one GPU we have: communicator from a unique id, all-reduce, grouped send/recv to self."""
+    import torch  # noqa: F401  (same process set-up as bench.py: torch's bundled librccl is loaded first)
+    from cubez_amd import CzHip
+    h = CzHip("f32")
+    assert h.lib.cz_comm_selftest() == 0
 
 
 def test_decomposed_converges_at_the_same_iteration():
