@@ -91,7 +91,7 @@ cz.sweeps(args.steps)
 barrier()
 dt = time.perf_counter() - t0
 nk, kern_ms = cz.timing_read("jacobi" if args.solver == "jacobi" else "rbsor")
-nk2, kern2_ms = cz.timing_read("jacobi2")  # two fused sweeps per launch (single-domain Jacobi)
+nk2, kern2_ms = cz.timing_read("jacobi2" if args.solver == "jacobi" else "rbsor2")  # fused: 2 sweeps / both colours per launch
 cz.timing(False)
 
 tot_points = float(my_points)
@@ -110,9 +110,12 @@ if rank == 0:
     alg_bytes_per_launch = my_points * word * (3 if args.solver == "jacobi" else 2)
     kernel_name = "stencil_k<jacobi>" if args.solver == "jacobi" else "stencil_k<rbsor colour>"
     tkey = f"{args.solver}_{n}_{args.prec}"
-    if nk2 > nk:  # the dominant kernel is the fused pair: 2 sweeps = 2 x 3 words per point and launch
+    if nk2 > nk:  # the dominant kernel is the fused one: 2 Jacobi sweeps (2 x 3 words) or both RB colours (2 x 2 words)
         nk, kern_ms, alg_bytes_per_launch = nk2, kern2_ms, 2 * alg_bytes_per_launch
-        kernel_name, tkey = "jacobi2_k (two fused sweeps per launch)", f"jacobi2_{n}_{args.prec}"
+        if args.solver == "jacobi":
+            kernel_name, tkey = "jacobi2_k<RB=0> (two fused sweeps per launch)", f"jacobi2_{n}_{args.prec}"
+        else:
+            kernel_name, tkey = "jacobi2_k<RB=1> (both colours of one iteration per launch)", f"rbsor2_{n}_{args.prec}"
     kern_avg_s = (kern_ms / nk) * 1e-3 if nk else float("nan")
     achieved = alg_bytes_per_launch / kern_avg_s / 1e9 if nk else None
     traffic = None

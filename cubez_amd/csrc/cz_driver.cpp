@@ -498,45 +498,93 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   // (cz_solver.f90:466), which is 1 instead of 2 on a face that borders another rank.
   int ip = 0;
   if (numProc > 1) ip = (head[0] + head[1] + head[2] + 1 + innerFidx[K_minus]) % 2;
+
+  // Preferred form: the whole iteration (colour 0, then colour 1) in ONE pass over memory, out of place X <-> WRK
+  // (czhip_rbsor2_async); decomposed runs then exchange two ghost layers once per iteration.  Fallback: the reference's
+  // two in-place colour launches with an exchange after each colour.
+  bool fused = czhip_use_t2() != 0;
+  int idx1[6];
+  for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
+  REAL_TYPE* buf[2] = {X, WRK};
+  int cur = 0, n_fused = 0;
+  if (fused) {
+    if (numProc > 1 && (!Comm_S2(X) || !Comm_S2(B))) return 0;
+    copy_shell_async(WRK, X, size, innerFidx, gc);
+  }
   hipEvent_t ev[POLL_SLOTS];
   int npoll = 0;
   bool stop = false;
   int itr;
   for (itr = 1; itr <= itr_max && !stop; itr++) {
-    const bool fused_check = converge_check && numProc == 1;
-    for (int color = 0; color < 2; color++) {  // :205-209
-      if (fused_check && color == 1)
-        czhip_rbsor_checked_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, 1, res_normal, eps, itr, d_hist,
-                                  d_flag, d_flag + 1);
-      else
-        czhip_rbsor_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, color, skip);
-      flop += 9.0 * npts();
-      // the reference exchanges once per iteration (:215); exchanging after each colour makes the decomposed run
-      // identical to the single-domain one
-      if (!Comm_S(X, skip)) return 0;
+    const bool in_kernel_check = converge_check && numProc == 1;
+    bool done = false;
+    if (fused) {
+      REAL_TYPE* src = buf[cur];
+      REAL_TYPE* dst = buf[cur ^ 1];
+      if (czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
+                             in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip)) {  // :205-209 (+ :218-230)
+        flop += 18.0 * npts();
+        if (numProc > 1) {
+          if (!Comm_S2(dst, skip)) return 0;  // :215
+          if (converge_check) {
+            if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
+            czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+          }
+        }
+        cur ^= 1;
+        n_fused++;
+        done = true;
+      } else {
+        fused = false;  // geometry not supported: nothing was launched, X is still the current iterate
+      }
     }
-    if (converge_check) {
-      if (!fused_check) {
+    if (!done) {
+      for (int color = 0; color < 2; color++) {  // :205-209
+        if (in_kernel_check && color == 1)
+          czhip_rbsor_checked_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, 1, res_normal, eps, itr, d_hist,
+                                    d_flag, d_flag + 1);
+        else
+          czhip_rbsor_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, color, skip);
+        flop += 9.0 * npts();
+        // the reference exchanges once per iteration (:215); exchanging after each colour makes the decomposed run
+        // identical to the single-domain one
+        if (!Comm_S(X, skip)) return 0;
+      }
+      if (converge_check && !in_kernel_check) {
         if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
         czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
-      if (itr % POLL_EVERY == 0 && itr < itr_max) {
-        const int slot = npoll % POLL_SLOTS;
-        if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
-        HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(ev[slot], st));
-        npoll++;
-        if (npoll >= 3) {
-          const int old = (npoll - 3) % POLL_SLOTS;
-          HIP_CHECK(hipEventSynchronize(ev[old]));
-          if (h_flag[2 * old] != 0) stop = true;
-        }
+    }
+    if (converge_check && itr % POLL_EVERY == 0 && itr < itr_max) {
+      const int slot = npoll % POLL_SLOTS;
+      if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
+      HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(ev[slot], st));
+      npoll++;
+      if (npoll >= 3) {
+        const int old = (npoll - 3) % POLL_SLOTS;
+        HIP_CHECK(hipEventSynchronize(ev[old]));
+        if (h_flag[2 * old] != 0) stop = true;
       }
     }
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
-  return finish_stationary(itr_max, 1, converge_check, res);
+  const int ret = finish_stationary(itr_max, 1, converge_check, res);
+  if (n_fused > 0) {
+    // out-of-place iterations executed = all of them up to convergence (later launches were no-ops)
+    const int n_exec = converge_check ? (ret > itr_max ? itr_max : ret) : itr_max;
+    if (n_exec & 1) {
+      if (X == P) {
+        REAL_TYPE* t = P;
+        P = WRK;
+        WRK = t;
+      } else {
+        copy_inner_async(X, WRK, size, innerFidx, gc);
+      }
+    }
+  }
+  return ret;
 }
 
 // cz_Poisson.cpp:239-270.  The reference reduces in REAL on every rank and all-reduces the REAL; here the double

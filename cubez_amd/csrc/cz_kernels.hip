@@ -416,17 +416,27 @@ struct Geom2 {
   int kk0a, kk1a, jj0a, jj1a;
   long long F0a, Fenda;
   int nseg, TJ, S;  // S = TB*MV - 2R
+  int par;          // RB: colour 0 = points with (kk + ii + jj + par) even
 };
 
 struct Fin2 {
   double* dst = nullptr;   // [0] <- sum of sweep n+1, [1] <- sum of sweep n+2
   int do_check = 0, itr = 0;  // itr = iteration number of sweep n+1
+  int single = 0;             // RB: both stages belong to ONE iteration: dst[0] = sum1 + sum2, one bookkeeping step
   double res_normal = 0.0, eps = 0.0;
   double* hist = nullptr;
   int* flag = nullptr;
   int* conv_itr = nullptr;
   unsigned* counter = nullptr;
 };
+
+// bit cc set when (base + cc) is even
+template <int V>
+__device__ __forceinline__ unsigned colour_bits(int base) {
+  const unsigned even = (V == 4) ? 0x5u : (V == 2) ? 0x1u : 0x1u;   // components 0,2 / 0 / 0
+  const unsigned odd = (V == 4) ? 0xAu : (V == 2) ? 0x2u : 0x0u;    // components 1,3 / 1 / -
+  return (base & 1) ? odd : even;
+}
 
 template <int V>
 __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
@@ -447,8 +457,11 @@ __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, 
   return o;
 }
 
-template <int V, int TB, int MV>
-__global__ void __launch_bounds__(TB)
+// RB = 0: two Jacobi sweeps.  RB = 1: one red-black SOR iteration (cz_solver.f90:466-480 for colour 0 then colour 1):
+// stage 1 updates the points of colour 0, stage 2 those of colour 1 from the freshly updated colour-0 neighbours; the
+// other colour passes through each stage unchanged.  Out of place (U -> W) like the Jacobi pair.
+template <int V, int TB, int MV, int RB>
+__global__ void __launch_bounds__(TB, (TB == 512 && MV <= 2) ? 4 : 1)
 jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
           const int* __restrict__ skip, Fin2 fin) {
   if (skip != nullptr && *skip != 0) return;
@@ -478,6 +491,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
     long long f[MV];
     unsigned ka[MV];     // stage-1 bits: components of the vector inside the stage-1 box (0 when the row is outside)
     unsigned own[MV];    // stage-2 bits if this workgroup owns the vector (stores, residual counts), else 0
+    int pbase[MV];       // RB: (kk + ii + par) of component 0; component cc on plane jj has colour (pbase + cc + jj) & 1
     bool ld[MV];
 #pragma unroll
     for (int m = 0; m < MV; m++) {
@@ -493,6 +507,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
         if (kk >= g.kk0a && kk <= g.kk1a) bits1 |= 1u << cc;
         if (kk >= g.kk0 && kk <= g.kk1) bits2 |= 1u << cc;
       }
+      pbase[m] = kv * V + (int)row + g.par;
       ka[m] = (e < LV && f[m] >= g.F0a && f[m] < g.Fenda) ? bits1 : 0u;
       own[m] = (e >= R && e < R + g.S && f[m] >= g.F0 && f[m] < g.Fend) ? bits2 : 0u;
     }
@@ -549,7 +564,8 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
       for (int m = 0; m < MV; m++) {
         const int e = t + m * TB;
         if (e >= LV) continue;
-        const unsigned msk = plane_inner ? ka[m] : 0u;
+        unsigned msk = plane_inner ? ka[m] : 0u;
+        if (RB) msk &= colour_bits<V>(pbase[m] + q);  // colour 0 on plane q
         if (msk == 0) {
           vc[m] = ub[m];  // outside the inner box: the first sweep leaves the value alone
         } else {
@@ -558,7 +574,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
           const Vec<V> ip = bufU[x + R];
           const REAL kl = bufUf[x * V - 1];
           const REAL kr = bufUf[x * V + V];
-          vc[m] = relax_vec<V>(ub[m], im, ip, ua[m], uc[m], kl, kr, b1[m], c, msk, count1 ? own[m] : 0u, acc1);
+          vc[m] = relax_vec<V>(ub[m], im, ip, ua[m], uc[m], kl, kr, b1[m], c, msk, count1 ? (own[m] & msk) : 0u, acc1);
         }
       }
       // ---- publish v(q) for the next step's stage 2
@@ -581,7 +597,9 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
           const Vec<V> ip = bufV[e + R];
           const REAL kl = bufVf[e * V - 1];
           const REAL kr = bufVf[e * V + V];
-          const Vec<V> o = relax_vec<V>(vb[m], im, ip, va[m], vc[m], kl, kr, b2[m], c, own[m], own[m], acc2);
+          unsigned m2 = own[m];
+          if (RB) m2 &= colour_bits<V>(pbase[m] + (q - 1) + 1);  // colour 1 on plane q-1
+          const Vec<V> o = relax_vec<V>(vb[m], im, ip, va[m], vc[m], kl, kr, b2[m], c, m2, m2, acc2);
           if (own[m] == (1u << V) - 1) {
             stv<V>(Wq, f[m], o);
           } else {
@@ -639,7 +657,19 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
     const double t1 = block_sum<TB>(x1, wsum);
     __syncthreads();
     const double t2 = block_sum<TB>(x2, wsum);
-    if (t == 0) {
+    if (t == 0 && fin.single) {
+      const double tot = t1 + t2;  // colour 0 + colour 1 (cz_Poisson.cpp:205-209 accumulate into one res)
+      fin.dst[0] = tot;
+      if (fin.do_check) {
+        const double r = sqrt(tot * fin.res_normal);
+        fin.hist[fin.itr] = r;
+        if (r < fin.eps) {
+          *fin.flag = 1;
+          *fin.conv_itr = fin.itr;
+        }
+      }
+      *fin.counter = 0u;
+    } else if (t == 0) {
       fin.dst[0] = t1;
       fin.dst[1] = t2;
       if (fin.do_check) {  // cz_Poisson.cpp:69-77 for iteration itr, then itr+1
@@ -845,8 +875,8 @@ struct Ctx {
 };
 thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
 
-enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_COUNT };
-const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2"};
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_COUNT };
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2"};
 
 struct ScopedTimer {
   bool on;
@@ -1008,9 +1038,9 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 
 
 // two fused sweeps; returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
-template <int TB, int MV>
+template <int TB, int MV, int RB>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
-                         const int* skip, const Fin2& fin_in) {
+                         const int* skip, const Fin2& fin_in, int par) {
   constexpr int V = VW;
   Geom2 g;
   g.R = b.nkp / V;
@@ -1023,6 +1053,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   g.F0a = (long long)ba.ii0 * g.R;
   g.Fenda = (long long)(ba.ii1 + 1) * g.R;
   g.S = TB * MV - 2 * g.R;
+  g.par = par;
   const long long nf = g.Fend - g.F0;
   g.nseg = (int)((nf + g.S - 1) / g.S);
   const int nplanes = b.jj1 - b.jj0 + 1;
@@ -1038,22 +1069,23 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2_k<V, TB, MV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2_k<V, TB, MV, RB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
   Fin2 fin = fin_in;
   fin.counter = ctx.counter;
   {
-    ScopedTimer tm(LBL_JACOBI2);
-    hipLaunchKernelGGL((jacobi2_k<V, TB, MV>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
+    ScopedTimer tm(RB ? LBL_RBSOR2 : LBL_JACOBI2);
+    hipLaunchKernelGGL((jacobi2_k<V, TB, MV, RB>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
   }
   HIP_CHECK(hipGetLastError());
   return true;
 }
 
+template <int RB>
 bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
-                    const Fin2& fin) {
+                    const Fin2& fin, int par = 0) {
   if (!vec_ok(b, {U, B, W})) return false;
   // the stage-1 box may exceed the output box by at most one layer per side
   if (ba.ii0 < b.ii0 - 1 || ba.ii0 > b.ii0 || ba.ii1 > b.ii1 + 1 || ba.ii1 < b.ii1 || ba.jj0 < b.jj0 - 1 || ba.jj0 > b.jj0 ||
@@ -1063,10 +1095,10 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
   const Tuning& tu = ctx.tune;
 #define CZ_INST2(TB_, MV_) \
-  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_>(U, B, W, c, b, ba, tu.t2_tj, skip, fin);
-  CZ_INST2(256, 4) CZ_INST2(256, 6) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(512, 4) CZ_INST2(1024, 2)
+  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par);
+  CZ_INST2(256, 4) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(1024, 2)
 #undef CZ_INST2
-  return launch_jacobi2_inst<512, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin);
+  return launch_jacobi2_inst<512, 2, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par);
 }
 
 Coef make_coef(const REAL* cf, REAL omg) {
@@ -1414,7 +1446,27 @@ int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const in
     fin.do_check = 1, fin.itr = itr, fin.res_normal = res_normal, fin.eps = eps;
     fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
   }
-  return launch_jacobi2(u, b, w, make_coef(cf, omg), bx, ba, hist_dev ? flag_dev : skip_flag_dev, fin) ? 1 : 0;
+  return launch_jacobi2<0>(u, b, w, make_coef(cf, omg), bx, ba, hist_dev ? flag_dev : skip_flag_dev, fin) ? 1 : 0;
+}
+
+// One complete red-black SOR iteration (colour 0 then colour 1, cz_Poisson.cpp:205-209) in one pass over memory, u -> w.
+// res_dev[0] receives the iteration's sum dp^2 (both colours).  Same conventions as czhip_jacobi2_async.
+int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
+                       const CZ_REAL* cf, int ofst, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr,
+                       double* hist_dev, int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev) {
+  ensure_init();
+  if (!ctx.tune.fuse_fin) return 0;
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty || g < 2) return 0;
+  const Box ba = idx1 ? make_box(sz, idx1, g) : bx;
+  Fin2 fin;
+  fin.dst = res_dev;
+  fin.single = 1;
+  if (hist_dev) {
+    fin.do_check = 1, fin.itr = itr, fin.res_normal = res_normal, fin.eps = eps;
+    fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
+  }
+  return launch_jacobi2<1>(u, b, w, make_coef(cf, omg), bx, ba, hist_dev ? flag_dev : skip_flag_dev, fin, rb_parity(g, idx, ofst, 0)) ? 1 : 0;
 }
 
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable) {
@@ -1424,10 +1476,11 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
   if (planes_per_chunk >= 0) t.t2_tj = planes_per_chunk;
   if (enable >= 0) t.use_t2 = enable;
   const int k = t.t2_threads * 100 + t.t2_mv;
-  if (k != 25604 && k != 25606 && k != 51202 && k != 51203 && k != 51204 && k != 102402) return 1;
+  if (k != 25604 && k != 51202 && k != 51203 && k != 102402) return 1;
   ctx.tune = t;
   return 0;
 }
+
 int czhip_use_t2(void) { return ctx.tune.use_t2; }
 
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,

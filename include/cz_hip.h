@@ -137,6 +137,12 @@ void czhip_rbsor_checked_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, cons
 int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
                         const CZ_REAL* cf, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev,
                         int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev);
+/* One complete red-black SOR iteration (colour 0 then colour 1, cz_Poisson.cpp:205-209) in ONE pass over memory,
+ * u -> w out of place (the caller ping-pongs like Jacobi): bit-identical to psor2sma_core_ colour 0 + colour 1.
+ * res_dev[0] = the iteration's sum dp^2 over both colours; check arguments as above (one iteration). */
+int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
+                       const CZ_REAL* cf, int ofst, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr,
+                       double* hist_dev, int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev);
 /* The same bookkeeping for a pair whose two sums were all-reduced first (decomposed runs). */
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);

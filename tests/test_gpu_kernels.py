@@ -237,7 +237,7 @@ def test_residual_is_run_to_run_deterministic():
 
 T2_BOXES = [((40, 36, 60), None), ((33, 70, 124), None), ((130, 20, 252), None), ((70, 45, 124), None),
             ((24, 20, 28), (1, 24, 1, 20, 1, 28)), ((64, 9, 60), None), ((96, 40, 508), None)]
-T2_TUNINGS = [(512, 3, 32), (512, 3, 5), (512, 2, 7), (512, 4, 16), (256, 4, 3), (256, 6, 16), (1024, 2, 11)]
+T2_TUNINGS = [(512, 3, 32), (512, 3, 5), (512, 2, 7), (512, 2, 16), (256, 4, 3), (256, 4, 16), (1024, 2, 11), (1024, 2, 4)]
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
@@ -272,6 +272,42 @@ def test_two_fused_sweeps_equal_two_oracle_sweeps(prec, box):
                 assert _beq(du.get(), p)  # the input is never modified
                 assert _rel(r1, r[0]) < RTOL_WIDE * 10 and _rel(r2, r[1]) < RTOL_WIDE * 10, (tb, mv, tj)
             dw.free()
+    finally:
+        h.set_tuning2(512, 2, 16, 1)
+    if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:
+        assert launched > 0
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", T2_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in T2_BOXES])
+def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
+    """czhip_rbsor2_async (both colours in one pass, out of place) == psor2sma_core colour 0 + colour 1 of the oracle."""
+    (ni, nj, nk), idx = box
+    sz = [ni, nj, nk]
+    idx = list(idx) if idx else [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(3 * ni + 5 * nj + 11 * nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    cf = rng.uniform(0.5, 1.5, 7).astype(R)
+    cf[6] = 6.2
+    p, b = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    du, db = h.alloc(sz, p), h.alloc(sz, b)
+    launched = 0
+    try:
+        for ofst in (0, 1):
+            a1, wide = p.copy(), np.zeros(1)
+            for color in (0, 1):
+                ko.psor2sma_core(a1, sz, idx, cf, ofst, color, 1.3, b, wide=wide)
+            for (tb, mv, tj) in T2_TUNINGS[::2]:
+                assert h.set_tuning2(tb, mv, tj, 1)
+                dw = h.alloc(sz, p)
+                ok, r = h.rbsor2(du, dw, db, sz, idx, cf, ofst, 1.3)
+                if ok:
+                    launched += 1
+                    assert _beq(dw.get(), a1), (ofst, tb, mv, tj)
+                    assert _rel(r, wide[0]) < RTOL_WIDE * 10
+                dw.free()
     finally:
         h.set_tuning2(512, 2, 16, 1)
     if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:

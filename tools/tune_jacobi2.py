@@ -10,7 +10,7 @@ assert cz.setup([N, N, N, "jacobi", 1000, 0.8]) == 1
 lib = cz.lib
 lups = float(N - 2) ** 3
 rows = []
-cfgs = [(0, 0, 0, 0)] + [(tb, mv, tj, 1) for (tb, mv) in ((512, 3), (512, 2), (512, 4), (1024, 2), (256, 4), (256, 6)) for tj in (8, 16, 22, 32, 43, 64)]
+cfgs = [(0, 0, 0, 0)] + [(tb, mv, tj, 1) for (tb, mv) in ((512, 2), (1024, 2), (512, 3), (256, 4)) for tj in (8, 16, 32, 64)]
 for rnd in range(2):
     for (tb, mv, tj, en) in cfgs:
         if lib.czhip_set_tuning2(tb, mv, tj, en) != 0:
