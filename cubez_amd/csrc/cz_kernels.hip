@@ -852,7 +852,11 @@ copy_shell_k(REAL* __restrict__ dst, const REAL* __restrict__ src, int nkp, int 
 struct Tuning {
   int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
   int fuse_fin = 1;
-  int t2_threads = 512, t2_mv = 2, t2_tj = 16;  // two-sweep kernel: threads, vectors/thread, planes/chunk
+  #ifdef CZ_REAL_IS_DOUBLE
+  int t2_threads = 1024, t2_mv = 2, t2_tj = 64;  // best of tools/tune_jacobi2.py at 512^3 FP64 (profiles/r01)
+#else
+  int t2_threads = 512, t2_mv = 2, t2_tj = 16;   // best at 512^3 FP32
+#endif  // two-sweep kernel: threads, vectors/thread, planes/chunk
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
 

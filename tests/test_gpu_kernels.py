@@ -273,7 +273,7 @@ def test_two_fused_sweeps_equal_two_oracle_sweeps(prec, box):
                 assert _rel(r1, r[0]) < RTOL_WIDE * 10 and _rel(r2, r[1]) < RTOL_WIDE * 10, (tb, mv, tj)
             dw.free()
     finally:
-        h.set_tuning2(512, 2, 16, 1)
+        h.set_tuning2(*((512, 2, 16) if prec == "f32" else (1024, 2, 64)), 1)
     if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:
         assert launched > 0
 
@@ -309,6 +309,6 @@ def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
                     assert _rel(r, wide[0]) < RTOL_WIDE * 10
                 dw.free()
     finally:
-        h.set_tuning2(512, 2, 16, 1)
+        h.set_tuning2(*((512, 2, 16) if prec == "f32" else (1024, 2, 64)), 1)
     if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:
         assert launched > 0
