@@ -1,8 +1,13 @@
-// cz_comm.cpp -- see cz_comm.h.  Face geometry (K-fastest layout, cz_solver.f90:29):
-//   J faces  are contiguous: rows i=1..NI of plane j  -> sent/received in place, no pack kernel
-//   I faces  are NJ runs of NK elements (one k-row per j)        -> packed [j][k]
-//   K faces  are fully strided (one element per (i,j))            -> packed [j][i]
-// Only owned cells travel (no edges/corners): the 7-point stencil never reads them.
+// cz_comm.cpp -- see cz_comm.h.
+//
+// One exchange = ONE pack launch, ONE grouped ncclSend/ncclRecv over all neighbours, ONE unpack launch.
+// A message is the box of owned cells next to a face or an edge of the brick; the receiver stores it in the mirror-image
+// ghost box.  Two shapes of exchange:
+//   depth 1, faces only          Comm_S(X, 1) of the reference (cz_comm.cpp:23-38): what one sweep reads
+//   depth 2, faces + 12 edges    what a fused pair of sweeps reads: the first sweep is also applied to ghost layer 1, which
+//                                needs ghost layer 2 behind it and the edge cells (ghost in two directions) beside it;
+//                                edges travel directly to the diagonal neighbours, so the exchange stays single-phase
+// Corners are never read by a 7-point stencil at this depth.
 #include "cz_comm.h"
 
 #include <rccl/rccl.h>
@@ -61,96 +66,61 @@ struct Boot {
 };
 thread_local Boot boot;
 
-template <typename T>
-__global__ void pack_iface_k(T* __restrict__ buf, const T* __restrict__ X, int NK, int NJ, int nkp, int nip, int ii, int g,
-                             const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;  // 0..NK-1
-  const int j = blockIdx.y;                             // 0..NJ-1
-  if (k >= NK) return;
-  buf[(size_t)j * NK + k] = X[(size_t)(k + g) + (size_t)ii * nkp + (size_t)(j + g) * nkp * nip];
-}
-template <typename T>
-__global__ void unpack_iface_k(T* __restrict__ X, const T* __restrict__ buf, int NK, int NJ, int nkp, int nip, int ii, int g,
-                               const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (k >= NK) return;
-  X[(size_t)(k + g) + (size_t)ii * nkp + (size_t)(j + g) * nkp * nip] = buf[(size_t)j * NK + k];
-}
-template <typename T>
-__global__ void pack_kface_k(T* __restrict__ buf, const T* __restrict__ X, int NI, int NJ, int nkp, int nip, int kk, int g,
-                             const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (i >= NI) return;
-  buf[(size_t)j * NI + i] = X[(size_t)kk + (size_t)(i + g) * nkp + (size_t)(j + g) * nkp * nip];
-}
-template <typename T>
-__global__ void unpack_kface_k(T* __restrict__ X, const T* __restrict__ buf, int NI, int NJ, int nkp, int nip, int kk, int g,
-                               const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;
-  if (i >= NI) return;
-  X[(size_t)kk + (size_t)(i + g) * nkp + (size_t)(j + g) * nkp * nip] = buf[(size_t)j * NI + i];
-}
 
-// ---- depth-2 exchange (two ghost layers, edges included) for the two-sweep kernel --------------------------------
-template <typename T>
-__global__ void pack_i2_k(T* __restrict__ buf, const T* __restrict__ X, int NK, int NJ, int nkp, int nip, int ii0, int g,
-                          const int* __restrict__ skip) {
+constexpr int MAX_BOX = 18;  // 6 faces + 12 edges
+
+struct BoxDesc {
+  int i0, j0, k0;   // padded 0-based start
+  int ni, nj, nk;   // extent
+  long long off;    // element offset in the packed buffer
+};
+struct BoxTable {
+  int n;
+  BoxDesc b[MAX_BOX];
+};
+
+// gather the boxes of X into the packed buffer (dir = 0) or scatter the packed buffer into the boxes (dir = 1)
+template <typename T, int DIR>
+__global__ void __launch_bounds__(256)
+box_copy_k(T* __restrict__ buf, T* __restrict__ X, BoxTable tab, int nkp, int nip, const int* __restrict__ skip) {
   if (skip && *skip) return;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, l = blockIdx.z;
-  if (k >= NK) return;
-  buf[((size_t)l * NJ + j) * NK + k] = X[(size_t)(k + g) + (size_t)(ii0 + l) * nkp + (size_t)(j + g) * nkp * nip];
-}
-template <typename T>
-__global__ void unpack_i2_k(T* __restrict__ X, const T* __restrict__ buf, int NK, int NJ, int nkp, int nip, int ii0, int g,
-                            const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y, l = blockIdx.z;
-  if (k >= NK) return;
-  X[(size_t)(k + g) + (size_t)(ii0 + l) * nkp + (size_t)(j + g) * nkp * nip] = buf[((size_t)l * NJ + j) * NK + k];
-}
-// K layers over the WHOLE padded (i,j) extent: carries the i/j ghost values received in the earlier phases (edges)
-template <typename T>
-__global__ void pack_k2_k(T* __restrict__ buf, const T* __restrict__ X, int nkp, int nip, int njp, int kk0,
-                          const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  const int ii = blockIdx.x * blockDim.x + threadIdx.x, jj = blockIdx.y, l = blockIdx.z;
-  if (ii >= nip) return;
-  buf[((size_t)l * njp + jj) * nip + ii] = X[(size_t)(kk0 + l) + (size_t)ii * nkp + (size_t)jj * nkp * nip];
-}
-template <typename T>
-__global__ void unpack_k2_k(T* __restrict__ X, const T* __restrict__ buf, int nkp, int nip, int njp, int kk0,
-                            const int* __restrict__ skip) {
-  if (skip && *skip) return;
-  const int ii = blockIdx.x * blockDim.x + threadIdx.x, jj = blockIdx.y, l = blockIdx.z;
-  if (ii >= nip) return;
-  X[(size_t)(kk0 + l) + (size_t)ii * nkp + (size_t)jj * nkp * nip] = buf[((size_t)l * njp + jj) * nip + ii];
+  const BoxDesc d = tab.b[blockIdx.y];
+  const long long n = (long long)d.ni * d.nj * d.nk;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int k = (int)(e % d.nk);
+    const long long r = e / d.nk;
+    const int i = (int)(r % d.ni), j = (int)(r / d.ni);
+    const size_t lin = (size_t)(d.k0 + k) + (size_t)(d.i0 + i) * nkp + (size_t)(d.j0 + j) * nkp * nip;
+    if (DIR == 0) buf[d.off + e] = X[lin];
+    else X[lin] = buf[d.off + e];
+  }
 }
 
 }  // namespace
+
+// one exchange pattern (depth + edges) of one brick
+struct Pattern {
+  int nmsg = 0;
+  int peer[MAX_BOX];
+  int dir[MAX_BOX][3];
+  size_t count[MAX_BOX], off[MAX_BOX];
+  BoxTable send, recv;
+  size_t total = 0;
+  void* sendbuf = nullptr;
+  void* recvbuf = nullptr;
+};
 
 struct CommCtx {
   Transport tr;
   int rank, nproc, eb;
   int size[3], nID[6];
+  int coord[3], div[3];
   int g = 2;
-  size_t face_elems[6];
-  void* sendbuf[6] = {nullptr};
-  void* recvbuf[6] = {nullptr};
   ncclComm_t nccl = nullptr;
   LocalWorld* world = nullptr;
-  void* cur_X = nullptr;  // LOCAL: array being exchanged, published for the neighbours' J-face copies
   double* h_red = nullptr;
-  // depth-2 exchange buffers (allocated on first use): [face] for I-,I+,K-,K+ (J faces travel in place)
-  void* send2[6] = {nullptr};
-  void* recv2[6] = {nullptr};
-  size_t elems2[6] = {0};
+  Pattern shallow, deep;   // depth 1 faces / depth 2 faces + edges
+  const Pattern* cur = nullptr;  // LOCAL: pattern being exchanged (published for the neighbours)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -203,7 +173,102 @@ bool comm_decompose(const int G[3], const int D[3], int nproc, int rank, int siz
   return true;
 }
 
-CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], int elem_bytes) {
+
+namespace {
+void build_pattern(CommCtx* c, Pattern& p, int depth, bool edges) {
+  const int N[3] = {c->size[0], c->size[1], c->size[2]};
+  const int g = c->g;
+  p.nmsg = 0;
+  p.total = 0;
+  for (int dk = -1; dk <= 1; dk++)
+    for (int dj = -1; dj <= 1; dj++)
+      for (int di = -1; di <= 1; di++) {
+        const int d[3] = {di, dj, dk};
+        const int nz = (di != 0) + (dj != 0) + (dk != 0);
+        if (nz == 0 || nz == 3 || (nz == 2 && !edges)) continue;
+        int rc[3];
+        bool exists = true;
+        for (int a = 0; a < 3; a++) {
+          rc[a] = c->coord[a] + d[a];
+          if (rc[a] < 0 || rc[a] >= c->div[a]) exists = false;
+        }
+        if (!exists) continue;
+        const int dep = (nz == 1) ? depth : 1;  // faces carry `depth` layers, edges one cell in each cut direction
+        BoxDesc sb, rb;
+        int s0[3], r0[3], ext[3];
+        for (int a = 0; a < 3; a++) {
+          if (d[a] == 0) {
+            s0[a] = r0[a] = 1, ext[a] = N[a];
+          } else if (d[a] < 0) {
+            s0[a] = 1, r0[a] = 1 - dep, ext[a] = dep;
+          } else {
+            s0[a] = N[a] - dep + 1, r0[a] = N[a] + 1, ext[a] = dep;
+          }
+        }
+        // 1-based (i,j,k) -> padded 0-based
+        sb.i0 = s0[0] + g - 1, sb.j0 = s0[1] + g - 1, sb.k0 = s0[2] + g - 1;
+        rb.i0 = r0[0] + g - 1, rb.j0 = r0[1] + g - 1, rb.k0 = r0[2] + g - 1;
+        sb.ni = rb.ni = ext[0], sb.nj = rb.nj = ext[1], sb.nk = rb.nk = ext[2];
+        sb.off = rb.off = (long long)p.total;
+        const int m = p.nmsg++;
+        p.send.b[m] = sb, p.recv.b[m] = rb;
+        p.peer[m] = rc[0] + c->div[0] * (rc[1] + c->div[1] * rc[2]);
+        p.dir[m][0] = di, p.dir[m][1] = dj, p.dir[m][2] = dk;
+        p.count[m] = (size_t)ext[0] * ext[1] * ext[2];
+        p.off[m] = p.total;
+        p.total += p.count[m];
+      }
+  p.send.n = p.recv.n = p.nmsg;
+  if (p.total) {
+    HIP_CHECK(hipMalloc(&p.sendbuf, p.total * c->eb));
+    HIP_CHECK(hipMalloc(&p.recvbuf, p.total * c->eb));
+  }
+}
+
+template <typename T>
+bool exchange(CommCtx* c, const Pattern& p, T* X, const int* skip, hipStream_t st) {
+  if (p.nmsg == 0) return true;
+  const int nkp = c->size[2] + 2 * c->g, nip = c->size[0] + 2 * c->g;
+  size_t biggest = 0;
+  for (int m = 0; m < p.nmsg; m++) biggest = std::max(biggest, p.count[m]);
+  const dim3 grid((unsigned)std::min<size_t>((biggest + 255) / 256, 2048), (unsigned)p.nmsg);
+  hipLaunchKernelGGL((box_copy_k<T, 0>), grid, dim3(256), 0, st, (T*)p.sendbuf, X, p.send, nkp, nip, skip);
+  HIP_CHECK(hipGetLastError());
+  if (c->tr == T_RCCL) {
+    const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
+    NCCL_CHECK(ncclGroupStart());
+    for (int m = 0; m < p.nmsg; m++) {
+      NCCL_CHECK(ncclSend((const T*)p.sendbuf + p.off[m], p.count[m], dt, p.peer[m], c->nccl, st));
+      NCCL_CHECK(ncclRecv((T*)p.recvbuf + p.off[m], p.count[m], dt, p.peer[m], c->nccl, st));
+    }
+    NCCL_CHECK(ncclGroupEnd());
+  } else {  // LOCAL: every rank has packed; copy what each neighbour packed for me (its message in direction -d)
+    c->cur = &p;
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->world->barrier();
+    for (int m = 0; m < p.nmsg; m++) {
+      const CommCtx* nb = c->world->ranks[p.peer[m]];
+      const Pattern* q = nb->cur;
+      int mm = -1;
+      for (int x = 0; x < q->nmsg; x++)
+        if (q->dir[x][0] == -p.dir[m][0] && q->dir[x][1] == -p.dir[m][1] && q->dir[x][2] == -p.dir[m][2]) mm = x;
+      if (mm < 0 || q->count[mm] != p.count[m] || q->peer[mm] != c->rank) {
+        fprintf(stderr, "czhip: LOCAL transport: rank %d has no matching message from rank %d\n", c->rank, p.peer[m]);
+        exit(1);
+      }
+      HIP_CHECK(hipMemcpyAsync((T*)p.recvbuf + p.off[m], (const T*)q->sendbuf + q->off[mm], p.count[m] * sizeof(T),
+                               hipMemcpyDeviceToDevice, st));
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+    c->world->barrier();  // nobody repacks before everyone has copied
+  }
+  hipLaunchKernelGGL((box_copy_k<T, 1>), grid, dim3(256), 0, st, (T*)p.recvbuf, X, p.recv, nkp, nip, skip);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+}  // namespace
+
+CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], int elem_bytes, const int div[3]) {
   if (boot.tr == T_NONE || boot.nproc != nproc) {
     fprintf(stderr, "czhip: %d ranks requested but no communicator was bootstrapped (cz_comm_bootstrap*)\n", nproc);
     return nullptr;
@@ -211,17 +276,11 @@ CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], i
   CommCtx* c = new CommCtx();
   c->tr = boot.tr, c->rank = rank, c->nproc = nproc, c->eb = elem_bytes;
   c->nccl = boot.nccl, c->world = boot.world;
-  for (int a = 0; a < 3; a++) c->size[a] = size[a];
+  for (int a = 0; a < 3; a++) c->size[a] = size[a], c->div[a] = div[a];
   for (int f = 0; f < 6; f++) c->nID[f] = nID[f];
-  const size_t NI = size[0], NJ = size[1], NK = size[2];
-  c->face_elems[0] = c->face_elems[1] = NJ * NK;
-  c->face_elems[2] = c->face_elems[3] = NI * (NK + 2 * c->g);  // in-place rows incl. k guide cells
-  c->face_elems[4] = c->face_elems[5] = NI * NJ;
-  for (int f = 0; f < 6; f++) {
-    if (nID[f] < 0 || f == 2 || f == 3) continue;
-    HIP_CHECK(hipMalloc(&c->sendbuf[f], c->face_elems[f] * elem_bytes));
-    HIP_CHECK(hipMalloc(&c->recvbuf[f], c->face_elems[f] * elem_bytes));
-  }
+  c->coord[0] = rank % div[0], c->coord[1] = (rank / div[0]) % div[1], c->coord[2] = rank / (div[0] * div[1]);
+  build_pattern(c, c->shallow, 1, false);
+  build_pattern(c, c->deep, 2, true);
   HIP_CHECK(hipHostMalloc(&c->h_red, 16 * sizeof(double), hipHostMallocDefault));
   if (c->tr == T_LOCAL) {
     std::lock_guard<std::mutex> lk(c->world->mu);
@@ -232,194 +291,23 @@ CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], i
 
 void comm_destroy(CommCtx* c) {
   if (!c) return;
-  for (int f = 0; f < 6; f++) {
-    if (c->sendbuf[f]) (void)hipFree(c->sendbuf[f]);
-    if (c->recvbuf[f]) (void)hipFree(c->recvbuf[f]);
-  }
-  for (int f = 0; f < 6; f++) {
-    if (c->send2[f]) (void)hipFree(c->send2[f]);
-    if (c->recv2[f]) (void)hipFree(c->recv2[f]);
+  for (Pattern* p : {&c->shallow, &c->deep}) {
+    if (p->sendbuf) (void)hipFree(p->sendbuf);
+    if (p->recvbuf) (void)hipFree(p->recvbuf);
   }
   (void)hipHostFree(c->h_red);
   delete c;
 }
 
-namespace {
-template <typename T>
-void pack_faces(CommCtx* c, const T* X, const int* skip, hipStream_t st) {
-  const int NI = c->size[0], NJ = c->size[1], NK = c->size[2], g = c->g;
-  const int nkp = NK + 2 * g, nip = NI + 2 * g;
-  // owned boundary layers: i = 1 / NI, k = 1 / NK (1-based) -> padded index +g-1
-  if (c->nID[0] >= 0) hipLaunchKernelGGL(pack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[0], X, NK, NJ, nkp, nip, g, g, skip);
-  if (c->nID[1] >= 0) hipLaunchKernelGGL(pack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[1], X, NK, NJ, nkp, nip, NI + g - 1, g, skip);
-  if (c->nID[4] >= 0) hipLaunchKernelGGL(pack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[4], X, NI, NJ, nkp, nip, g, g, skip);
-  if (c->nID[5] >= 0) hipLaunchKernelGGL(pack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, (T*)c->sendbuf[5], X, NI, NJ, nkp, nip, NK + g - 1, g, skip);
-  HIP_CHECK(hipGetLastError());
-}
-template <typename T>
-void unpack_faces(CommCtx* c, T* X, const int* skip, hipStream_t st) {
-  const int NI = c->size[0], NJ = c->size[1], NK = c->size[2], g = c->g;
-  const int nkp = NK + 2 * g, nip = NI + 2 * g;
-  // ghost layers: i = 0 / NI+1, k = 0 / NK+1 (1-based) -> padded index g-1 / N+g
-  if (c->nID[0] >= 0) hipLaunchKernelGGL(unpack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[0], NK, NJ, nkp, nip, g - 1, g, skip);
-  if (c->nID[1] >= 0) hipLaunchKernelGGL(unpack_iface_k<T>, dim3((NK + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[1], NK, NJ, nkp, nip, NI + g, g, skip);
-  if (c->nID[4] >= 0) hipLaunchKernelGGL(unpack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[4], NI, NJ, nkp, nip, g - 1, g, skip);
-  if (c->nID[5] >= 0) hipLaunchKernelGGL(unpack_kface_k<T>, dim3((NI + 127) / 128, NJ), dim3(128), 0, st, X, (const T*)c->recvbuf[5], NI, NJ, nkp, nip, NK + g, g, skip);
-  HIP_CHECK(hipGetLastError());
-}
-// J faces in place: element offset of row i=1 (1-based) of plane j (1-based), k from the first guide cell
-inline size_t jface_off(const CommCtx* c, int j1) {
-  const size_t nkp = c->size[2] + 2 * c->g, nip = c->size[0] + 2 * c->g;
-  return (size_t)(j1 + c->g - 1) * nkp * nip + (size_t)c->g * nkp;
-}
-}  // namespace
-
 bool comm_halo(CommCtx* c, void* X, const int* skip, hipStream_t st) {
   if (!c) return true;
-  char* Xb = (char*)X;
-  const int NJ = c->size[1];
-  const int opp[6] = {1, 0, 3, 2, 5, 4};
-  if (c->eb == 4) pack_faces<float>(c, (const float*)X, skip, st);
-  else pack_faces<double>(c, (const double*)X, skip, st);
-
-  if (c->tr == T_RCCL) {
-    const ncclDataType_t dt = c->eb == 4 ? ncclFloat : ncclDouble;
-    NCCL_CHECK(ncclGroupStart());
-    for (int f = 0; f < 6; f++) {
-      if (c->nID[f] < 0) continue;
-      const void* sb;
-      void* rb;
-      if (f == 2) sb = Xb + jface_off(c, 1) * c->eb, rb = Xb + jface_off(c, 0) * c->eb;
-      else if (f == 3) sb = Xb + jface_off(c, NJ) * c->eb, rb = Xb + jface_off(c, NJ + 1) * c->eb;
-      else sb = c->sendbuf[f], rb = c->recvbuf[f];
-      NCCL_CHECK(ncclSend(sb, c->face_elems[f], dt, c->nID[f], c->nccl, st));
-      NCCL_CHECK(ncclRecv(rb, c->face_elems[f], dt, c->nID[f], c->nccl, st));
-    }
-    NCCL_CHECK(ncclGroupEnd());
-  } else {  // LOCAL
-    c->cur_X = X;
-    HIP_CHECK(hipStreamSynchronize(st));
-    c->world->barrier();  // every rank has packed and published
-    for (int f = 0; f < 6; f++) {
-      if (c->nID[f] < 0) continue;
-      CommCtx* nb = c->world->ranks[c->nID[f]];
-      if (f == 2 || f == 3) {
-        // my ghost plane (j=0 / NJ+1) <- neighbour's owned plane (j=NJnb / 1)
-        char* nbX = (char*)nb->cur_X;
-        const size_t src = (f == 2) ? jface_off(nb, nb->size[1]) : jface_off(nb, 1);
-        const size_t dst = (f == 2) ? jface_off(c, 0) : jface_off(c, NJ + 1);
-        HIP_CHECK(hipMemcpyAsync(Xb + dst * c->eb, nbX + src * c->eb, c->face_elems[f] * c->eb, hipMemcpyDeviceToDevice, st));
-      } else {
-        HIP_CHECK(hipMemcpyAsync(c->recvbuf[f], nb->sendbuf[opp[f]], c->face_elems[f] * c->eb, hipMemcpyDeviceToDevice, st));
-      }
-    }
-    HIP_CHECK(hipStreamSynchronize(st));
-    c->world->barrier();  // nobody repacks before everyone has copied
-  }
-
-  if (c->eb == 4) unpack_faces<float>(c, (float*)X, skip, st);
-  else unpack_faces<double>(c, (double*)X, skip, st);
-  return true;
+  return c->eb == 4 ? exchange<float>(c, c->shallow, (float*)X, skip, st) : exchange<double>(c, c->shallow, (double*)X, skip, st);
 }
-
-
-// ------------------------------------------------------------------------------------------------------------
-// Depth-2 exchange in three dependent phases I -> J -> K.  Each later phase sends the ghost cells the earlier ones
-// received, so the edge cells the first sweep of a fused pair needs (ghost layer 1 in two directions) arrive after
-// two hops; no diagonal messages.
-//   I: layers i = 1,2 / NI-1,NI of the owned (j,k) extent, packed [layer][j][k]
-//   J: planes j = 1,2 / NJ-1,NJ, whole padded planes, in place (contiguous)
-//   K: layers k = 1,2 / NK-1,NK of the whole padded (i,j) extent, packed [layer][jj][ii]
-// ------------------------------------------------------------------------------------------------------------
-namespace {
-template <typename T>
-bool halo2_impl(CommCtx* c, T* X, const int* skip, hipStream_t st) {
-  const int NI = c->size[0], NJ = c->size[1], NK = c->size[2], g = c->g;
-  const int nkp = NK + 2 * g, nip = NI + 2 * g, njp = NJ + 2 * g;
-  const size_t PS = (size_t)nkp * nip;
-  const int opp[6] = {1, 0, 3, 2, 5, 4};
-  if (!c->elems2[0]) {
-    c->elems2[0] = c->elems2[1] = (size_t)2 * NJ * NK;
-    c->elems2[2] = c->elems2[3] = (size_t)2 * PS;
-    c->elems2[4] = c->elems2[5] = (size_t)2 * nip * njp;
-    for (int f : {0, 1, 4, 5}) {
-      if (c->nID[f] < 0) continue;
-      HIP_CHECK(hipMalloc(&c->send2[f], c->elems2[f] * sizeof(T)));
-      HIP_CHECK(hipMalloc(&c->recv2[f], c->elems2[f] * sizeof(T)));
-    }
-  }
-  const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
-  auto exchange = [&](int f0, const void* sb0, void* rb0, const void* sb1, void* rb1) {
-    // faces f0 (minus) and f0+1 (plus) of one axis
-    const void* sb[2] = {sb0, sb1};
-    void* rb[2] = {rb0, rb1};
-    if (c->tr == T_RCCL) {
-      if (c->nID[f0] < 0 && c->nID[f0 + 1] < 0) return;
-      NCCL_CHECK(ncclGroupStart());
-      for (int s = 0; s < 2; s++) {
-        const int f = f0 + s;
-        if (c->nID[f] < 0) continue;
-        NCCL_CHECK(ncclSend(sb[s], c->elems2[f], dt, c->nID[f], c->nccl, st));
-        NCCL_CHECK(ncclRecv(rb[s], c->elems2[f], dt, c->nID[f], c->nccl, st));
-      }
-      NCCL_CHECK(ncclGroupEnd());
-    } else {
-      // LOCAL: publish my send pointers, then copy from the neighbours'
-      c->send2[f0 + 0] = const_cast<void*>(sb0);  // (for J these are array regions, for I/K the pack buffers)
-      c->send2[f0 + 1] = const_cast<void*>(sb1);
-      HIP_CHECK(hipStreamSynchronize(st));
-      c->world->barrier();
-      for (int s = 0; s < 2; s++) {
-        const int f = f0 + s;
-        if (c->nID[f] < 0) continue;
-        CommCtx* nb = c->world->ranks[c->nID[f]];
-        HIP_CHECK(hipMemcpyAsync(rb[s], nb->send2[opp[f]], c->elems2[f] * sizeof(T), hipMemcpyDeviceToDevice, st));
-      }
-      HIP_CHECK(hipStreamSynchronize(st));
-      c->world->barrier();
-    }
-  };
-
-  // ---- phase I
-  {
-    dim3 grid((NK + 127) / 128, NJ, 2);
-    void* s0 = c->send2[0];
-    void* s1 = c->send2[1];
-    if (c->nID[0] >= 0) hipLaunchKernelGGL(pack_i2_k<T>, grid, dim3(128), 0, st, (T*)s0, X, NK, NJ, nkp, nip, g, g, skip);
-    if (c->nID[1] >= 0) hipLaunchKernelGGL(pack_i2_k<T>, grid, dim3(128), 0, st, (T*)s1, X, NK, NJ, nkp, nip, NI + g - 2, g, skip);
-    exchange(0, s0, c->recv2[0], s1, c->recv2[1]);
-    c->send2[0] = s0, c->send2[1] = s1;
-    if (c->nID[0] >= 0) hipLaunchKernelGGL(unpack_i2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[0], NK, NJ, nkp, nip, 0, g, skip);
-    if (c->nID[1] >= 0) hipLaunchKernelGGL(unpack_i2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[1], NK, NJ, nkp, nip, NI + g, g, skip);
-  }
-  // ---- phase J (in place: two whole padded planes)
-  {
-    void* keep0 = c->send2[2];
-    void* keep1 = c->send2[3];
-    exchange(2, X + (size_t)g * PS, X, X + (size_t)(NJ + g - 2) * PS, X + (size_t)(NJ + g) * PS);
-    c->send2[2] = keep0, c->send2[3] = keep1;
-  }
-  // ---- phase K
-  {
-    dim3 grid((nip + 127) / 128, njp, 2);
-    void* s0 = c->send2[4];
-    void* s1 = c->send2[5];
-    if (c->nID[4] >= 0) hipLaunchKernelGGL(pack_k2_k<T>, grid, dim3(128), 0, st, (T*)s0, X, nkp, nip, njp, g, skip);
-    if (c->nID[5] >= 0) hipLaunchKernelGGL(pack_k2_k<T>, grid, dim3(128), 0, st, (T*)s1, X, nkp, nip, njp, NK + g - 2, skip);
-    exchange(4, s0, c->recv2[4], s1, c->recv2[5]);
-    c->send2[4] = s0, c->send2[5] = s1;
-    if (c->nID[4] >= 0) hipLaunchKernelGGL(unpack_k2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[4], nkp, nip, njp, 0, skip);
-    if (c->nID[5] >= 0) hipLaunchKernelGGL(unpack_k2_k<T>, grid, dim3(128), 0, st, X, (const T*)c->recv2[5], nkp, nip, njp, NK + g, skip);
-  }
-  HIP_CHECK(hipGetLastError());
-  return true;
-}
-}  // namespace
 
 bool comm_halo2(CommCtx* c, void* X, const int* skip, hipStream_t st) {
   if (!c) return true;
   if (c->g != 2) return false;
-  return c->eb == 4 ? halo2_impl<float>(c, (float*)X, skip, st) : halo2_impl<double>(c, (double*)X, skip, st);
+  return c->eb == 4 ? exchange<float>(c, c->deep, (float*)X, skip, st) : exchange<double>(c, c->deep, (double*)X, skip, st);
 }
 
 bool comm_allreduce_sum(CommCtx* c, double* d_val, int count, hipStream_t st) {

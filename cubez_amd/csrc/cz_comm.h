@@ -20,11 +20,11 @@ void comm_auto_division(int nproc, const int G_size[3], int G_div[3]);
 // cell-ownership decomposition: local size, 1-based global head, neighbour table (I-,I+,J-,J+,K-,K+; -1 = physical)
 bool comm_decompose(const int G_size[3], const int G_div[3], int nproc, int rank, int size[3], int head[3], int nID[6]);
 
-CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], int elem_bytes);
+CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], int elem_bytes, const int div[3]);
 void comm_destroy(CommCtx*);
 // one-layer exchange of the six faces of X (device pointer), stream-ordered on `st`
 bool comm_halo(CommCtx*, void* X, const int* skip_flag_dev, hipStream_t st);
-// two-layer exchange incl. edges (three dependent phases I, J, K); needs g == 2
+// two ghost layers on the faces + the 12 edges, single phase (diagonal neighbours get the edges directly); needs g == 2
 bool comm_halo2(CommCtx*, void* X, const int* skip_flag_dev, hipStream_t st);
 bool comm_allreduce_sum(CommCtx*, double* d_val, int count, hipStream_t st);
 double comm_allreduce_max_host(CommCtx*, double v);

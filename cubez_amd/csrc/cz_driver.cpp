@@ -196,7 +196,7 @@ int CZ::Setup(int argc, char** argv) {
 
   if (!decompose(div_type)) return 0;
   if (numProc > 1) {
-    comm = comm_create(myRank, numProc, size, nID, sizeof(REAL_TYPE));
+    comm = comm_create(myRank, numProc, size, nID, sizeof(REAL_TYPE), G_div);
     if (!comm) return 0;
   }
 
