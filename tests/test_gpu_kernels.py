@@ -299,7 +299,7 @@ def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
             a1, wide = p.copy(), np.zeros(1)
             for color in (0, 1):
                 ko.psor2sma_core(a1, sz, idx, cf, ofst, color, 1.3, b, wide=wide)
-            for (tb, mv, tj) in T2_TUNINGS[::2]:
+            for (tb, mv, tj) in T2_TUNINGS[::2] + T2_TUNINGS[-1:]:
                 assert h.set_tuning2(tb, mv, tj, 1)
                 dw = h.alloc(sz, p)
                 ok, r = h.rbsor2(du, dw, db, sz, idx, cf, ofst, 1.3)
