@@ -460,50 +460,6 @@ __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, 
 // RB = 0: two Jacobi sweeps.  RB = 1: one red-black SOR iteration (cz_solver.f90:466-480 for colour 0 then colour 1):
 // stage 1 updates the points of colour 0, stage 2 those of colour 1 from the freshly updated colour-0 neighbours; the
 // other colour passes through each stage unchanged.  Out of place (U -> W) like the Jacobi pair.
-// RB = 0: two Jacobi sweeps.  RB = 1: one red-black SOR iteration (cz_solver.f90:466-480 for colour 0 then colour 1):
-// stage 1 updates the points of colour 0, stage 2 those of colour 1 from the freshly updated colour-0 neighbours; the
-// other colour passes through each stage unchanged.  Out of place (U -> W) like the Jacobi pair.
-// keep a value in a VGPR across the optimiser: without this, `s ? a.v[1] : a.v[0]` is rewritten into a load from a
-// run-time-indexed address and every register-resident vector of the kernel moves to scratch (7x slower, measured)
-template <typename T>
-__device__ __forceinline__ T in_reg(T x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
-// Red-black form of relax_vec: only the V/2 components of the active colour (sel = index of the first one: 0 or 1; they
-// alternate along k) go through the arithmetic, the others are passed through -- half the VALU work of relax_vec.
-template <int V>
-__device__ __forceinline__ Vec<V> relax_colour(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
-                                               const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c, int sel,
-                                               unsigned mask, unsigned count_mask, double& acc) {
-  Vec<V> o;
-  if (V == 1) return relax_vec<V>(pc, im, ip, pm, pn, kl, kr, bb, c, mask, count_mask, acc);
-#pragma unroll
-  for (int h = 0; h < V / 2; h++) {
-    const int c0 = 2 * h, c1 = 2 * h + 1;  // the active component is c0 (sel == 0) or c1 (sel == 1)
-    const bool s = sel != 0;
-    const REAL p0 = in_reg(pc.v[c0]), p1 = in_reg(pc.v[c1]);
-    const REAL pp = s ? p1 : p0;
-    const REAL vi0 = s ? in_reg(im.v[c1]) : in_reg(im.v[c0]), vi1 = s ? in_reg(ip.v[c1]) : in_reg(ip.v[c0]);
-    const REAL vj0 = s ? in_reg(pm.v[c1]) : in_reg(pm.v[c0]), vj1 = s ? in_reg(pn.v[c1]) : in_reg(pn.v[c0]);
-    const REAL b0 = s ? in_reg(bb.v[c1]) : in_reg(bb.v[c0]);
-    const REAL left = in_reg((c0 == 0) ? kl : pc.v[c0 > 0 ? c0 - 1 : 0]);        // k-1 of c0
-    const REAL right = in_reg((c1 == V - 1) ? kr : pc.v[c1 < V - 1 ? c1 + 1 : 0]);  // k+1 of c1
-    const REAL km1 = s ? p0 : left;
-    const REAL kp1 = s ? right : p1;
-    const REAL ss = c.c1 * vi1 + c.c2 * vi0 + c.c3 * vj1 + c.c4 * vj0 + c.c5 * kp1 + c.c6 * km1;
-    const REAL dp = ((ss - b0) / c.dd - pp) * c.omg;
-    const REAL d2 = dp * dp;
-    const unsigned bit = s ? (1u << c1) : (1u << c0);
-    const REAL nv = (mask & bit) ? pp + dp : pp;
-    o.v[c0] = s ? p0 : nv;
-    o.v[c1] = s ? nv : p1;
-    if (count_mask & bit) acc += (double)d2;
-  }
-  return o;
-}
-
 template <int V, int TB, int MV, int RB>
 __global__ void __launch_bounds__(TB, (TB == 512 && MV <= 2) ? 4 : 1)
 jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
@@ -593,373 +549,6 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
       for (int m = 0; m < MV; m++) {
         uc[m] = ld[m] ? ldv<V>(Uc, f[m]) : zerov<V>();
         b1[m] = (ka[m] != 0 && plane_inner) ? ldv<V>(Bq, f[m]) : zerov<V>();
-      }
-      Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
-      const bool halo_in_regs = (R <= TB);
-      if (more && halo_in_regs && t < R) {
-        hlo = ldv<V>(Pn, fb - R + t);
-        const long long fh = fb + g.S + t;
-        if (fh < lim_ld) hhi = ldv<V>(Pn, fh);
-      }
-
-      // ---- update plane jj
-      const Vec<V>* buf = ldsv + (size_t)cur * L;
-      const REAL* buff = ldsf + (size_t)cur * L * V;
-      REAL* Oc = OUT + (long long)jj * g.PSV * V;
-#pragma unroll
-      for (int m = 0; m < M; m++) {
-        if (mk[m] == 0) continue;
-        const int li = t + m * TB;
-        const Vec<V> im = buf[li];
-        const Vec<V> ip = buf[li + 2 * R];
-        const REAL kl = buff[(R + li) * V - 1];
-        const REAL kr = buff[(R + li) * V + V];
-        Vec<V> o;
-        unsigned wmask = mk[m];
-        if (MODE == MODE_RB) {
-          // colour: (kk + ii + jj + par) even
-          unsigned cm = 0;
-#pragma unroll
-          for (int cc = 0; cc < V; cc++)
-            if (((pbase[m] + cc + jj) & 1) == 0) cm |= 1u << cc;
-          wmask &= cm;
-        }
-#pragma unroll
-        for (int cc = 0; cc < V; cc++) {
-          const REAL pp = pc[m].v[cc];
-          const REAL km1 = (cc == 0) ? kl : pc[m].v[cc > 0 ? cc - 1 : 0];
-          const REAL kp1 = (cc == V - 1) ? kr : pc[m].v[cc < V - 1 ? cc + 1 : V - 1];
-          const REAL ss = c.c1 * ip.v[cc] + c.c2 * im.v[cc] + c.c3 * pn[m].v[cc] + c.c4 * pm[m].v[cc] + c.c5 * kp1 +
-                          c.c6 * km1;
-          if (MODE == MODE_JACOBI || MODE == MODE_RB) {
-            const REAL dp = ((ss - bb[m].v[cc]) / c.dd - pp) * c.omg;
-            o.v[cc] = pp + dp;
-            const REAL d2 = dp * dp;
-            if (wmask & (1u << cc)) acc += (double)d2;
-          } else if (MODE == MODE_AX) {
-            o.v[cc] = ss - c.dd * pp;
-          } else {
-            o.v[cc] = bb[m].v[cc] - (ss - c.dd * pp);
-          }
-        }
-        if (MODE == MODE_RB) {
-          // in place: components of the other colour / outside the box keep their value; a full-vector store
-          // of unchanged bits is harmless because every element is owned by exactly one thread.
-          if (mk[m] == (1u << V) - 1) {
-#pragma unroll
-            for (int cc = 0; cc < V; cc++)
-              if (!(wmask & (1u << cc))) o.v[cc] = pc[m].v[cc];
-            stv<V>(Oc, f[m], o);
-          } else {
-#pragma unroll
-            for (int cc = 0; cc < V; cc++)
-              if (wmask & (1u << cc)) Oc[f[m] * V + cc] = o.v[cc];
-          }
-        } else {
-          if (wmask == (1u << V) - 1) {
-            stv<V>(Oc, f[m], o);
-          } else {
-#pragma unroll
-            for (int cc = 0; cc < V; cc++)
-              if (wmask & (1u << cc)) Oc[f[m] * V + cc] = o.v[cc];
-          }
-        }
-      }
-
-      // ---- stage plane jj+1 into the other LDS buffer, rotate the register queue
-      if (more) {
-        Vec<V>* nbuf = ldsv + (size_t)(cur ^ 1) * L;
-#pragma unroll
-        for (int m = 0; m < M; m++) nbuf[R + t + m * TB] = pn[m];
-        if (halo_in_regs) {
-          if (t < R) {
-            nbuf[t] = hlo;
-            nbuf[R + g.S + t] = hhi;
-          }
-        } else {
-          for (int h = t; h < R; h += TB) {
-            nbuf[h] = ldv<V>(Pn, fb - R + h);
-            const long long fh = fb + g.S + h;
-            nbuf[R + g.S + h] = (fh < lim_ld) ? ldv<V>(Pn, fh) : zerov<V>();
-          }
-        }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int m = 0; m < M; m++) {
-        pm[m] = pc[m];
-        pc[m] = pn[m];
-        if (PF) {
-          pn[m] = pnn[m];
-          bb[m] = bbn[m];
-        }
-      }
-      cur ^= 1;
-    }
-  }
-
-  if (MODE == MODE_JACOBI || MODE == MODE_RB) {
-    __syncthreads();
-    const double s = block_sum<TB>(acc, wsum);
-    if (fin.dst == nullptr) {
-      if (t == 0) partials[lb] = s;
-    } else {
-      int* last_flag = reinterpret_cast<int*>(wsum + 16);
-      if (t == 0) {
-        // write-through (sc1) store of the partial, drained, then the ticket: no L2 write-back fence per workgroup
-        // (a release fence here flushes the XCD's dirty p' lines and cost +27 % on the whole sweep, profiles/README.md)
-        __hip_atomic_store(&partials[lb], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *last_flag = (ticket == (unsigned)nblk - 1u);
-      }
-      __syncthreads();
-      if (*last_flag) {
-        double x = 0.0;
-        // every load of the handed-off partials is an sc1 (agent-scope) load
-        for (int i = t; i < nblk; i += TB) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const double tot = block_sum<TB>(x, wsum);
-        if (t == 0) {
-          double r = fin.accumulate ? fin.dst[0] + tot : tot;
-          fin.dst[0] = r;
-          if (fin.do_check) {  // cz_Poisson.cpp:69-77
-            r *= fin.res_normal;
-            r = sqrt(r);
-            fin.hist[fin.itr] = r;
-            if (r < fin.eps) {
-              *fin.flag = 1;
-              *fin.conv_itr = fin.itr;
-            }
-          }
-          *fin.counter = 0u;
-        }
-      }
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------------------
-// TWO relaxed-Jacobi sweeps per pass over memory (temporal blocking, single-domain runs).
-//
-// Each sweep of cz_solver.f90:334-351 is HBM bound at 12 B per update and stencil_k already moves within 5 % of the
-// ideal bytes (profiles/r01), so the only way past the streaming ceiling is to apply sweep n+1 and sweep n+2 while
-// the data are on chip.  Same 2.5-D march as stencil_k, two stages deep:
-//     stage 1 at plane q   : v(q)   = relax(u(q-1), u(q), u(q+1))     on E1 = own segment +- one k-row (R vectors)
-//     stage 2 at plane q-1 : w(q-1) = relax(v(q-2), v(q-1), v(q))     on the own segment
-// u = input field (time n), v = time n+1 (never leaves the CU: registers + LDS), w = output (time n+2).
-// Register queues hold u(q-1..q+1) and v(q-2..q) of the thread's vectors; LDS holds the centre planes u(q) (own
-// segment +- 2 rows) and v(q-1) (own +- 1 row) for the i+-1 / k+-1 neighbours, double-buffered, one barrier per plane.
-// The halo rows of v and the first/last plane of a chunk are recomputed by the neighbouring workgroups (redundant
-// arithmetic, (S+2R)/S in i and (TJ+2)/TJ in j) instead of being exchanged.  Points outside the inner box pass
-// through unchanged (v = u), exactly what a separate first sweep would have left in memory, and the per-point
-// arithmetic is the same un-fused float sequence, so the result is bit-identical to two launches of stencil_k.
-// Both residuals (sum dp^2 of sweep n+1 and of sweep n+2) are produced; each point is counted by the one workgroup
-// that owns it.
-// ------------------------------------------------------------------------------------------------------------
-struct Geom2 {
-  int R;
-  long long PSV;
-  int kk0, kk1, jj0, jj1;      // stage-2 (output) box = the inner box
-  long long F0, Fend;
-  // stage-1 box: the inner box, grown by one layer across rank-internal faces of a decomposed run (the first sweep
-  // must also be applied to the ghost layer the second sweep reads; two ghost layers are exchanged per pair)
-  int kk0a, kk1a, jj0a, jj1a;
-  long long F0a, Fenda;
-  int nseg, TJ, S;  // S = TB*MV - 2R
-  int par;          // RB: colour 0 = points with (kk + ii + jj + par) even
-};
-
-struct Fin2 {
-  double* dst = nullptr;   // [0] <- sum of sweep n+1, [1] <- sum of sweep n+2
-  int do_check = 0, itr = 0;  // itr = iteration number of sweep n+1
-  int single = 0;             // RB: both stages belong to ONE iteration: dst[0] = sum1 + sum2, one bookkeeping step
-  double res_normal = 0.0, eps = 0.0;
-  double* hist = nullptr;
-  int* flag = nullptr;
-  int* conv_itr = nullptr;
-  unsigned* counter = nullptr;
-};
-
-// bit cc set when (base + cc) is even
-template <int V>
-__device__ __forceinline__ unsigned colour_bits(int base) {
-  const unsigned even = (V == 4) ? 0x5u : (V == 2) ? 0x1u : 0x1u;   // components 0,2 / 0 / 0
-  const unsigned odd = (V == 4) ? 0xAu : (V == 2) ? 0x2u : 0x0u;    // components 1,3 / 1 / -
-  return (base & 1) ? odd : even;
-}
-
-template <int V>
-__device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
-                                            const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c,
-                                            unsigned mask, unsigned count_mask, double& acc) {
-  Vec<V> o;
-#pragma unroll
-  for (int cc = 0; cc < V; cc++) {
-    const REAL pp = pc.v[cc];
-    const REAL km1 = (cc == 0) ? kl : pc.v[cc > 0 ? cc - 1 : 0];
-    const REAL kp1 = (cc == V - 1) ? kr : pc.v[cc < V - 1 ? cc + 1 : V - 1];
-    const REAL ss = c.c1 * ip.v[cc] + c.c2 * im.v[cc] + c.c3 * pn.v[cc] + c.c4 * pm.v[cc] + c.c5 * kp1 + c.c6 * km1;
-    const REAL dp = ((ss - bb.v[cc]) / c.dd - pp) * c.omg;
-    const REAL d2 = dp * dp;
-    o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;
-    if (count_mask & (1u << cc)) acc += (double)d2;
-  }
-  return o;
-}
-
-// RB = 0: two Jacobi sweeps.  RB = 1: one red-black SOR iteration (cz_solver.f90:466-480 for colour 0 then colour 1):
-// stage 1 updates the points of colour 0, stage 2 those of colour 1 from the freshly updated colour-0 neighbours; the
-// other colour passes through each stage unchanged.  Out of place (U -> W) like the Jacobi pair.
-// RB = 0: two Jacobi sweeps.  RB = 1: one red-black SOR iteration (cz_solver.f90:466-480 for colour 0 then colour 1):
-// stage 1 updates the points of colour 0, stage 2 those of colour 1 from the freshly updated colour-0 neighbours; the
-// other colour passes through each stage unchanged.  Out of place (U -> W) like the Jacobi pair.
-// keep a value in a VGPR across the optimiser: without this, `s ? a.v[1] : a.v[0]` is rewritten into a load from a
-// run-time-indexed address and every register-resident vector of the kernel moves to scratch (7x slower, measured)
-template <typename T>
-__device__ __forceinline__ T in_reg(T x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
-// Red-black form of relax_vec: only the V/2 components of the active colour (sel = index of the first one: 0 or 1; they
-// alternate along k) go through the arithmetic, the others are passed through -- half the VALU work of relax_vec.
-template <int V>
-__device__ __forceinline__ Vec<V> relax_colour(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
-                                               const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c, int sel,
-                                               unsigned mask, unsigned count_mask, double& acc) {
-  Vec<V> o;
-  if (V == 1) return relax_vec<V>(pc, im, ip, pm, pn, kl, kr, bb, c, mask, count_mask, acc);
-#pragma unroll
-  for (int h = 0; h < V / 2; h++) {
-    const int c0 = 2 * h, c1 = 2 * h + 1;  // the active component is c0 (sel == 0) or c1 (sel == 1)
-    const bool s = sel != 0;
-    const REAL p0 = in_reg(pc.v[c0]), p1 = in_reg(pc.v[c1]);
-    const REAL pp = s ? p1 : p0;
-    const REAL vi0 = s ? in_reg(im.v[c1]) : in_reg(im.v[c0]), vi1 = s ? in_reg(ip.v[c1]) : in_reg(ip.v[c0]);
-    const REAL vj0 = s ? in_reg(pm.v[c1]) : in_reg(pm.v[c0]), vj1 = s ? in_reg(pn.v[c1]) : in_reg(pn.v[c0]);
-    const REAL b0 = s ? in_reg(bb.v[c1]) : in_reg(bb.v[c0]);
-    const REAL left = in_reg((c0 == 0) ? kl : pc.v[c0 > 0 ? c0 - 1 : 0]);        // k-1 of c0
-    const REAL right = in_reg((c1 == V - 1) ? kr : pc.v[c1 < V - 1 ? c1 + 1 : 0]);  // k+1 of c1
-    const REAL km1 = s ? p0 : left;
-    const REAL kp1 = s ? right : p1;
-    const REAL ss = c.c1 * vi1 + c.c2 * vi0 + c.c3 * vj1 + c.c4 * vj0 + c.c5 * kp1 + c.c6 * km1;
-    const REAL dp = ((ss - b0) / c.dd - pp) * c.omg;
-    const REAL d2 = dp * dp;
-    const unsigned bit = s ? (1u << c1) : (1u << c0);
-    const REAL nv = (mask & bit) ? pp + dp : pp;
-    o.v[c0] = s ? p0 : nv;
-    o.v[c1] = s ? nv : p1;
-    if (count_mask & bit) acc += (double)d2;
-  }
-  return o;
-}
-
-template <int V, int TB, int MV, int RB>
-__global__ void __launch_bounds__(TB, (TB == 512 && MV <= 2) ? 4 : 1)
-jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
-          const int* __restrict__ skip, Fin2 fin) {
-  if (skip != nullptr && *skip != 0) return;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int t = threadIdx.x;
-  const int R = g.R;
-  const int LU = g.S + 4 * R, LV = g.S + 2 * R;
-  Vec<V>* ldsU = reinterpret_cast<Vec<V>*>(smem);                 // 2 buffers of LU vectors
-  Vec<V>* ldsV = ldsU + (size_t)2 * LU;                            // 2 buffers of LV vectors
-  double* wsum = reinterpret_cast<double*>(ldsV + (size_t)2 * LV);  // 16 doubles + flag
-
-  int lb = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) lb = (lb & 7) * (nblk >> 3) + (lb >> 3);
-  const int seg = lb % g.nseg;
-  const int chunk = lb / g.nseg;
-  const long long fb = g.F0 + (long long)seg * g.S;
-  const int ja = g.jj0 + chunk * g.TJ;
-  int jb = ja + g.TJ - 1;
-  if (jb > g.jj1) jb = g.jj1;
-
-  double acc1 = 0.0, acc2 = 0.0;
-
-  if (ja <= jb && fb < g.Fend) {
-    const long long e1_0 = fb - R;       // first vector of E1
-    const long long e2_0 = fb - 2 * R;   // first vector of E2
-    long long f[MV];
-    unsigned ka[MV];     // stage-1 bits: components of the vector inside the stage-1 box (0 when the row is outside)
-    unsigned own[MV];    // stage-2 bits if this workgroup owns the vector (stores, residual counts), else 0
-    int pbase[MV];       // RB: (kk + ii + par) of component 0; component cc on plane jj has colour (pbase + cc + jj) & 1
-    bool ld[MV];
-#pragma unroll
-    for (int m = 0; m < MV; m++) {
-      const int e = t + m * TB;
-      f[m] = e1_0 + e;
-      ld[m] = (e < LV) && (f[m] < g.PSV);
-      const long long row = f[m] / R;
-      const int kv = (int)(f[m] - row * R);
-      unsigned bits1 = 0, bits2 = 0;
-#pragma unroll
-      for (int cc = 0; cc < V; cc++) {
-        const int kk = kv * V + cc;
-        if (kk >= g.kk0a && kk <= g.kk1a) bits1 |= 1u << cc;
-        if (kk >= g.kk0 && kk <= g.kk1) bits2 |= 1u << cc;
-      }
-      pbase[m] = kv * V + (int)row + g.par;
-      ka[m] = (e < LV && f[m] >= g.F0a && f[m] < g.Fenda) ? bits1 : 0u;
-      own[m] = (e >= R && e < R + g.S && f[m] >= g.F0 && f[m] < g.Fend) ? bits2 : 0u;
-    }
-
-    Vec<V> ua[MV], ub[MV], uc[MV], b1[MV], b2[MV], va[MV], vb[MV], vc[MV];
-    // prologue: u(ja-2), u(ja-1); LDS_U[0] = u(ja-1) on E2
-    {
-      const REAL* Ua = U + (long long)(ja - 2) * g.PSV * V;
-      const REAL* Ub = U + (long long)(ja - 1) * g.PSV * V;
-#pragma unroll
-      for (int m = 0; m < MV; m++) {
-        ua[m] = ld[m] ? ldv<V>(Ua, f[m]) : zerov<V>();
-        ub[m] = ld[m] ? ldv<V>(Ub, f[m]) : zerov<V>();
-        b2[m] = zerov<V>();
-        va[m] = zerov<V>();
-        vb[m] = zerov<V>();
-      }
-#pragma unroll
-      for (int m = 0; m < MV; m++)
-        if (t + m * TB < LV) ldsU[R + t + m * TB] = ub[m];
-      if (t < R) {
-        ldsU[t] = ldv<V>(Ub, e2_0 + t);
-        const long long fh = fb + g.S + R + t;
-        ldsU[R + LV + t] = (fh < g.PSV) ? ldv<V>(Ub, fh) : zerov<V>();
-      }
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int q = ja - 1; q <= jb + 1; q++) {
-      const bool more = q <= jb;
-      const bool plane_inner = (q >= g.jj0a && q <= g.jj1a);
-      const bool count1 = (q >= ja && q <= jb);
-      const bool do2 = (q - 1 >= ja);
-      // ---- loads of this step: u(q+1) and b(q) on E1, outer halo rows of u(q+1)
-      const REAL* Uc = U + (long long)(q + 1) * g.PSV * V;
-      const REAL* Bq = B + (long long)q * g.PSV * V;
-      if (PF) {
-        const REAL* Un = Uc + g.PSV * V;                      // u(q+2)
-        const REAL* Bn = Bq + g.PSV * V;                      // b(q+1)
-        const bool pin = (q + 1 >= g.jj0a && q + 1 <= g.jj1a);
-#pragma unroll
-        for (int m = 0; m < MV; m++) {
-          uc[m] = un[m];
-          b1[m] = bn[m];
-          if (more) {
-            un[m] = ld[m] ? ldv<V>(Un, f[m]) : zerov<V>();
-            bn[m] = (ka[m] != 0 && pin) ? ldv<V>(Bn, f[m]) : zerov<V>();
-          }
-        }
-      } else {
-#pragma unroll
-        for (int m = 0; m < MV; m++) {
-          uc[m] = ld[m] ? ldv<V>(Uc, f[m]) : zerov<V>();
-          b1[m] = (ka[m] != 0 && plane_inner) ? ldv<V>(Bq, f[m]) : zerov<V>();
-        }
       }
       Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
       if (more && t < R) {
@@ -1897,7 +1486,6 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
 }
 
 int czhip_use_t2(void) { return ctx.tune.use_t2; }
-
 
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev) {
