@@ -60,3 +60,44 @@ def face_slices(size):
         K_MINUS: ((J, I_, g), (J, I_, g - 1)),
         K_PLUS: ((J, I_, g + nk - 1), (J, I_, g + nk)),
     }
+
+
+def exchange_boxes(size, div, rank, depth=1, edges=False):
+    """Mirror of build_pattern() in cz_comm.cpp: the messages of one single-phase exchange of one brick.
+    -> list of dict(peer, dir, send, recv): numpy index tuples into the padded [j, i, k] array.
+    depth-1 faces = Comm_S(X, 1); depth-2 faces + the 12 one-cell edges = what a fused pair of sweeps reads."""
+    g = GUIDE
+    coord = [rank % div[0], (rank // div[0]) % div[1], rank // (div[0] * div[1])]
+    out = []
+    for dk in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            for di in (-1, 0, 1):
+                d = (di, dj, dk)
+                nz = sum(1 for v in d if v)
+                if nz == 0 or nz == 3 or (nz == 2 and not edges):
+                    continue
+                rc = [coord[a] + d[a] for a in range(3)]
+                if any(rc[a] < 0 or rc[a] >= div[a] for a in range(3)):
+                    continue
+                dep = depth if nz == 1 else 1
+                send, recv = [], []
+                for a in range(3):
+                    n = size[a]
+                    if d[a] == 0:
+                        s0, r0, ext = 1, 1, n
+                    elif d[a] < 0:
+                        s0, r0, ext = 1, 1 - dep, dep
+                    else:
+                        s0, r0, ext = n - dep + 1, n + 1, dep
+                    send.append(slice(s0 + g - 1, s0 + g - 1 + ext))
+                    recv.append(slice(r0 + g - 1, r0 + g - 1 + ext))
+                # (i, j, k) order -> array order [j, i, k]
+                out.append(dict(peer=rc[0] + div[0] * (rc[1] + div[1] * rc[2]), dir=d,
+                                send=(send[1], send[0], send[2]), recv=(recv[1], recv[0], recv[2])))
+    return out
+
+
+def first_sweep_range(idx, nID):
+    """index range of the FIRST sweep of a fused pair: one layer into the ghost cells across rank-internal faces
+    (CZ::JACOBI / RBSOR, idx1)."""
+    return [idx[f] + ((1 if f & 1 else -1) if nID[f] >= 0 else 0) for f in range(6)]

@@ -154,3 +154,86 @@ def test_gloo_decomposed_equals_single_domain(case):
         G[g + hj - 1:g + hj - 1 + nj, g + hi - 1:g + hi - 1 + ni, g + hk - 1:g + hk - 1 + nk] = P[g:g + nj, g:g + ni, g:g + nk]
         assert np.allclose(hist, [r for _, r in ref.history], rtol=1e-12, atol=0)
     assert G[g:-g, g:-g, g:-g].tobytes() == ref.P[g:-g, g:-g, g:-g].tobytes()
+
+
+def _rank_pairs(rank, world, port, gsz, div, solver, npairs, coef, prec, q):
+    """the decomposed FUSED-PAIR algorithm of the GPU driver with the oracle doing the arithmetic: two ghost layers +
+    edges exchanged once per pair (or per red-black iteration), first sweep / first colour also applied to ghost layer 1."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        k = O.Kernels("oracle", prec)
+        R = k.real
+        b = decomp.decompose(gsz, div, world, rank)
+        size, head, nID = b["size"], b["head"], b["nID"]
+        idx = decomp.inner_range(size, nID)
+        idx1 = decomp.first_sweep_range(idx, nID)
+        pitch = R(1.0 / float(R(gsz[2] - 1)))
+        cf = np.array([1, 1, 1, 1, 1, 1, 6], dtype=R)
+        P, RHS, WRK = k.alloc(size), k.alloc(size), k.alloc(size)
+        msgs = decomp.exchange_boxes(size, div, rank, depth=2, edges=True)
+
+        def halo2(X):
+            reqs, recvs = [], []
+            for tag, m in enumerate(msgs):
+                send = torch.from_numpy(np.ascontiguousarray(X[m["send"]]))
+                recv = torch.empty_like(send)
+                d = m["dir"]
+                stag = (d[0] + 1) + 3 * (d[1] + 1) + 9 * (d[2] + 1)
+                rtag = (-d[0] + 1) + 3 * (-d[1] + 1) + 9 * (-d[2] + 1)
+                reqs.append(dist.isend(send, dst=m["peer"], tag=stag))
+                reqs.append(dist.irecv(recv, src=m["peer"], tag=rtag))
+                recvs.append((m["recv"], recv))
+            for r in reqs:
+                r.wait()
+            for sl, recv in recvs:
+                X[sl] = recv.numpy()
+
+        Pg = k.alloc(gsz)
+        k.bc_k(gsz, Pg, pitch, np.zeros(3, dtype=R), [-1] * 6)
+        (ni, nj, nk), (hi, hj, hk) = size, head
+        own = (slice(2, 2 + nj), slice(2, 2 + ni), slice(2, 2 + nk))
+        glob = (slice(hj + 1, hj + 1 + nj), slice(hi + 1, hi + 1 + ni), slice(hk + 1, hk + 1 + nk))
+        P[own] = Pg[glob]
+        RHS[own] = Pg[glob]
+        halo2(P), halo2(RHS)
+        ofst = decomp.rb_offset(head, idx, world)
+        ofst1 = (ofst + idx[4] + idx1[4]) % 2   # same global colouring for the grown box (its kst may differ)
+        for _ in range(npairs):
+            if solver == "jacobi":
+                k.jacobi(P, size, idx1, cf, coef, RHS, WRK)   # sweep n+1 incl. ghost layer 1 (redundant with the neighbour)
+                k.jacobi(P, size, idx, cf, coef, RHS, WRK)    # sweep n+2 on the owned inner box
+            else:
+                k.psor2sma_core(P, size, idx1, cf, ofst1, 0, coef, RHS)  # colour 0 incl. ghost layer 1
+                k.psor2sma_core(P, size, idx, cf, ofst, 1, coef, RHS)    # colour 1 on the owned inner box
+            halo2(P)
+        q.put((rank, size, head, P))
+    finally:
+        dist.destroy_process_group()
+
+
+PAIR_CASES = [("jacobi", (20, 18, 22), (1, 2, 1), 5, 0.8, "f32"), ("jacobi", (21, 19, 23), (2, 2, 1), 4, 0.8, "f32"),
+              ("sor2sma", (21, 19, 23), (2, 1, 2), 6, 1.5, "f32"), ("jacobi", (12, 13, 14), (2, 2, 2), 3, 0.8, "f64")]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES, ids=[f"{c[0]}_{'x'.join(map(str, c[2]))}_{c[5]}" for c in PAIR_CASES])
+def test_gloo_fused_pairs_with_two_layer_exchange(case):
+    solver, gsz, div, npairs, coef, prec = case
+    world = div[0] * div[1] * div[2]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_pairs, args=(r, world, port, gsz, div, solver, npairs, coef, prec, q)) for r in range(world)]
+    [p.start() for p in procs]
+    outs = [q.get(timeout=240) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    nsweeps = 2 * npairs if solver == "jacobi" else npairs
+    ref = O.run(gsz, solver, nsweeps, coef, kind="oracle", prec=prec)
+    g = 2
+    G = np.zeros_like(ref.P)
+    for rank, size, head, P in outs:
+        (ni, nj, nk), (hi, hj, hk) = size, head
+        G[g + hj - 1:g + hj - 1 + nj, g + hi - 1:g + hi - 1 + ni, g + hk - 1:g + hk - 1 + nk] = P[g:g + nj, g:g + ni, g:g + nk]
+    assert G[g:-g, g:-g, g:-g].tobytes() == ref.P[g:-g, g:-g, g:-g].tobytes()
