@@ -54,6 +54,8 @@ n = args.n
 gsz = [n * div[0], n * div[1], n * div[2]]
 coef = 0.8 if args.solver == "jacobi" else 1.5
 
+if torch.cuda.is_available():
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
 cz = CZ(args.prec, quiet=True, device=local_rank)
 lib = cz.lib
 if world > 1:
