@@ -4,6 +4,8 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+(--solver sor2sma / pbicgstab time the other BASELINE configs the same way: step = one RB-SOR iteration / one BiCGSTAB
+iteration incl. its 2 x 8 preconditioner sweeps; pbicgstab defaults to --prec f64 as in configs[3].)
 A "step" is one relaxed-Jacobi sweep of the FP32 cube with everything the reference's checked loop does per
 iteration (sweep, residual reduction, normalise + history + eps test; cz_Poisson.cpp:39-79), inputs resident in HBM.
 N=1: BASELINE.json configs[1], `cz 512 512 512 jacobi K 0.8`.  N>1: weak scaling, 512^3 cells per GPU
@@ -27,11 +29,14 @@ ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--n", type=int, default=512, help="cells per GPU and axis")
-ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma"])
+ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab"])
+ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "sor2sma"])
 ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
 ap.add_argument("--no-cpu-baseline", action="store_true")
 ap.add_argument("--cpu-seconds", type=float, default=12.0)
 args = ap.parse_args()
+if args.solver == "pbicgstab" and "--prec" not in " ".join(sys.argv):
+    args.prec = "f64"
 
 rank = int(os.environ.get("RANK", "0"))
 world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -52,7 +57,7 @@ if world not in DIVS:
 div = DIVS[world]
 n = args.n
 gsz = [n * div[0], n * div[1], n * div[2]]
-coef = 0.8 if args.solver == "jacobi" else 1.5
+coef = 1.5 if (args.solver == "sor2sma" or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
 
 if torch.cuda.is_available():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -68,7 +73,8 @@ if world > 1:
     dist.broadcast(t, src=0)
     lib.cz_comm_bootstrap(rank, world, bytes(t.numpy().tobytes()))
 
-argv = gsz + [args.solver, args.steps + args.warmup, coef]
+bicg = args.solver == "pbicgstab"
+argv = gsz + [args.solver, (args.warmup + 1) if bicg else (args.steps + args.warmup), coef] + ([args.precond] if bicg else [])
 if world > 1:
     argv += list(div)
 assert cz.setup(argv) == 1, "cz_setup failed"
@@ -85,15 +91,31 @@ def barrier():
         dist.barrier()
 
 
-cz.sweeps(args.warmup)
-barrier()
-cz.timing(True)
-t0 = time.perf_counter()
-cz.sweeps(args.steps)
-barrier()
-dt = time.perf_counter() - t0
-nk, kern_ms = cz.timing_read("jacobi" if args.solver == "jacobi" else "rbsor")
-nk2, kern2_ms = cz.timing_read("jacobi2" if args.solver == "jacobi" else "rbsor2")  # fused: 2 sweeps / both colours per launch
+if bicg:
+    # the Krylov loop has no "continue" entry point: warm up with one solve of W iterations, time a second one of K
+    cz.solve()
+    cz.close()
+    cz = CZ(args.prec, quiet=True, device=local_rank)
+    argv[4] = args.steps + 1
+    assert cz.setup(argv) == 1
+    barrier()
+    cz.timing(True)
+    t0 = time.perf_counter()
+    cz.solve()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert len(cz.history()) == args.steps, "BiCGSTAB converged before the requested number of iterations"
+else:
+    cz.sweeps(args.warmup)
+    barrier()
+    cz.timing(True)
+    t0 = time.perf_counter()
+    cz.sweeps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+_jl = args.solver == "jacobi" or (args.solver == "pbicgstab" and args.precond == "jacobi")
+nk, kern_ms = cz.timing_read("jacobi" if _jl else "rbsor")
+nk2, kern2_ms = cz.timing_read("jacobi2" if _jl else "rbsor2")  # fused: 2 sweeps / both colours per launch
 cz.timing(False)
 
 tot_points = float(my_points)
@@ -109,12 +131,13 @@ if rank == 0:
     word = 4 if args.prec == "f32" else 8
     # algorithmic bytes per lattice update: Jacobi reads p and b once, writes p' once = 3 words;
     # one RB-SOR colour launch updates half the points of the box: 4 words per point and iteration = 2 per launch
-    alg_bytes_per_launch = my_points * word * (3 if args.solver == "jacobi" else 2)
-    kernel_name = "stencil_k<jacobi>" if args.solver == "jacobi" else "stencil_k<rbsor colour>"
-    tkey = f"{args.solver}_{n}_{args.prec}"
+    jac_like = args.solver == "jacobi" or (bicg and args.precond == "jacobi")
+    alg_bytes_per_launch = my_points * word * (3 if jac_like else 2)
+    kernel_name = "stencil_k<jacobi>" if jac_like else "stencil_k<rbsor colour>"
+    tkey = f"{'jacobi' if jac_like else 'sor2sma'}_{n}_{args.prec}"
     if nk2 > nk:  # the dominant kernel is the fused one: 2 Jacobi sweeps (2 x 3 words) or both RB colours (2 x 2 words)
         nk, kern_ms, alg_bytes_per_launch = nk2, kern2_ms, 2 * alg_bytes_per_launch
-        if args.solver == "jacobi":
+        if jac_like:
             kernel_name, tkey = "jacobi2_k<RB=0> (two fused sweeps per launch)", f"jacobi2_{n}_{args.prec}"
         else:
             kernel_name, tkey = "jacobi2_k<RB=1> (both colours of one iteration per launch)", f"rbsor2_{n}_{args.prec}"
@@ -131,9 +154,10 @@ if rank == 0:
             traffic = None
     out = {
         "metric": "MLUPS (lattice updates/s), 512^3 FP32 Jacobi per GPU" if args.solver == "jacobi" and args.prec == "f32" and n == 512
-        else f"MLUPS (lattice updates/s), {n}^3 {args.prec} {args.solver} per GPU",
-        "value": tot_points * args.steps / dt / 1e6,
-        "unit": "MLUPS",
+        else (f"BiCGSTAB iterations/s, {n}^3 {args.prec}, preconditioner {args.precond}" if bicg else
+              f"MLUPS (lattice updates/s), {n}^3 {args.prec} {args.solver} per GPU"),
+        "value": (args.steps / dt) if bicg else tot_points * args.steps / dt / 1e6,
+        "unit": "iterations/s" if bicg else "MLUPS",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -143,7 +167,8 @@ if rank == 0:
         "vs_baseline": None,
         "dtype": args.prec,
         "data": "synthetic (the reference problem: P=0, Dirichlet sin(pi x)sin(pi y) on z faces, RHS=0)",
-        "config": {"workload": f"cz {gsz[0]} {gsz[1]} {gsz[2]} {args.solver} {args.steps} {coef}" + (f" {div[0]} {div[1]} {div[2]}" if world > 1 else ""),
+        "config": {"workload": f"cz {gsz[0]} {gsz[1]} {gsz[2]} {args.solver} {args.steps} {coef}" + (f" {args.precond}" if bicg else "")
+                   + (f" {div[0]} {div[1]} {div[2]}" if world > 1 else ""),
                    "cells_per_gpu": f"{n}^3", "division": list(div), "global_grid": gsz,
                    "step": "one sweep + residual reduction + convergence bookkeeping (cz_Poisson.cpp:39-79)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -152,7 +177,11 @@ if rank == 0:
                      "kernel_avg_ms": kern_avg_s * 1e3, "kernel_launches_timed": nk,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if bicg:
+        out["config"]["step"] = "one BiCGSTAB iteration: 2 x 8 preconditioner sweeps, 2 SpMV, 5 dots, 4 axpy-type updates (cz_Poisson.cpp:373-500)"
+        # 76 words per point and iteration with the Jacobi preconditioner
+        out["roofline"]["iteration_algorithmic_GBps"] = my_points * word * (76 if args.precond == "jacobi" else 92) * args.steps / dt / 1e9
+    if world == 1 and not args.no_cpu_baseline and not bicg:
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--n", str(n), "--solver", args.solver,
                                 "--prec", args.prec, "--seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)
