@@ -365,3 +365,174 @@ void oracle_err_t(const int* sz, const int* idx, const int* gp, double* d, const
         }
       }
 }
+
+/* ==================================================================================================
+ * MAF flavour: the same solvers on a metric-form Laplacian whose six neighbour
+ * weights and diagonal are recomputed at every point from the 1-D coordinate arrays X, Y, Z
+ * (cz_maf.f90, cz_blas.f90:738-1039).  X(-1:sz(1)+2) etc.: X(i) is x[i+1] in C.
+ * ================================================================================================== */
+#define XC(i) x[(i) + 1]
+#define YC(j) y[(j) + 1]
+#define ZC(k) z[(k) + 1]
+
+/* cz_maf.f90:193-221 (identical block in every MAF kernel) */
+#define MAF_COEF                                                 \
+  const REAL XG = (REAL)0.5 * (XC(i + 1) - XC(i - 1));           \
+  const REAL YE = (REAL)0.5 * (YC(j + 1) - YC(j - 1));           \
+  const REAL ZT = (REAL)0.5 * (ZC(k + 1) - ZC(k - 1));           \
+  const REAL XGG = XC(i + 1) - (REAL)2.0 * XC(i) + XC(i - 1);    \
+  const REAL YEE = YC(j + 1) - (REAL)2.0 * YC(j) + YC(j - 1);    \
+  const REAL ZTT = ZC(k + 1) - (REAL)2.0 * ZC(k) + ZC(k - 1);    \
+  const REAL YJA = XG * YE * ZT;                                 \
+  const REAL YJAI = (REAL)1.0 / YJA;                             \
+  const REAL GX = YE * ZT * YJAI;                                \
+  const REAL EY = XG * ZT * YJAI;                                \
+  const REAL TZ = XG * YE * YJAI;                                \
+  const REAL C1 = GX * GX, C2 = EY * EY, C3 = TZ * TZ;           \
+  const REAL C7 = -XGG * C1 * GX;                                \
+  const REAL C8 = -YEE * C2 * EY;                                \
+  const REAL C9 = -ZTT * C3 * TZ
+
+/* ---- jacobi_maf : cz_maf.f90:131-285 */
+void oracle_jacobi_maf_w(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y, const REAL* z,
+                         const REAL* omg_p, const REAL* b, double* res, REAL* wk2, REAL* tmp, double* flop, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL omg = *omg_p;
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  for (int k = -1; k <= sz[2] + 2; k++) tmp[k + 1] = (REAL)0.0; /* :155 */
+  *flop += 66.0 * NPTS;
+#pragma omp parallel
+  {
+#pragma omp for schedule(static) collapse(2) reduction(+ : res1, resw)
+    for (int j = jst; j <= jed; j++)
+      for (int i = ist; i <= ied; i++)
+        for (int k = kst; k <= ked; k++) {
+          const REAL bb = b[IDX(k, i, j)];
+          const REAL pp = p[IDX(k, i, j)];
+          MAF_COEF;
+          const REAL dd = (REAL)2.0 * (C1 + C2 + C3);
+          const REAL rp = (C1 + (REAL)0.5 * C7) * p[IDX(k, i + 1, j)] + (C1 - (REAL)0.5 * C7) * p[IDX(k, i - 1, j)] +
+                          (C2 + (REAL)0.5 * C8) * p[IDX(k, i, j + 1)] + (C2 - (REAL)0.5 * C8) * p[IDX(k, i, j - 1)] +
+                          (C3 + (REAL)0.5 * C9) * p[IDX(k + 1, i, j)] + (C3 - (REAL)0.5 * C9) * p[IDX(k - 1, i, j)] + bb;
+          const REAL dp = (rp / dd - pp) * omg;
+          wk2[IDX(k, i, j)] = pp + dp;
+          const REAL d2 = dp * dp;
+          res1 = res1 + d2; /* non-_SVR build, :233 */
+          resw += (double)d2;
+        }
+#pragma omp for schedule(static) collapse(2)
+    for (int j = jst; j <= jed; j++)
+      for (int i = ist; i <= ied; i++)
+        for (int k = kst; k <= ked; k++) p[IDX(k, i, j)] = wk2[IDX(k, i, j)];
+  }
+  *res = *res + (double)res1;
+  if (res_wide) *res_wide += resw;
+}
+
+void oracle_jacobi_maf(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y, const REAL* z,
+                       const REAL* omg, const REAL* b, double* res, REAL* wk2, REAL* tmp, double* flop) {
+  oracle_jacobi_maf_w(p, sz, idx, gp, x, y, z, omg, b, res, wk2, tmp, flop, NULL);
+}
+
+/* ---- psor2sma_core_maf : cz_maf.f90:301-438 */
+void oracle_psor2sma_core_maf_w(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y,
+                                const REAL* z, const int* ofst, const int* color, const REAL* omg_p, const REAL* b,
+                                double* res, REAL* tmp, double* flop, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  (void)tmp;
+  const int kp = *ofst + *color;
+  const REAL omg = *omg_p;
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  *flop += 66.0 * 0.5 * NPTS;
+#pragma omp parallel for schedule(static) collapse(2) reduction(+ : res1, resw)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst + ((i + j + kp) % 2); k <= ked; k += 2) {
+        const REAL pp = p[IDX(k, i, j)];
+        const REAL bb = b[IDX(k, i, j)];
+        MAF_COEF;
+        const REAL dd = (REAL)2.0 * (C1 + C2 + C3);
+        const REAL rp = (C1 + (REAL)0.5 * C7) * p[IDX(k, i + 1, j)] + (C1 - (REAL)0.5 * C7) * p[IDX(k, i - 1, j)] +
+                        (C2 + (REAL)0.5 * C8) * p[IDX(k, i, j + 1)] + (C2 - (REAL)0.5 * C8) * p[IDX(k, i, j - 1)] +
+                        (C3 + (REAL)0.5 * C9) * p[IDX(k + 1, i, j)] + (C3 - (REAL)0.5 * C9) * p[IDX(k - 1, i, j)] + bb;
+        const REAL dp = (rp / dd - pp) * omg;
+        p[IDX(k, i, j)] = pp + dp;
+        const REAL d2 = dp * dp;
+        res1 = res1 + d2;
+        resw += (double)d2;
+      }
+  *res = *res + (double)res1;
+  if (res_wide) *res_wide += resw;
+}
+
+void oracle_psor2sma_core_maf(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y,
+                              const REAL* z, const int* ofst, const int* color, const REAL* omg, const REAL* b, double* res,
+                              REAL* tmp, double* flop) {
+  oracle_psor2sma_core_maf_w(p, sz, idx, gp, x, y, z, ofst, color, omg, b, res, tmp, flop, NULL);
+}
+
+/* ---- calc_rk_maf : cz_blas.f90:738-832   r = (b + dd*p - sum w*p_nb) * pvt */
+void oracle_calc_rk_maf(REAL* r, const REAL* p, const REAL* b, const int* sz, const int* idx, const int* gp, const REAL* x,
+                        const REAL* y, const REAL* z, const REAL* pvt, double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  *flop += 63.0 * NPTS; /* cz_blas.f90:762-765 */
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        MAF_COEF;
+        r[IDX(k, i, j)] = (b[IDX(k, i, j)] + (REAL)2.0 * (C1 + C2 + C3) * p[IDX(k, i, j)] -
+                           (C1 + (REAL)0.5 * C7) * p[IDX(k, i + 1, j)] - (C1 - (REAL)0.5 * C7) * p[IDX(k, i - 1, j)] -
+                           (C2 + (REAL)0.5 * C8) * p[IDX(k, i, j + 1)] - (C2 - (REAL)0.5 * C8) * p[IDX(k, i, j - 1)] -
+                           (C3 + (REAL)0.5 * C9) * p[IDX(k + 1, i, j)] - (C3 - (REAL)0.5 * C9) * p[IDX(k - 1, i, j)]) *
+                          pvt[IDX(k, i, j)];
+      }
+}
+
+/* ---- calc_ax_maf : cz_blas.f90:845-934   ap = (sum w*p_nb - dd*p) * pvt */
+void oracle_calc_ax_maf(REAL* ap, const REAL* p, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y,
+                        const REAL* z, const REAL* pvt, double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  *flop += 63.0 * NPTS; /* :868-871 */
+#pragma omp parallel for schedule(static) collapse(2)
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        MAF_COEF;
+        ap[IDX(k, i, j)] = ((C1 + (REAL)0.5 * C7) * p[IDX(k, i + 1, j)] + (C1 - (REAL)0.5 * C7) * p[IDX(k, i - 1, j)] +
+                            (C2 + (REAL)0.5 * C8) * p[IDX(k, i, j + 1)] + (C2 - (REAL)0.5 * C8) * p[IDX(k, i, j - 1)] +
+                            (C3 + (REAL)0.5 * C9) * p[IDX(k + 1, i, j)] + (C3 - (REAL)0.5 * C9) * p[IDX(k - 1, i, j)] -
+                            (REAL)2.0 * (C1 + C2 + C3) * p[IDX(k, i, j)]) *
+                           pvt[IDX(k, i, j)];
+      }
+}
+
+/* ---- search_pivot : cz_blas.f90:947-1039   pvt = 1 / max |row entries| */
+void oracle_search_pivot(REAL* pvt, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y, const REAL* z) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+#ifdef CZ_REAL_IS_DOUBLE
+#define R_ABS fabs
+#define R_MAX fmax
+#else
+#define R_ABS fabsf
+#define R_MAX fmaxf
+#endif
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        MAF_COEF;
+        const REAL s1 = R_ABS(C1 + (REAL)0.5 * C7), s2 = R_ABS(C1 - (REAL)0.5 * C7);
+        const REAL s3 = R_ABS(C2 + (REAL)0.5 * C8), s4 = R_ABS(C2 - (REAL)0.5 * C8);
+        const REAL s5 = R_ABS(C3 + (REAL)0.5 * C9), s6 = R_ABS(C3 - (REAL)0.5 * C9);
+        const REAL s7 = R_ABS((REAL)2.0 * (C1 + C2 + C3));
+        const REAL ss = R_MAX(R_MAX(R_MAX(R_MAX(R_MAX(R_MAX(s1, s2), s3), s4), s5), s6), s7);
+        pvt[IDX(k, i, j)] = (REAL)1.0 / ss;
+      }
+}

@@ -173,6 +173,49 @@ class Kernels:
         self._f("blas_calc_rk")(self._rp(r), self._rp(p), self._rp(b), self._ip(sz), self._ip(idx), C.byref(g),
                                 self._rp(cf), C.byref(fl))
 
+    # -- MAF flavour (cz_maf.f90, cz_blas.f90:738-1039); x, y, z: 1-D coordinate arrays of length N+4 (X(-1:N+2))
+    def jacobi_maf(self, p, sz, idx, x, y, z, omg, b, wk2, res=0.0, wide=None):
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        tmp = np.zeros(sz[2] + 4, dtype=self.real)
+        args = [self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(x), self._rp(y), self._rp(z), self._rs(omg),
+                self._rp(b), C.byref(r), self._rp(wk2), self._rp(tmp), C.byref(fl)]
+        if wide is not None:
+            self.lib.oracle_jacobi_maf_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("jacobi_maf")(*args)
+        self.last_flop = fl.value
+        return r.value
+
+    def psor2sma_core_maf(self, p, sz, idx, x, y, z, ofst, color, omg, b, res=0.0, wide=None):
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        r, fl, o, c = C.c_double(res), C.c_double(0.0), C.c_int(ofst), C.c_int(color)
+        tmp = np.zeros(sz[2] + 4, dtype=self.real)
+        args = [self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(x), self._rp(y), self._rp(z), C.byref(o),
+                C.byref(c), self._rs(omg), self._rp(b), C.byref(r), self._rp(tmp), C.byref(fl)]
+        if wide is not None:
+            self.lib.oracle_psor2sma_core_maf_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("psor2sma_core_maf")(*args)
+        self.last_flop = fl.value
+        return r.value
+
+    def calc_rk_maf(self, r, p, b, sz, idx, x, y, z, pvt):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self._f("calc_rk_maf")(self._rp(r), self._rp(p), self._rp(b), self._ip(sz), self._ip(idx), C.byref(g), self._rp(x),
+                               self._rp(y), self._rp(z), self._rp(pvt), C.byref(fl))
+        self.last_flop = fl.value
+
+    def calc_ax_maf(self, ap, p, sz, idx, x, y, z, pvt):
+        sz, idx, g, fl = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_double(0.0)
+        self._f("calc_ax_maf")(self._rp(ap), self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(x), self._rp(y),
+                               self._rp(z), self._rp(pvt), C.byref(fl))
+        self.last_flop = fl.value
+
+    def search_pivot(self, pvt, sz, idx, x, y, z):
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        self._f("search_pivot")(self._rp(pvt), self._ip(sz), self._ip(idx), C.byref(g), self._rp(x), self._rp(y), self._rp(z))
+
     def exact_t(self, sz, e, dh, org):
         sz, g = _ia(sz), C.c_int(GUIDE)
         org = np.ascontiguousarray(org, dtype=self.real)
@@ -243,19 +286,24 @@ class CZ:
         self.res_normal = 1.0 / npts
         k = self.k
         self.P, self.RHS, self.WRK = k.alloc(self.size), k.alloc(self.size), k.alloc(self.size)
+        # 1-D grid (cz_Evaluate.cpp:342-363) and pivot array (:369) for the MAF flavours
+        self.xc, self.yc, self.zc = (np.array([R(i - 1) * self.pitch for i in range(n + 2 * GUIDE)], dtype=R) for n in self.size)
+        self.pvt = k.alloc(self.size)
+        k.search_pivot(self.pvt, self.size, self.idx, self.xc, self.yc, self.zc)
         k.bc_k(self.size, self.P, self.pitch, self.origin, self.nID)
         k.bc_k(self.size, self.RHS, self.pitch, self.origin, self.nID)
 
     # cz_Poisson.cpp:30-82
-    def JACOBI(self, X, B, itr_max, converge_check=True):
+    def JACOBI(self, X, B, itr_max, converge_check=True, maf=False):
         k, res, itr = self.k, 0.0, 1
         while itr <= itr_max:
-            if self.wide:
-                w = np.zeros(1)
-                k.jacobi(X, self.size, self.idx, self.cf, self.ac1, B, self.WRK, res=0.0, wide=w)
-                res = float(w[0])
+            w = np.zeros(1) if self.wide else None
+            if maf:  # cz_Poisson.cpp:45-53
+                res = k.jacobi_maf(X, self.size, self.idx, self.xc, self.yc, self.zc, self.ac1, B, self.WRK, res=0.0, wide=w)
             else:
-                res = k.jacobi(X, self.size, self.idx, self.cf, self.ac1, B, self.WRK, res=0.0)
+                res = k.jacobi(X, self.size, self.idx, self.cf, self.ac1, B, self.WRK, res=0.0, wide=w)
+            if self.wide:
+                res = float(w[0])
             if converge_check:
                 res = math.sqrt(res * self.res_normal)
                 self.history.append((itr, res))
@@ -266,14 +314,18 @@ class CZ:
         return itr, res
 
     # cz_Poisson.cpp:159-235
-    def RBSOR(self, X, B, itr_max, converge_check=True):
+    def RBSOR(self, X, B, itr_max, converge_check=True, maf=False):
         k, res, itr = self.k, 0.0, 1
         ip = 0  # numProc == 1 (:183-186)
         while itr <= itr_max:
             res = 0.0
             w = np.zeros(1) if self.wide else None
             for color in (0, 1):
-                res = k.psor2sma_core(X, self.size, self.idx, self.cf, ip, color, self.ac1, B, res=res, wide=w)
+                if maf:  # cz_Poisson.cpp:190-200
+                    res = k.psor2sma_core_maf(X, self.size, self.idx, self.xc, self.yc, self.zc, ip, color, self.ac1, B, res=res,
+                                              wide=w)
+                else:
+                    res = k.psor2sma_core(X, self.size, self.idx, self.cf, ip, color, self.ac1, B, res=res, wide=w)
             if self.wide:
                 res = float(w[0])
             if converge_check:
@@ -287,16 +339,23 @@ class CZ:
 
     # cz_Poisson.cpp:273-322
     def Preconditioner(self, xx, bb, pc):
-        if pc == "jacobi":
-            self.JACOBI(xx, bb, LC_MAX, converge_check=False)
-        elif pc == "sor2sma":
-            self.RBSOR(xx, bb, LC_MAX, converge_check=False)
+        if pc in ("jacobi", "jacobi_maf"):
+            self.JACOBI(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
+        elif pc in ("sor2sma", "sor2sma_maf"):
+            self.RBSOR(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
         else:
             self.k.blas_copy(xx, bb, self.size)
 
     # cz_Poisson.cpp:332-504
-    def PBiCGSTAB(self, X, B, ItrMax, pc):
+    def PBiCGSTAB(self, X, B, ItrMax, pc, maf=False):
         k, R, sz, idx = self.k, self.R, self.size, self.idx
+
+        def calc_ax(ap, p):  # cz_Poisson.cpp:415-422
+            if maf:
+                k.calc_ax_maf(ap, p, sz, idx, self.xc, self.yc, self.zc, self.pvt)
+            else:
+                k.blas_calc_ax(ap, p, sz, idx, self.cf)
+
         if self.wide:
             def dot1(x):
                 w = np.zeros(1)
@@ -316,7 +375,10 @@ class CZ:
         a = {n: k.alloc(sz) for n in ("p", "p_", "r", "r0", "q", "s", "s_", "t_")}
         res = 0.0
         k.blas_clear(a["q"], sz)
-        k.blas_calc_rk(a["r"], X, B, sz, idx, self.cf)
+        if maf:  # cz_Poisson.cpp:350-353
+            k.calc_rk_maf(a["r"], X, B, sz, idx, self.xc, self.yc, self.zc, self.pvt)
+        else:
+            k.blas_calc_rk(a["r"], X, B, sz, idx, self.cf)
         k.blas_copy(a["r0"], a["r"], sz)
         rho_old, alpha, omega = R(1.0), R(0.0), R(1.0)
         itr = 1
@@ -332,12 +394,12 @@ class CZ:
                 k.blas_bicg_1(a["p"], a["r"], a["q"], beta, omega, sz, idx)
             k.blas_clear(a["p_"], sz)
             self.Preconditioner(a["p_"], a["p"], pc)
-            k.blas_calc_ax(a["q"], a["p_"], sz, idx, self.cf)
+            calc_ax(a["q"], a["p_"])
             alpha = R(rho / dot2(a["q"], a["r0"]))  # :427
             k.blas_triad(a["s"], a["q"], a["r"], R(-alpha), sz, idx)
             k.blas_clear(a["s_"], sz)
             self.Preconditioner(a["s_"], a["s"], pc)
-            k.blas_calc_ax(a["t_"], a["s_"], sz, idx, self.cf)
+            calc_ax(a["t_"], a["s_"])
             omega = R(dot2(a["t_"], a["s"]) / dot1(a["t_"]))  # :464
             k.blas_bicg_2(X, a["p_"], a["s_"], alpha, omega, sz, idx)
             k.blas_triad(a["r"], a["t_"], a["s"], R(-omega), sz, idx)
@@ -362,12 +424,12 @@ def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", wit
     """``cz gsz_x gsz_y gsz_z solver ItrMax coef [precond]`` on the chosen back-end, one thread semantics."""
     cz = CZ(Kernels(kind, prec), wide=wide)
     cz.setup(gsz, coef)
-    if solver == "jacobi":
-        itr, res = cz.JACOBI(cz.P, cz.RHS, itr_max)
-    elif solver == "sor2sma":
-        itr, res = cz.RBSOR(cz.P, cz.RHS, itr_max)
-    elif solver == "pbicgstab":
-        itr, res = cz.PBiCGSTAB(cz.P, cz.RHS, itr_max, precond or "none")
+    if solver in ("jacobi", "jacobi_maf"):
+        itr, res = cz.JACOBI(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
+    elif solver in ("sor2sma", "sor2sma_maf"):
+        itr, res = cz.RBSOR(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
+    elif solver in ("pbicgstab", "pbicgstab_maf"):
+        itr, res = cz.PBiCGSTAB(cz.P, cz.RHS, itr_max, precond or "none", maf=solver.endswith("_maf"))
     else:
         raise ValueError(solver)
     out = Result(itr=itr, res=res, history=cz.history, P=cz.P)

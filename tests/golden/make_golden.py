@@ -2,7 +2,7 @@
 """Generate the golden fixtures in this directory from the REFERENCE itself.
 
 Runs only in the build container: it needs oracle/_ref/libczref_{f32,f64}.so, i.e. the
-reference's own Fortran kernels (cz_solver.f90, cz_blas.f90, cz_utility.f90) compiled in
+reference's own Fortran kernels (cz_solver.f90, cz_blas.f90, cz_utility.f90, cz_maf.f90) compiled in
 place by oracle/Makefile with amdflang, called with OMP_NUM_THREADS=1 (the deterministic
 mode, SURVEY.md finding 2).  Fixtures are DATA (inputs + expected outputs), committed so the
 tests can run where /root/reference does not exist.
@@ -101,6 +101,34 @@ def kernel_vectors(prec):
     e = np.zeros_like(p)
     k.exact_t(sz, e, 1.0 / (BOX[2] - 1), [0.0, 0.0, 0.0])
     out["exact"] = e
+    # MAF flavour (cz_maf.f90, cz_blas.f90:738-1039) on a stretched grid: monotone random coordinates so that the
+    # second-difference terms (XGG, YEE, ZTT) are exercised, which the uniform benchmark grid leaves at rounding level
+    def coords(n):
+        return np.cumsum(rng.uniform(0.5, 1.5, n + 4)).astype(R) * R(0.05)
+
+    xc, yc, zc = coords(BOX[0]), coords(BOX[1]), coords(BOX[2])
+    out.update(maf_x=xc, maf_y=yc, maf_z=zc)
+    pv = rnd()
+    out["maf_pvt_in"] = pv.copy()
+    k.search_pivot(pv, sz, idx, xc, yc, zc)
+    out["maf_pvt"] = pv
+    pm_, wm = p.copy(), np.zeros_like(p)
+    out["maf_jacobi_res"] = np.array(k.jacobi_maf(pm_, sz, idx, xc, yc, zc, OMG, b, wm, res=0.5))
+    out["maf_jacobi_p"], out["maf_jacobi_wk2"], out["maf_jacobi_flop"] = pm_, wm, np.array(k.last_flop)
+    for ofst in (0, 1):
+        ps, r = p.copy(), 0.0
+        for color in (0, 1):
+            r = k.psor2sma_core_maf(ps, sz, idx, xc, yc, zc, ofst, color, OMG, b, res=r)
+            out[f"maf_rb{ofst}_p_c{color}"] = ps.copy()
+            out[f"maf_rb{ofst}_res_c{color}"] = np.array(r)
+    apm = rnd()
+    out["maf_ax_in"] = apm.copy()
+    k.calc_ax_maf(apm, p, sz, idx, xc, yc, zc, pv)
+    out["maf_ax"] = apm
+    rkm = rnd()
+    out["maf_rk_in"] = rkm.copy()
+    k.calc_rk_maf(rkm, p, b, sz, idx, xc, yc, zc, pv)
+    out["maf_rk"] = rkm
     np.savez_compressed(os.path.join(HERE, f"kernels_{prec}.npz"), **out)
 
 
@@ -124,6 +152,14 @@ SOLVER_CASES = [
     ((20, 24, 28), "sor2sma", 40, 1.2, None, "f32", None),
     ((24, 20, 36), "pbicgstab", 60, 0.9, "sor2sma", "f64", None),
     ((24, 20, 36), "pbicgstab", 60, 0.9, "none", "f64", None),
+    # MAF flavour (no CLI pin)
+    ((32, 32, 32), "jacobi_maf", 40, 0.8, None, "f32", None),
+    ((24, 20, 28), "jacobi_maf", 30, 0.8, None, "f64", None),
+    ((32, 32, 32), "sor2sma_maf", 40, 1.5, None, "f32", None),
+    ((24, 20, 28), "sor2sma_maf", 30, 1.5, None, "f64", None),
+    ((32, 32, 32), "pbicgstab_maf", 100, 0.8, "jacobi_maf", "f64", None),
+    ((32, 32, 32), "pbicgstab_maf", 100, 1.5, "sor2sma_maf", "f64", None),
+    ((32, 32, 32), "pbicgstab_maf", 100, 0.8, "jacobi", "f32", None),
 ]
 
 

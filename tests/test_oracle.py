@@ -68,6 +68,27 @@ def test_kernels_match_golden(prec):
     k.exact_t(sz, e, 1.0 / (sz[2] - 1), [0.0, 0.0, 0.0])
     assert _beq(e, g["exact"])
 
+    # MAF flavour on the stretched grid
+    xc, yc, zc = g["maf_x"], g["maf_y"], g["maf_z"]
+    pv = g["maf_pvt_in"].copy()
+    k.search_pivot(pv, sz, idx, xc, yc, zc)
+    assert _beq(pv, g["maf_pvt"])
+    pm, wm = p.copy(), np.zeros_like(p)
+    res = k.jacobi_maf(pm, sz, idx, xc, yc, zc, omg, b, wm, res=0.5)
+    assert _beq(pm, g["maf_jacobi_p"]) and _beq(wm, g["maf_jacobi_wk2"])
+    assert res == float(g["maf_jacobi_res"]) and k.last_flop == float(g["maf_jacobi_flop"])
+    for ofst in (0, 1):
+        ps, r = p.copy(), 0.0
+        for color in (0, 1):
+            r = k.psor2sma_core_maf(ps, sz, idx, xc, yc, zc, ofst, color, omg, b, res=r)
+            assert _beq(ps, g[f"maf_rb{ofst}_p_c{color}"]) and r == float(g[f"maf_rb{ofst}_res_c{color}"])
+    a = g["maf_ax_in"].copy()
+    k.calc_ax_maf(a, p, sz, idx, xc, yc, zc, pv)
+    assert _beq(a, g["maf_ax"])
+    a = g["maf_rk_in"].copy()
+    k.calc_rk_maf(a, p, b, sz, idx, xc, yc, zc, pv)
+    assert _beq(a, g["maf_rk"])
+
 
 def test_wide_accumulators_consistent():
     """the *_w entry points return the same REAL result plus a double accumulation of the same terms."""
