@@ -29,6 +29,17 @@ void calc_ax_async(CZ_REAL* ap, const CZ_REAL* p, const int* sz, const int* idx,
 void calc_rk_async(CZ_REAL* r, const CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf);
 void dot1_async(const CZ_REAL* p, const int* sz, const int* idx, int g, double* dst_dev);
 void dot2_async(const CZ_REAL* p, const CZ_REAL* q, const int* sz, const int* idx, int g, double* dst_dev);
+void jacobi_maf_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* xc,
+                      const CZ_REAL* yc, const CZ_REAL* zc, CZ_REAL omg, double* res_dev, const int* skip, int check, double res_normal,
+                      double eps, int itr, double* hist, int* flag, int* conv_itr);
+void rbsor_maf_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* xc, const CZ_REAL* yc,
+                     const CZ_REAL* zc, int ofst, int color, CZ_REAL omg, double* res_dev, int accumulate, const int* skip, int check,
+                     double res_normal, double eps, int itr, double* hist, int* flag, int* conv_itr);
+void calc_ax_maf_async(CZ_REAL* ap, const CZ_REAL* p, const int* sz, const int* idx, int g, const CZ_REAL* xc, const CZ_REAL* yc,
+                       const CZ_REAL* zc, const CZ_REAL* pvt);
+void calc_rk_maf_async(CZ_REAL* r, const CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* xc,
+                       const CZ_REAL* yc, const CZ_REAL* zc, const CZ_REAL* pvt);
+void search_pivot_async(CZ_REAL* pvt, const int* sz, const int* idx, int g, const CZ_REAL* xc, const CZ_REAL* yc, const CZ_REAL* zc);
 void copy_shell_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
 void copy_inner_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
 void bc_async(const int* sz, int g, CZ_REAL* p, CZ_REAL dh, const CZ_REAL* org, const int* nID, int ioff = 0, int joff = 0);

@@ -46,6 +46,7 @@ struct Coef {
 
 // Geometry of one launch, all in PADDED 0-based indices (kk = k+g-1, ...).
 struct Geom {
+  int nip;          // padded rows per plane = NI+2g
   int R;            // vectors per k-row = (NK+2g)/V
   long long PSV;    // vectors per plane = R*(NI+2g)
   int kk0, kk1;     // inner k range (inclusive)
@@ -124,6 +125,39 @@ __device__ __forceinline__ double block_sum(double x, double* wsum /* TB/64 doub
   return s;  // valid on thread 0
 }
 
+// MAF flavour (cz_maf.f90, cz_blas.f90:738-1039): the six neighbour weights and the diagonal are
+// recomputed at every point from 1-D coordinate arrays (device copies of xc, yc, zc; X(i) of the Fortran is xc[i+1], which
+// for g = 2 is xc[padded index]).  pvt: row scaling of calc_ax_maf / calc_rk_maf.
+struct MafArgs {
+  const REAL* xc;
+  const REAL* yc;
+  const REAL* zc;
+  const REAL* pvt;
+};
+
+struct MafW {
+  REAL w1, w2, w3, w4, w5, w6, dd;  // weights of p(i+1), p(i-1), p(j+1), p(j-1), p(k+1), p(k-1); dd = 2(C1+C2+C3)
+};
+
+// cz_maf.f90:193-221, operation for operation
+__device__ __forceinline__ MafW maf_weights(REAL XG, REAL XGG, REAL YE, REAL YEE, REAL ZT, REAL ZTT) {
+  const REAL YJA = XG * YE * ZT;
+  const REAL YJAI = (REAL)1.0 / YJA;
+  const REAL GX = YE * ZT * YJAI;
+  const REAL EY = XG * ZT * YJAI;
+  const REAL TZ = XG * YE * YJAI;
+  const REAL C1 = GX * GX, C2 = EY * EY, C3 = TZ * TZ;
+  const REAL C7 = -XGG * C1 * GX;
+  const REAL C8 = -YEE * C2 * EY;
+  const REAL C9 = -ZTT * C3 * TZ;
+  MafW w;
+  w.w1 = C1 + (REAL)0.5 * C7, w.w2 = C1 - (REAL)0.5 * C7;
+  w.w3 = C2 + (REAL)0.5 * C8, w.w4 = C2 - (REAL)0.5 * C8;
+  w.w5 = C3 + (REAL)0.5 * C9, w.w6 = C3 - (REAL)0.5 * C9;
+  w.dd = (REAL)2.0 * (C1 + C2 + C3);
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // The 7-point sweep.  MODE selects the point update:
 //   JACOBI  cz_solver.f90:334-351   out = p + ((ss-b)/dd - p)*omg , acc += dp*dp
@@ -133,10 +167,12 @@ __device__ __forceinline__ double block_sum(double x, double* wsum /* TB/64 doub
 // with ss = c1*p(i+1) + c2*p(i-1) + c3*p(j+1) + c4*p(j-1) + c5*p(k+1) + c6*p(k-1), left to right.
 // Elements outside the inner box are never written.
 // ------------------------------------------------------------------------------------------------------------
-template <int V, int TB, int M, int PF, int MODE>
+// MAF = 1: the weights come from maf_weights() instead of c (cz_maf.f90:131-438, cz_blas.f90:738-934):
+//   JACOBI/RB  dp = ((sum w*p_nb + b)/dd - p)*omg      AX  out = (sum w*p_nb - dd*p)*pvt      RK  out = (b + dd*p - sum w*p_nb)*pvt
+template <int V, int TB, int M, int PF, int MODE, int MAF>
 __global__ void __launch_bounds__(TB)
 stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, double* partials,
-          const int* __restrict__ skip, Fin fin) {
+          const int* __restrict__ skip, Fin fin, MafArgs ma) {
   if (skip != nullptr && *skip != 0) return;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -167,6 +203,8 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
     long long f[M];
     unsigned mk[M];   // bit c set: component c is an inner point (k range, valid row)
     int pbase[M];     // (kk + ii + par) & 1 of component 0 (MODE_RB)
+    REAL XG[MAF ? M : 1], XGG[MAF ? M : 1];   // MAF: metric terms of the row ...
+    Vec<V> ZT[MAF ? M : 1], ZTT[MAF ? M : 1];  // ... and of each k component
     const long long lim_ld = g.Fend + R;  // vectors below this exist in the plane (row ii1+1 is a halo row)
 #pragma unroll
     for (int m = 0; m < M; m++) {
@@ -183,6 +221,24 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
       }
       mk[m] = bits;
       pbase[m] = (kv * V + (int)row + par) & 1;
+      if (MAF) {
+        const int nkp = R * V;
+        int ii = (int)row;  // padded row index == index into xc for g = 2
+        if (ii < 1) ii = 1;
+        if (ii > g.nip - 2) ii = g.nip - 2;
+        const REAL xm = ma.xc[ii - 1], x0 = ma.xc[ii], xp = ma.xc[ii + 1];
+        XG[m] = (REAL)0.5 * (xp - xm);
+        XGG[m] = xp - (REAL)2.0 * x0 + xm;
+#pragma unroll
+        for (int cc = 0; cc < V; cc++) {
+          int kk = kv * V + cc;
+          if (kk < 1) kk = 1;
+          if (kk > nkp - 2) kk = nkp - 2;
+          const REAL zm = ma.zc[kk - 1], z0 = ma.zc[kk], zp = ma.zc[kk + 1];
+          ZT[m].v[cc] = (REAL)0.5 * (zp - zm);
+          ZTT[m].v[cc] = zp - (REAL)2.0 * z0 + zm;
+        }
+      }
     }
 
     Vec<V> pm[M], pc[M], pn[M], bb[M];
@@ -254,6 +310,12 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
       const Vec<V>* buf = ldsv + (size_t)cur * L;
       const REAL* buff = ldsf + (size_t)cur * L * V;
       REAL* Oc = OUT + (long long)jj * g.PSV * V;
+      REAL YE = (REAL)0, YEE = (REAL)0;
+      if (MAF) {
+        const REAL ym = ma.yc[jj - 1], y0 = ma.yc[jj], yp = ma.yc[jj + 1];
+        YE = (REAL)0.5 * (yp - ym);
+        YEE = yp - (REAL)2.0 * y0 + ym;
+      }
 #pragma unroll
       for (int m = 0; m < M; m++) {
         if (mk[m] == 0) continue;
@@ -264,6 +326,8 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
         const REAL kr = buff[(R + li) * V + V];
         Vec<V> o;
         unsigned wmask = mk[m];
+        Vec<V> pv;
+        if (MAF && (MODE == MODE_AX || MODE == MODE_RK)) pv = ldv<V>(ma.pvt + (long long)jj * g.PSV * V, f[m]);
         if (MODE == MODE_RB) {
           // colour: (kk + ii + jj + par) even
           unsigned cm = 0;
@@ -277,6 +341,24 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
           const REAL pp = pc[m].v[cc];
           const REAL km1 = (cc == 0) ? kl : pc[m].v[cc > 0 ? cc - 1 : 0];
           const REAL kp1 = (cc == V - 1) ? kr : pc[m].v[cc < V - 1 ? cc + 1 : V - 1];
+          if (MAF) {
+            const MafW w = maf_weights(XG[m], XGG[m], YE, YEE, ZT[m].v[cc], ZTT[m].v[cc]);
+            if (MODE == MODE_JACOBI || MODE == MODE_RB) {
+              const REAL rp = w.w1 * ip.v[cc] + w.w2 * im.v[cc] + w.w3 * pn[m].v[cc] + w.w4 * pm[m].v[cc] + w.w5 * kp1 +
+                              w.w6 * km1 + bb[m].v[cc];  // cz_maf.f90:219-225
+              const REAL dp = (rp / w.dd - pp) * c.omg;
+              o.v[cc] = pp + dp;
+              const REAL d2 = dp * dp;
+              if (wmask & (1u << cc)) acc += (double)d2;
+            } else if (MODE == MODE_AX) {  // cz_blas.f90:916-924
+              o.v[cc] = (w.w1 * ip.v[cc] + w.w2 * im.v[cc] + w.w3 * pn[m].v[cc] + w.w4 * pm[m].v[cc] + w.w5 * kp1 + w.w6 * km1 -
+                         w.dd * pp) * pv.v[cc];
+            } else {  // cz_blas.f90:811-820
+              o.v[cc] = (bb[m].v[cc] + w.dd * pp - w.w1 * ip.v[cc] - w.w2 * im.v[cc] - w.w3 * pn[m].v[cc] - w.w4 * pm[m].v[cc] -
+                         w.w5 * kp1 - w.w6 * km1) * pv.v[cc];
+            }
+            continue;
+          }
           const REAL ss = c.c1 * ip.v[cc] + c.c2 * im.v[cc] + c.c3 * pn[m].v[cc] + c.c4 * pm[m].v[cc] + c.c5 * kp1 +
                           c.c6 * km1;
           if (MODE == MODE_JACOBI || MODE == MODE_RB) {
@@ -782,6 +864,39 @@ ewise_k(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL b, EGeom g) {
   }
 }
 
+// search_pivot (cz_blas.f90:947-1039): pvt = 1 / max(|row entries|) on the inner box
+template <int V>
+__global__ void __launch_bounds__(256)
+pivot_k(REAL* PVT, EGeom g, MafArgs ma, int nkp, int nip) {
+  const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
+  if (f >= g.Fend) return;
+  const int jj = g.jj0 + blockIdx.y;
+  const long long pv = (long long)jj * g.PSV + f;
+  const long long row = f / g.R;
+  const int kv = (int)(f - row * g.R);
+  const int ii = (int)row;
+  const REAL xm = ma.xc[ii - 1], x0 = ma.xc[ii], xp = ma.xc[ii + 1];
+  const REAL ym = ma.yc[jj - 1], y0 = ma.yc[jj], yp = ma.yc[jj + 1];
+  const REAL XG = (REAL)0.5 * (xp - xm), XGG = xp - (REAL)2.0 * x0 + xm;
+  const REAL YE = (REAL)0.5 * (yp - ym), YEE = yp - (REAL)2.0 * y0 + ym;
+#pragma unroll
+  for (int cc = 0; cc < V; cc++) {
+    const int kk = kv * V + cc;
+    if (kk < g.kk0 || kk > g.kk1) continue;
+    const REAL zm = ma.zc[kk - 1], z0 = ma.zc[kk], zp = ma.zc[kk + 1];
+    const MafW w = maf_weights(XG, XGG, YE, YEE, (REAL)0.5 * (zp - zm), zp - (REAL)2.0 * z0 + zm);
+    REAL ss = fmax(fabs(w.w1), fabs(w.w2));  // max(s1..s7), left to right (cz_blas.f90:1024)
+    ss = fmax(ss, fabs(w.w3));
+    ss = fmax(ss, fabs(w.w4));
+    ss = fmax(ss, fabs(w.w5));
+    ss = fmax(ss, fabs(w.w6));
+    ss = fmax(ss, fabs(w.dd));
+    PVT[pv * V + cc] = (REAL)1.0 / ss;
+  }
+  (void)nkp;
+  (void)nip;
+}
+
 // dot products (cz_blas.f90:361-362, :426): per-point product in REAL, accumulated in double.
 template <int V, int TWO>
 __global__ void __launch_bounds__(256)
@@ -867,6 +982,8 @@ struct Ctx {
   double* partials = nullptr;   // device
   size_t partials_cap = 0;
   unsigned* counter = nullptr;  // arrival ticket of the in-kernel finalisation
+  REAL* xyz = nullptr;           // device copies of the host coordinate arrays X, Y, Z handed to the *_maf_ drop-in symbols
+  size_t xyz_cap = 0;
   double* scal_dev = nullptr;   // a few device doubles for the synchronous entry points
   double* scal_host = nullptr;  // pinned
   Tuning tune;
@@ -961,10 +1078,11 @@ EGeom make_egeom(const Box& b) {
   return e;
 }
 
-template <int V, int TB, int M, int PF, int MODE>
+template <int V, int TB, int M, int PF, int MODE, int MAF = 0>
 void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, const Box& b, int par, int tj_req,
-                         const int* skip, int* nblk_out, const Fin& fin) {
+                         const int* skip, int* nblk_out, const Fin& fin, const MafArgs& ma = MafArgs()) {
   Geom g;
+  g.nip = b.nip;
   g.R = b.nkp / V;
   g.PSV = (long long)g.R * b.nip;
   g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
@@ -999,14 +1117,14 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
   if (MODE == MODE_JACOBI || MODE == MODE_RB) ensure_partials((size_t)nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil_k<V, TB, M, PF, MODE>),
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil_k<V, TB, M, PF, MODE, MAF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   {
     ScopedTimer tm(MODE == MODE_JACOBI ? LBL_JACOBI : MODE == MODE_RB ? LBL_RBSOR : MODE == MODE_AX ? LBL_AX : LBL_RK);
-    hipLaunchKernelGGL((stencil_k<V, TB, M, PF, MODE>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, P, B, OUT, c, g, par,
-                       ctx.partials, skip, fin);
+    hipLaunchKernelGGL((stencil_k<V, TB, M, PF, MODE, MAF>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, P, B, OUT, c, g, par,
+                       ctx.partials, skip, fin, ma);
   }
   HIP_CHECK(hipGetLastError());
   if (nblk_out) *nblk_out = (int)nblk;
@@ -1032,6 +1150,23 @@ void launch_stencil(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, cons
   }
 #undef CZ_INST
   launch_stencil_inst<VW, 512, 2, 0, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out, fin);
+}
+
+// MAF flavour: one tuned shape (and the scalar fallback); coordinates / pvt are device pointers
+template <int MODE>
+void launch_stencil_maf(const REAL* P, const REAL* B, REAL* OUT, REAL omg, const Box& b, int par, const int* skip, int* nblk_out,
+                        const Fin& fin, const MafArgs& ma) {
+  if (b.g != 2) {
+    fprintf(stderr, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2), cz_maf.f90:146-148)\n");
+    exit(1);
+  }
+  Coef c;
+  c.c1 = c.c2 = c.c3 = c.c4 = c.c5 = c.c6 = c.dd = (REAL)0;
+  c.omg = omg;
+  if (vec_ok(b, {P, B, OUT, ma.pvt}))
+    launch_stencil_inst<VW, 512, 2, 0, MODE, 1>(P, B, OUT, c, b, par, ctx.tune.tj, skip, nblk_out, fin, ma);
+  else
+    launch_stencil_inst<1, 256, 2, 0, MODE, 1>(P, B, OUT, c, b, par, ctx.tune.tj, skip, nblk_out, fin, ma);
 }
 
 void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
@@ -1103,6 +1238,13 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   CZ_INST2(256, 4) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(1024, 2)
 #undef CZ_INST2
   return launch_jacobi2_inst<512, 2, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par);
+}
+
+Coef make_coef_omg(REAL omg) {
+  Coef c;
+  c.c1 = c.c2 = c.c3 = c.c4 = c.c5 = c.c6 = c.dd = (REAL)0;
+  c.omg = omg;
+  return c;
 }
 
 Coef make_coef(const REAL* cf, REAL omg) {
@@ -1212,16 +1354,18 @@ struct CheckArgs {
 };
 template <int MODE>
 void sweep_async(const REAL* p_in, REAL* p_out, const REAL* b, const Box& bx, const Coef& cf, int par, double* res_dev,
-                 int accumulate, const int* skip, const CheckArgs& ck) {
+                 int accumulate, const int* skip, const CheckArgs& ck, const MafArgs* ma = nullptr) {
   int nblk = 0;
   if (ctx.tune.fuse_fin) {
     Fin fin;
     fin.dst = res_dev, fin.accumulate = accumulate, fin.counter = ctx.counter;
     fin.do_check = ck.enabled, fin.itr = ck.itr, fin.res_normal = ck.res_normal, fin.eps = ck.eps;
     fin.hist = ck.hist, fin.flag = ck.flag, fin.conv_itr = ck.conv_itr;
-    launch_stencil<MODE>(p_in, b, p_out, cf, bx, par, skip, &nblk, fin);
+    if (ma) launch_stencil_maf<MODE>(p_in, b, p_out, cf.omg, bx, par, skip, &nblk, fin, *ma);
+    else launch_stencil<MODE>(p_in, b, p_out, cf, bx, par, skip, &nblk, fin);
   } else {
-    launch_stencil<MODE>(p_in, b, p_out, cf, bx, par, skip, &nblk);
+    if (ma) launch_stencil_maf<MODE>(p_in, b, p_out, cf.omg, bx, par, skip, &nblk, Fin(), *ma);
+    else launch_stencil<MODE>(p_in, b, p_out, cf, bx, par, skip, &nblk);
     reduce_partials(nblk, res_dev, accumulate, skip);
     if (ck.enabled) czhip_check_async(res_dev, ck.res_normal, ck.eps, ck.itr, ck.hist, ck.flag, ck.conv_itr);
   }
@@ -1233,6 +1377,43 @@ static inline int rb_parity(int g, const int* idx, int ofst, int color) {
   // padded 0-based indices shift each of k,i,j by g-1
   return (3 * (g - 1) + idx[4] + ofst + color) & 1;
 }
+
+namespace {
+// device copies of the reference's host-resident 1-D coordinate arrays (cz_Evaluate.cpp:342-363 fills them on the host)
+MafArgs upload_xyz(const int* sz, int g, const REAL* X, const REAL* Y, const REAL* Z, const REAL* pvt) {
+  const size_t nx = sz[0] + 2 * g, ny = sz[1] + 2 * g, nz = sz[2] + 2 * g, tot = nx + ny + nz;
+  if (tot > ctx.xyz_cap) {
+    if (ctx.xyz) {
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      HIP_CHECK(hipFree(ctx.xyz));
+    }
+    HIP_CHECK(hipMalloc(&ctx.xyz, tot * sizeof(REAL)));
+    ctx.xyz_cap = tot;
+  }
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));  // the previous call may still read the old copy
+  HIP_CHECK(hipMemcpy(ctx.xyz, X, nx * sizeof(REAL), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(ctx.xyz + nx, Y, ny * sizeof(REAL), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMemcpy(ctx.xyz + nx + ny, Z, nz * sizeof(REAL), hipMemcpyHostToDevice));
+  MafArgs ma;
+  ma.xc = ctx.xyz, ma.yc = ctx.xyz + nx, ma.zc = ctx.xyz + nx + ny, ma.pvt = pvt;
+  return ma;
+}
+
+void launch_pivot(REAL* pvt, const Box& b, const MafArgs& ma) {
+  if (b.empty) return;
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  if (vec_ok(b, {pvt})) {
+    EGeom e = make_egeom<VW>(b);
+    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
+    hipLaunchKernelGGL((pivot_k<VW>), grid, dim3(256), 0, ctx.stream, pvt, e, ma, b.nkp, b.nip);
+  } else {
+    EGeom e = make_egeom<1>(b);
+    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
+    hipLaunchKernelGGL((pivot_k<1>), grid, dim3(256), 0, ctx.stream, pvt, e, ma, b.nkp, b.nip);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+}  // namespace
 
 // ============================================================================================================
 // Part 2: runtime
@@ -1617,6 +1798,64 @@ void blas_calc_rk_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g
   HIP_CHECK(hipStreamSynchronize(ctx.stream));
 }
 
+// ---- MAF flavour, drop-in symbols (cz_Ffunc.h:170-208, 524-553).  X, Y, Z are HOST arrays as in the reference.
+void jacobi_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, CZ_REAL* omg, CZ_REAL* b, double* res,
+                 CZ_REAL* wk2, CZ_REAL* tmp, double* flop) {
+  ensure_init();
+  *flop += 66.0 * npts(idx);                                    // cz_maf.f90:157-160
+  for (int k = 0; k < sz[2] + 2 * *g; k++) tmp[k] = (REAL)0;    // :155 (host work array; only used by the _SVR build)
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  const MafArgs ma = upload_xyz(sz, *g, X, Y, Z, nullptr);
+  sweep_async<MODE_JACOBI>(p, wk2, b, bx, make_coef_omg(*omg), 0, ctx.scal_dev + 0, 0, nullptr, CheckArgs(), &ma);
+  launch_ewise<OP_COPY>(p, wk2, nullptr, (REAL)0, (REAL)0, bx);
+  *res += read_scalar(0);
+}
+
+void psor2sma_core_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, int* ip, int* color,
+                        CZ_REAL* omg, CZ_REAL* b, double* res, CZ_REAL* tmp, double* flop) {
+  ensure_init();
+  (void)tmp;
+  *flop += 66.0 * 0.5 * npts(idx);
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  const MafArgs ma = upload_xyz(sz, *g, X, Y, Z, nullptr);
+  sweep_async<MODE_RB>(p, p, b, bx, make_coef_omg(*omg), rb_parity(*g, idx, *ip, *color), ctx.scal_dev + 0, 0, nullptr,
+                       CheckArgs(), &ma);
+  *res += read_scalar(0);
+}
+
+void calc_rk_maf_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z,
+                  CZ_REAL* pvt, double* flop) {
+  ensure_init();
+  *flop += 63.0 * npts(idx);
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  const MafArgs ma = upload_xyz(sz, *g, X, Y, Z, pvt);
+  launch_stencil_maf<MODE_RK>(p, b, r, (REAL)0, bx, 0, nullptr, nullptr, Fin(), ma);
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void calc_ax_maf_(CZ_REAL* ap, CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, CZ_REAL* pvt,
+                  double* flop) {
+  ensure_init();
+  *flop += 63.0 * npts(idx);
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  const MafArgs ma = upload_xyz(sz, *g, X, Y, Z, pvt);
+  launch_stencil_maf<MODE_AX>(p, p, ap, (REAL)0, bx, 0, nullptr, nullptr, Fin(), ma);
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
+void search_pivot_(CZ_REAL* pvt, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  const MafArgs ma = upload_xyz(sz, *g, X, Y, Z, nullptr);
+  launch_pivot(pvt, bx, ma);
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
 }  // extern "C"
 
 // internal hooks for the driver (cz_driver.cpp): asynchronous forms of the blas kernels
@@ -1647,6 +1886,45 @@ void dot1_async(const REAL* p, const int* sz, const int* idx, int g, double* dst
 }
 void dot2_async(const REAL* p, const REAL* q, const int* sz, const int* idx, int g, double* dst_dev) {
   launch_dot<1>(p, q, make_box(sz, idx, g), dst_dev);
+}
+// MAF flavour, device-resident coordinates (xc|yc|zc and pvt are device pointers)
+void jacobi_maf_async(const REAL* p_in, REAL* p_out, const REAL* b, const int* sz, const int* idx, int g, const REAL* xc,
+                      const REAL* yc, const REAL* zc, REAL omg, double* res_dev, const int* skip, int check, double res_normal,
+                      double eps, int itr, double* hist, int* flag, int* conv_itr) {
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty) return;
+  MafArgs ma{xc, yc, zc, nullptr};
+  CheckArgs ck;
+  if (check) ck.enabled = 1, ck.itr = itr, ck.res_normal = res_normal, ck.eps = eps, ck.hist = hist, ck.flag = flag, ck.conv_itr = conv_itr;
+  sweep_async<MODE_JACOBI>(p_in, p_out, b, bx, make_coef_omg(omg), 0, res_dev, 0, check ? flag : skip, ck, &ma);
+}
+void rbsor_maf_async(REAL* p, const REAL* b, const int* sz, const int* idx, int g, const REAL* xc, const REAL* yc, const REAL* zc,
+                     int ofst, int color, REAL omg, double* res_dev, int accumulate, const int* skip, int check, double res_normal,
+                     double eps, int itr, double* hist, int* flag, int* conv_itr) {
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty) return;
+  MafArgs ma{xc, yc, zc, nullptr};
+  CheckArgs ck;
+  if (check) ck.enabled = 1, ck.itr = itr, ck.res_normal = res_normal, ck.eps = eps, ck.hist = hist, ck.flag = flag, ck.conv_itr = conv_itr;
+  sweep_async<MODE_RB>(p, p, b, bx, make_coef_omg(omg), rb_parity(g, idx, ofst, color), res_dev, accumulate, check ? flag : skip, ck,
+                       &ma);
+}
+void calc_ax_maf_async(REAL* ap, const REAL* p, const int* sz, const int* idx, int g, const REAL* xc, const REAL* yc, const REAL* zc,
+                       const REAL* pvt) {
+  const Box bx = make_box(sz, idx, g);
+  MafArgs ma{xc, yc, zc, pvt};
+  if (!bx.empty) launch_stencil_maf<MODE_AX>(p, p, ap, (REAL)0, bx, 0, nullptr, nullptr, Fin(), ma);
+}
+void calc_rk_maf_async(REAL* r, const REAL* p, const REAL* b, const int* sz, const int* idx, int g, const REAL* xc, const REAL* yc,
+                       const REAL* zc, const REAL* pvt) {
+  const Box bx = make_box(sz, idx, g);
+  MafArgs ma{xc, yc, zc, pvt};
+  if (!bx.empty) launch_stencil_maf<MODE_RK>(p, b, r, (REAL)0, bx, 0, nullptr, nullptr, Fin(), ma);
+}
+void search_pivot_async(REAL* pvt, const int* sz, const int* idx, int g, const REAL* xc, const REAL* yc, const REAL* zc) {
+  const Box bx = make_box(sz, idx, g);
+  MafArgs ma{xc, yc, zc, nullptr};
+  launch_pivot(pvt, bx, ma);
 }
 void copy_shell_async(REAL* dst, const REAL* src, const int* sz, const int* idx, int g) {
   ensure_init();

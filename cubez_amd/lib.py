@@ -14,6 +14,7 @@ _LOADED: dict = {}
 ABI_SYMBOLS = [
     "bc_k_", "jacobi_", "psor2sma_core_", "blas_clear_", "blas_copy_", "blas_triad_", "blas_dot1_", "blas_dot2_",
     "blas_bicg_1_", "blas_bicg_2_", "blas_calc_ax_", "blas_calc_rk_",
+    "jacobi_maf_", "psor2sma_core_maf_", "calc_rk_maf_", "calc_ax_maf_", "search_pivot_",
     "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
     "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
     "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async", "czhip_jacobi_checked_async",
@@ -164,6 +165,44 @@ class CzHip:
                                 C.c_void_p(b.ptr), C.byref(r), C.byref(fl))
         self.last_flop = fl.value
         return r.value
+
+    # MAF flavour: x, y, z are host numpy arrays (length N+4), like the reference's xc, yc, zc
+    def jacobi_maf(self, p, sz, idx, x, y, z, omg, b, wk2, res=0.0):
+        (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
+        (xk, xp), (yk, yp), (zk, zp) = self._r(x), self._r(y), self._r(z)
+        tmp = np.zeros(sz[2] + 4, dtype=self.real)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self.lib.jacobi_maf_(C.c_void_p(p.ptr), szp, idxp, C.byref(g), xp, yp, zp, self._s(omg), C.c_void_p(b.ptr), C.byref(r),
+                             C.c_void_p(wk2.ptr), tmp.ctypes.data_as(C.c_void_p), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def psor2sma_core_maf(self, p, sz, idx, x, y, z, ofst, color, omg, b, res=0.0):
+        (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
+        (xk, xp), (yk, yp), (zk, zp) = self._r(x), self._r(y), self._r(z)
+        tmp = np.zeros(sz[2] + 4, dtype=self.real)
+        r, fl, o, c = C.c_double(res), C.c_double(0.0), C.c_int(ofst), C.c_int(color)
+        self.lib.psor2sma_core_maf_(C.c_void_p(p.ptr), szp, idxp, C.byref(g), xp, yp, zp, C.byref(o), C.byref(c), self._s(omg),
+                                    C.c_void_p(b.ptr), C.byref(r), tmp.ctypes.data_as(C.c_void_p), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def calc_rk_maf(self, r, p, b, sz, idx, x, y, z, pvt):
+        (_, szp), (_, idxp), g, fl = self._i(sz), self._i(idx), C.c_int(GUIDE), C.c_double(0.0)
+        (xk, xp), (yk, yp), (zk, zp) = self._r(x), self._r(y), self._r(z)
+        self.lib.calc_rk_maf_(C.c_void_p(r.ptr), C.c_void_p(p.ptr), C.c_void_p(b.ptr), szp, idxp, C.byref(g), xp, yp, zp,
+                              C.c_void_p(pvt.ptr), C.byref(fl))
+
+    def calc_ax_maf(self, ap, p, sz, idx, x, y, z, pvt):
+        (_, szp), (_, idxp), g, fl = self._i(sz), self._i(idx), C.c_int(GUIDE), C.c_double(0.0)
+        (xk, xp), (yk, yp), (zk, zp) = self._r(x), self._r(y), self._r(z)
+        self.lib.calc_ax_maf_(C.c_void_p(ap.ptr), C.c_void_p(p.ptr), szp, idxp, C.byref(g), xp, yp, zp, C.c_void_p(pvt.ptr),
+                              C.byref(fl))
+
+    def search_pivot(self, pvt, sz, idx, x, y, z):
+        (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
+        (xk, xp), (yk, yp), (zk, zp) = self._r(x), self._r(y), self._r(z)
+        self.lib.search_pivot_(C.c_void_p(pvt.ptr), szp, idxp, C.byref(g), xp, yp, zp)
 
     def blas_clear(self, x, sz):
         (_, szp), g = self._i(sz), C.c_int(GUIDE)

@@ -73,6 +73,24 @@ void blas_calc_ax_(CZ_REAL* ap, CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* 
 /* cz_Ffunc.h:515-522 <- cz_blas.f90:658-723   r = b - (ss - dd*p) */
 void blas_calc_rk_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g, CZ_REAL* cf, double* flop);
 
+/* MAF flavour: the same solvers on the metric-form Laplacian whose weights are recomputed per
+ * point from 1-D coordinate arrays.  X, Y, Z (length N+4, Fortran X(-1:sz+2)) and tmp are HOST arrays exactly as in
+ * the reference (cz_Evaluate.cpp:342-363 fills them on the host); p, b, wk2, pvt, r, ap are device arrays. */
+/* cz_Ffunc.h:170-182 <- cz_maf.f90:131-285 */
+void jacobi_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, CZ_REAL* omg, CZ_REAL* b, double* res,
+                 CZ_REAL* wk2, CZ_REAL* tmp, double* flop);
+/* cz_Ffunc.h:196-209 <- cz_maf.f90:301-438 */
+void psor2sma_core_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, int* ip, int* color,
+                        CZ_REAL* omg, CZ_REAL* b, double* res, CZ_REAL* tmp, double* flop);
+/* cz_Ffunc.h:524-534 <- cz_blas.f90:738-832   r = (b + dd*p - sum w*p_nb) * pvt */
+void calc_rk_maf_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z,
+                  CZ_REAL* pvt, double* flop);
+/* cz_Ffunc.h:536-545 <- cz_blas.f90:845-934   ap = (sum w*p_nb - dd*p) * pvt */
+void calc_ax_maf_(CZ_REAL* ap, CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, CZ_REAL* pvt,
+                  double* flop);
+/* cz_Ffunc.h:547-553 <- cz_blas.f90:947-1039  pvt = 1 / max |row entries| */
+void search_pivot_(CZ_REAL* pvt, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z);
+
 /* ------------------------------------------------------------------------------------------------
  * Part 2 -- runtime
  * ---------------------------------------------------------------------------------------------- */

@@ -312,3 +312,80 @@ def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
         h.set_tuning2(*((512, 2, 16) if prec == "f32" else (1024, 2, 64)), 1)
     if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:
         assert launched > 0
+
+
+def _coords(rng, n, R):
+    return (np.cumsum(rng.uniform(0.5, 1.5, n + 4)).astype(R) * R(0.05)).astype(R)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_maf_golden_vectors(prec):
+    """MAF flavour: reference-generated vectors on a stretched grid through the drop-in symbols."""
+    g = np.load(os.path.join(GOLDEN, f"kernels_{prec}.npz"))
+    h = _hip(prec)
+    sz, idx, omg = list(g["sz"]), list(g["idx"]), float(g["omg"])
+    p, b = g["in_p"], g["in_b"]
+    xc, yc, zc = g["maf_x"], g["maf_y"], g["maf_z"]
+    dp, db = h.alloc(sz, p), h.alloc(sz, b)
+    pv = h.alloc(sz, g["maf_pvt_in"])
+    h.search_pivot(pv, sz, idx, xc, yc, zc)
+    assert _beq(pv.get(), g["maf_pvt"])
+    pm, wm = h.alloc(sz, p), h.alloc(sz, np.zeros_like(p))
+    res = h.jacobi_maf(pm, sz, idx, xc, yc, zc, omg, db, wm, res=0.5)
+    assert _beq(pm.get(), g["maf_jacobi_p"]) and _beq(wm.get(), g["maf_jacobi_wk2"])
+    assert h.last_flop == float(g["maf_jacobi_flop"])
+    assert _rel(res, float(g["maf_jacobi_res"])) < _real_tol(prec)
+    for ofst in (0, 1):
+        ps, r = h.alloc(sz, p), 0.0
+        for color in (0, 1):
+            r = h.psor2sma_core_maf(ps, sz, idx, xc, yc, zc, ofst, color, omg, db, res=r)
+            assert _beq(ps.get(), g[f"maf_rb{ofst}_p_c{color}"])
+            assert _rel(r, float(g[f"maf_rb{ofst}_res_c{color}"])) < _real_tol(prec)
+    a = h.alloc(sz, g["maf_ax_in"])
+    h.calc_ax_maf(a, dp, sz, idx, xc, yc, zc, pv)
+    assert _beq(a.get(), g["maf_ax"])
+    a = h.alloc(sz, g["maf_rk_in"])
+    h.calc_rk_maf(a, dp, db, sz, idx, xc, yc, zc, pv)
+    assert _beq(a.get(), g["maf_rk"])
+
+
+MAF_BOXES = [((9, 12, 7), None), ((16, 8, 32), None), ((40, 36, 60), None), ((33, 70, 124), None),
+             ((24, 20, 28), (1, 24, 1, 20, 1, 28)), ((130, 20, 252), None)]
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", MAF_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in MAF_BOXES])
+def test_maf_random_boxes_vs_oracle(prec, box):
+    (ni, nj, nk), idx = box
+    sz = [ni, nj, nk]
+    idx = list(idx) if idx else [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(17 * ni + 3 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    xc, yc, zc = _coords(rng, ni, R), _coords(rng, nj, R), _coords(rng, nk, R)
+    p, b = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    sentinel = rng.uniform(-1, 1, shape).astype(R)
+    dp, db = h.alloc(sz, p), h.alloc(sz, b)
+    pv1, pv2 = sentinel.copy(), h.alloc(sz, sentinel)
+    ko.search_pivot(pv1, sz, idx, xc, yc, zc), h.search_pivot(pv2, sz, idx, xc, yc, zc)
+    assert _beq(pv2.get(), pv1)
+    a1, w1, wide = p.copy(), sentinel.copy(), np.zeros(1)
+    ko.jacobi_maf(a1, sz, idx, xc, yc, zc, 0.9, b, w1, res=0.0, wide=wide)
+    a2, w2 = h.alloc(sz, p), h.alloc(sz, sentinel)
+    r2 = h.jacobi_maf(a2, sz, idx, xc, yc, zc, 0.9, db, w2, res=0.0)
+    assert _beq(a2.get(), a1) and _beq(w2.get(), w1)
+    assert _rel(r2, wide[0]) < RTOL_WIDE * 10
+    for ofst in (0, 1):
+        a1, a2, r2, wide = p.copy(), h.alloc(sz, p), 0.0, np.zeros(1)
+        for color in (0, 1):
+            ko.psor2sma_core_maf(a1, sz, idx, xc, yc, zc, ofst, color, 1.2, b, wide=wide)
+            r2 = h.psor2sma_core_maf(a2, sz, idx, xc, yc, zc, ofst, color, 1.2, db, res=r2)
+            assert _beq(a2.get(), a1), (ofst, color)
+        assert _rel(r2, wide[0]) < RTOL_WIDE * 10
+    o1, o2 = sentinel.copy(), h.alloc(sz, sentinel)
+    ko.calc_ax_maf(o1, p, sz, idx, xc, yc, zc, pv1), h.calc_ax_maf(o2, dp, sz, idx, xc, yc, zc, pv2)
+    assert _beq(o2.get(), o1)
+    o1, o2 = sentinel.copy(), h.alloc(sz, sentinel)
+    ko.calc_rk_maf(o1, p, b, sz, idx, xc, yc, zc, pv1), h.calc_rk_maf(o2, dp, db, sz, idx, xc, yc, zc, pv2)
+    assert _beq(o2.get(), o1)
