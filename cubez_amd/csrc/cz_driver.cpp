@@ -39,6 +39,9 @@ const char* printMethod(int t) {
     case LS_SOR2SMA: return "SOR2SMA";
     case LS_BICGSTAB: return "PBiCGSTAB";
     case LS_PSOR: return "PSOR";
+    case LS_JACOBI_MAF: return "JACOBI_MAF";
+    case LS_SOR2SMA_MAF: return "SOR2SMA_MAF";
+    case LS_BICGSTAB_MAF: return "PBiCGSTAB_MAF";
     default: return "NONE";
   }
 }
@@ -61,7 +64,10 @@ CZ::CZ() {
 
 CZ::~CZ() {
   czhip_sync();
-  REAL_TYPE* arrs[] = {WRK, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_};
+  REAL_TYPE* arrs[] = {WRK, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt};
+  if (d_xc) (void)hipFree(d_xc);
+  if (d_yc) (void)hipFree(d_yc);
+  if (d_zc) (void)hipFree(d_zc);
   for (REAL_TYPE* a : arrs)
     if (a) czhip_free(a);
   if (d_hist) (void)hipFree(d_hist);
@@ -97,9 +103,11 @@ double CZ::range_inner_index() {
 void CZ::setStrPre() {
   if (!strcasecmp(precon.c_str(), "jacobi")) pc_type = LS_JACOBI;
   else if (!strcasecmp(precon.c_str(), "sor2sma")) pc_type = LS_SOR2SMA;
+  else if (!strcasecmp(precon.c_str(), "jacobi_maf")) pc_type = LS_JACOBI_MAF, SW_maf = 1;
+  else if (!strcasecmp(precon.c_str(), "sor2sma_maf")) pc_type = LS_SOR2SMA_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "none")) pc_type = LS_NONE;
   else {
-    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | sor2sma)\n", precon.c_str());
+    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | sor2sma | jacobi_maf | sor2sma_maf)\n", precon.c_str());
     exit(0);
   }
 }
@@ -116,6 +124,19 @@ void CZ::setLS(const char* q) {
     ls_type = LS_BICGSTAB;
     hist_name = "pbicgstab.txt";
     setStrPre();
+  } else if (!strcasecmp(q, "jacobi_maf")) {  // :738-760, the MAF flavours
+    ls_type = LS_JACOBI_MAF;
+    hist_name = "jacobi_maf.txt";
+    SW_maf = 1;
+  } else if (!strcasecmp(q, "sor2sma_maf")) {
+    ls_type = LS_SOR2SMA_MAF;
+    hist_name = "sor2sma_maf.txt";
+    SW_maf = 1;
+  } else if (!strcasecmp(q, "pbicgstab_maf")) {
+    ls_type = LS_BICGSTAB_MAF;
+    hist_name = "pbicgstab_maf.txt";
+    setStrPre();
+    SW_maf = 1;
   } else {
     printf("Invalid solver\n");  // :799-802
     exit(0);
@@ -170,7 +191,7 @@ int CZ::Setup(int argc, char** argv) {
   }
 
   const char* q = argv[4];
-  if (!strcasecmp(q, "pbicgstab")) {  // :63-70
+  if (!strcasecmp(q, "pbicgstab") || !strcasecmp(q, "pbicgstab_maf")) {  // :63-70
     if (argc != 8 && argc != 11) {
       Hostonly_ printf("command line error : pbicgstab\n");
       exit(0);
@@ -203,7 +224,7 @@ int CZ::Setup(int argc, char** argv) {
   setLS(q);
   if (!quiet) Hostonly_ {
     printf("Iterative Mehtod = %s\n", printMethod(ls_type));  // :194 (sic)
-    if (ls_type == LS_BICGSTAB) printf("Preconditioner = %s\n", printMethod(pc_type));
+    if (ls_type == LS_BICGSTAB || ls_type == LS_BICGSTAB_MAF) printf("Preconditioner = %s\n", printMethod(pc_type));
   }
 
   if (!quiet) Hostonly_ {  // :210-218
@@ -222,7 +243,8 @@ int CZ::Setup(int argc, char** argv) {
   RHS = czhip_alloc_s3d(size);
   P = czhip_alloc_s3d(size);
   WRK = czhip_alloc_s3d(size);
-  if (ls_type == LS_BICGSTAB) {
+  const bool bicg = ls_type == LS_BICGSTAB || ls_type == LS_BICGSTAB_MAF;
+  if (bicg) {
     pcg_p = czhip_alloc_s3d(size), pcg_p_ = czhip_alloc_s3d(size), pcg_r = czhip_alloc_s3d(size);
     pcg_r0 = czhip_alloc_s3d(size), pcg_q = czhip_alloc_s3d(size), pcg_s = czhip_alloc_s3d(size);
     pcg_s_ = czhip_alloc_s3d(size), pcg_t_ = czhip_alloc_s3d(size);
@@ -230,11 +252,25 @@ int CZ::Setup(int argc, char** argv) {
   if (!quiet) Hostonly_ {
     const double arr = (double)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
     printf("\n----------\n\n\tDevice memory per rank : %.1f MiB in %d arrays of (%d+4)x(%d+4)x(%d+4) %s\n", arr *
-           (ls_type == LS_BICGSTAB ? 11 : 3) / 1048576.0, ls_type == LS_BICGSTAB ? 11 : 3, size[0], size[1], size[2],
+           (bicg ? 11 : 3) / 1048576.0, bicg ? 11 : 3, size[0], size[1], size[2],
            sizeof(REAL_TYPE) == 4 ? "float" : "double");
   }
 
   ItrMax = atoi(argv[5]);  // :330
+
+  if (SW_maf) {
+    // :342-363 one-dimensional grid xc[i] = (i-1)*pitch (local index; the reference adds no brick origin), uploaded once;
+    // :369 search_pivot_
+    REAL_TYPE** dst[3] = {&d_xc, &d_yc, &d_zc};
+    for (int a = 0; a < 3; a++) {
+      std::vector<REAL_TYPE> c(size[a] + 2 * gc);
+      for (int i = 0; i < size[a] + 2 * gc; i++) c[i] = (REAL_TYPE)(i - 1) * pitch[a];
+      HIP_CHECK(hipMalloc(dst[a], c.size() * sizeof(REAL_TYPE)));
+      HIP_CHECK(hipMemcpy(*dst[a], c.data(), c.size() * sizeof(REAL_TYPE), hipMemcpyHostToDevice));
+    }
+    pvt = czhip_alloc_s3d(size);
+    search_pivot_async(pvt, size, innerFidx, gc, d_xc, d_yc, d_zc);
+  }
 
   // :375-386  boundary values on P and RHS, ghost layers filled from the neighbours
   // (global origin + integer brick offset instead of the brick origin: bit-identical faces on every decomposition)
@@ -258,12 +294,15 @@ int CZ::Solve() {
   const double t0 = now_s();
   switch (ls_type) {  // :415-488
     case LS_JACOBI:
+    case LS_JACOBI_MAF:
       if (0 == (itr = JACOBI(res, P, RHS, ItrMax, flop, ls_type))) return 0;
       break;
     case LS_SOR2SMA:
+    case LS_SOR2SMA_MAF:
       if (0 == (itr = RBSOR(res, P, RHS, ItrMax, flop, ls_type))) return 0;
       break;
     case LS_BICGSTAB:
+    case LS_BICGSTAB_MAF:
       if (0 == (itr = PBiCGSTAB(res, P, RHS, flop, ls_type))) return 0;
       break;
     default:
@@ -291,7 +330,7 @@ int CZ::Evaluate(int argc, char** argv) {
   if (!Solve()) return 0;
   if (!quiet) Hostonly_ {
     const double lups = 1.0 / res_normal * (double)(result_itr > ItrMax ? ItrMax : result_itr);
-    if (ls_type != LS_BICGSTAB)
+    if (ls_type != LS_BICGSTAB && ls_type != LS_BICGSTAB_MAF)
       printf("\n\tGPU time = %.6f s   %.1f MLUPS\n", solve_seconds, lups / solve_seconds * 1e-6);
     else
       printf("\n\tGPU time = %.6f s\n", solve_seconds);
@@ -307,12 +346,12 @@ int CZ::Evaluate(int argc, char** argv) {
 // Bench leg: n more iterations of the stationary solver, with the complete per-iteration work of the checked loop
 // (sweep, residual reduction, convergence bookkeeping) but eps disabled so that nothing is skipped.
 int CZ::Sweeps(int n) {
-  if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA)) return 0;
+  if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA && ls_type != LS_JACOBI_MAF && ls_type != LS_SOR2SMA_MAF)) return 0;
   const double keep = eps;
   eps = -1.0;
   double res = 0.0, flop = 0.0;
   history.clear();
-  if (ls_type == LS_JACOBI) JACOBI(res, P, RHS, n, flop, ls_type);
+  if (ls_type == LS_JACOBI || ls_type == LS_JACOBI_MAF) JACOBI(res, P, RHS, n, flop, ls_type);
   else RBSOR(res, P, RHS, n, flop, ls_type);
   eps = keep;
   sweeps_done += n;
@@ -368,7 +407,7 @@ int CZ::finish_stationary(int itr_max, int first_itr, bool converge_check, doubl
 // ------------------------------------------------------------------------------------------------------------
 // cz_Poisson.cpp:30-82
 int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
-  (void)s_type;
+  const bool maf = (s_type == LS_JACOBI_MAF);  // cz_Poisson.cpp:45-53
   const int gc = GUIDE;
   hipStream_t st = stream();
   // ping-pong partner: same guide cells / Dirichlet faces as X
@@ -386,7 +425,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     int first_itr, nsweep, src;
   };
   std::vector<Launch> launches;
-  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2;
+  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2 && !maf;  // the MAF flavour runs sweep by sweep
   int idx1[6];  // index range of the first sweep of a pair: one layer into the ghost cells across rank-internal faces
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
   if (can_pair && numProc > 1) {
@@ -418,7 +457,10 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     }
     if (!done) {
       const bool fused_check = converge_check && numProc == 1;  // no all-reduce between sweep and test: one launch
-      if (fused_check)
+      if (maf)
+        jacobi_maf_async(src, dst, B, size, innerFidx, gc, d_xc, d_yc, d_zc, ac1, d_res, skip, fused_check ? 1 : 0, res_normal, eps,
+                         itr, d_hist, d_flag, d_flag + 1);
+      else if (fused_check)
         czhip_jacobi_checked_async(src, dst, B, size, innerFidx, gc, cf, ac1, d_res, res_normal, eps, itr, d_hist, d_flag,
                                    d_flag + 1);  // :58 + :67-77
       else
@@ -430,7 +472,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       }
       done = 1;
     }
-    flop += 18.0 * npts() * done;
+    flop += (maf ? 66.0 : 18.0) * npts() * done;
     launches.push_back({itr, done, cur});
     itr += done;
     cur ^= 1;
@@ -465,7 +507,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       if (last->nsweep == 2 && ret == last->first_itr) {
         // the first sweep of a fused pair converged: the pair wrote time n+2 into its destination; its source is
         // untouched, so one plain sweep reproduces the converged iterate (exactly what the sequential loop holds)
-        czhip_jacobi_async(buf[last->src], buf[last->src ^ 1], B, size, innerFidx, gc, cf, ac1, d_res + 4, 0, nullptr);
+        czhip_jacobi_async(buf[last->src], buf[last->src ^ 1], B, size, innerFidx, gc, cf, ac1, d_res + 4, 0, nullptr);  // (never MAF: pairs are not formed there)
       }
     }
     final_buf = last->src ^ 1;
@@ -485,7 +527,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
 
 // cz_Poisson.cpp:159-235
 int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
-  (void)s_type;
+  const bool maf = (s_type == LS_SOR2SMA_MAF);  // cz_Poisson.cpp:190-200
   const int gc = GUIDE;
   hipStream_t st = stream();
   const int* skip = nullptr;
@@ -502,7 +544,7 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   // Preferred form: the whole iteration (colour 0, then colour 1) in ONE pass over memory, out of place X <-> WRK
   // (czhip_rbsor2_async); decomposed runs then exchange two ghost layers once per iteration.  Fallback: the reference's
   // two in-place colour launches with an exchange after each colour.
-  bool fused = czhip_use_t2() != 0;
+  bool fused = czhip_use_t2() != 0 && !maf;
   int idx1[6];
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
   REAL_TYPE* buf[2] = {X, WRK};
@@ -540,7 +582,10 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
     }
     if (!done) {
       for (int color = 0; color < 2; color++) {  // :205-209
-        if (in_kernel_check && color == 1)
+        if (maf)
+          rbsor_maf_async(X, B, size, innerFidx, gc, d_xc, d_yc, d_zc, ip, color, ac1, d_res, color, skip,
+                          (in_kernel_check && color == 1) ? 1 : 0, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+        else if (in_kernel_check && color == 1)
           czhip_rbsor_checked_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, 1, res_normal, eps, itr, d_hist,
                                     d_flag, d_flag + 1);
         else
@@ -613,9 +658,11 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
   const int lc_max = 8;  // :280
   switch (s_type) {
     case LS_JACOBI:
+    case LS_JACOBI_MAF:
       JACOBI(res, xx, bb, lc_max, flop, s_type, false);
       break;
     case LS_SOR2SMA:
+    case LS_SOR2SMA_MAF:
       RBSOR(res, xx, bb, lc_max, flop, s_type, false);
       break;
     default: {
@@ -627,7 +674,7 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
 
 // cz_Poisson.cpp:332-504
 int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_type) {
-  (void)s_type;
+  const bool maf = (s_type == LS_BICGSTAB_MAF);
   const int gc = GUIDE;
   hipStream_t st = stream();
   const size_t nbytes = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
@@ -636,8 +683,9 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
   res = 0.0;
 
   HIP_CHECK(hipMemsetAsync(pcg_q, 0, nbytes, st));                       // :344 blas_clear_
-  calc_rk_async(pcg_r, X, B, size, innerFidx, gc, cf);                  // :356
-  flop += 14.0 * npts();
+  if (maf) calc_rk_maf_async(pcg_r, X, B, size, innerFidx, gc, d_xc, d_yc, d_zc, pvt);  // :352
+  else calc_rk_async(pcg_r, X, B, size, innerFidx, gc, cf);                             // :356
+  flop += (maf ? 63.0 : 14.0) * npts();
   if (!Comm_S(pcg_r)) return 0;                                         // :362
   HIP_CHECK(hipMemcpyAsync(pcg_r0, pcg_r, nbytes, hipMemcpyDeviceToDevice, st));  // :365 blas_copy_
 
@@ -664,8 +712,9 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     Preconditioner(pcg_p_, pcg_p, flop_count, pc_type);  // :409
     flop += flop_count;
 
-    calc_ax_async(pcg_q, pcg_p_, size, innerFidx, gc, cf);  // :421
-    flop += 13.0 * npts();
+    if (maf) calc_ax_maf_async(pcg_q, pcg_p_, size, innerFidx, gc, d_xc, d_yc, d_zc, pvt);  // :417
+    else calc_ax_async(pcg_q, pcg_p_, size, innerFidx, gc, cf);                              // :421
+    flop += (maf ? 63.0 : 13.0) * npts();
 
     flop_count = 0.0;
     alpha = rho / Fdot2(pcg_q, pcg_r0, flop_count);  // :427
@@ -681,8 +730,9 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     Preconditioner(pcg_s_, pcg_s, flop_count, pc_type);  // :445
     flop += flop_count;
 
-    calc_ax_async(pcg_t_, pcg_s_, size, innerFidx, gc, cf);  // :457
-    flop += 13.0 * npts();
+    if (maf) calc_ax_maf_async(pcg_t_, pcg_s_, size, innerFidx, gc, d_xc, d_yc, d_zc, pvt);  // :453
+    else calc_ax_async(pcg_t_, pcg_s_, size, innerFidx, gc, cf);                              // :457
+    flop += (maf ? 63.0 : 13.0) * npts();
 
     flop_count = 0.0;
     const REAL_TYPE ts = Fdot2(pcg_t_, pcg_s, flop_count);
