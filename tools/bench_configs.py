@@ -7,7 +7,8 @@ from cubez_amd import CZ
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 lups = float(N - 2) ** 3
 out = {}
-for solver, prec, coef, bpl in (("jacobi", "f32", 0.8, 12), ("sor2sma", "f32", 1.5, 16), ("jacobi", "f64", 0.8, 24), ("sor2sma", "f64", 1.5, 32)):
+for solver, prec, coef, bpl in (("jacobi", "f32", 0.8, 12), ("sor2sma", "f32", 1.5, 16), ("jacobi", "f64", 0.8, 24), ("sor2sma", "f64", 1.5, 32),
+                                ("jacobi_maf", "f32", 0.8, 12), ("sor2sma_maf", "f32", 1.5, 16), ("jacobi_maf", "f64", 0.8, 24)):
     cz = CZ(prec, quiet=True)
     assert cz.setup([N, N, N, solver, 1000, coef]) == 1
     cz.sweeps(10); cz.lib.czhip_sync()
