@@ -406,7 +406,8 @@ int CZ::finish_stationary(int itr_max, int first_itr, bool converge_check, doubl
 
 // ------------------------------------------------------------------------------------------------------------
 // cz_Poisson.cpp:30-82
-int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check,
+               bool x_is_zero) {
   const bool maf = (s_type == LS_JACOBI_MAF);  // cz_Poisson.cpp:45-53
   const int gc = GUIDE;
   hipStream_t st = stream();
@@ -441,7 +442,19 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     REAL_TYPE* src = buf[cur];
     REAL_TYPE* dst = buf[cur ^ 1];
     int done = 0;
-    if (can_pair && itr + 1 <= itr_max) {
+    if (x_is_zero && itr == 1) {
+      // start vector identically zero (preconditioner): neither cleared in memory nor read -- if the fused kernel takes it
+      if (can_pair && itr + 1 <= itr_max && !converge_check)
+        done = 2 * czhip_jacobi2_from_zero_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res);
+      if (done) {
+        if (numProc > 1 && !Comm_S2(dst, skip)) return 0;
+      } else {
+        // not taken (geometry, tuning): do the blas_clear_ the caller skipped (guide cells / faces are zero already)
+        const size_t nbytes = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
+        HIP_CHECK(hipMemsetAsync(src, 0, nbytes, st));
+      }
+    }
+    if (!done && can_pair && itr + 1 <= itr_max) {
       const bool in_kernel_check = converge_check && numProc == 1;
       done = 2 * czhip_jacobi2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res, res_normal, eps, itr,
                                      in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :58 + :67-77, twice
@@ -652,14 +665,25 @@ REAL_TYPE CZ::Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop) {
   return (REAL_TYPE)h_scal[1];
 }
 
+// The work vectors the preconditioner solves into are allocated zero-filled and afterwards only written on the inner box,
+// so their guide cells and faces are zero for the whole run.
+bool CZ::xx_shell_is_zero(const REAL_TYPE* xx) const { return xx == pcg_p_ || xx == pcg_s_; }
+
 // cz_Poisson.cpp:273-322
 void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) {
   double res = 0.0;
   const int lc_max = 8;  // :280
+  const size_t nbytes = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE) * sizeof(REAL_TYPE);
+  // blas_clear_(xx) of the caller (cz_Poisson.cpp:405, 441) is folded in here.  With the plain Jacobi preconditioner on
+  // the fused-pair path the clear is not even executed: xx's guide cells / faces are zero from allocation on (sweeps only
+  // ever write its inner box) and the first pair takes "u == 0" as a literal instead of reading it.
+  // (single-domain only: a decomposed run leaves the neighbours' values in xx's ghost layers)
+  const bool zero_start = (s_type == LS_JACOBI) && numProc == 1 && czhip_use_t2() != 0 && xx_shell_is_zero(xx);
+  if (!zero_start) HIP_CHECK(hipMemsetAsync(xx, 0, nbytes, stream()));
   switch (s_type) {
     case LS_JACOBI:
     case LS_JACOBI_MAF:
-      JACOBI(res, xx, bb, lc_max, flop, s_type, false);
+      JACOBI(res, xx, bb, lc_max, flop, s_type, false, zero_start);
       break;
     case LS_SOR2SMA:
     case LS_SOR2SMA_MAF:
@@ -707,8 +731,7 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
       flop += 4.0 * npts();
     }
     if (!Comm_S(pcg_p)) return 0;                    // :402
-    HIP_CHECK(hipMemsetAsync(pcg_p_, 0, nbytes, st));  // :405
-    flop_count = 0.0;
+    flop_count = 0.0;                                // :405 blas_clear_(pcg_p_) happens inside Preconditioner
     Preconditioner(pcg_p_, pcg_p, flop_count, pc_type);  // :409
     flop += flop_count;
 
@@ -725,8 +748,7 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     flop += 2.0 * npts();
     if (!Comm_S(pcg_s)) return 0;  // :438
 
-    HIP_CHECK(hipMemsetAsync(pcg_s_, 0, nbytes, st));  // :441
-    flop_count = 0.0;
+    flop_count = 0.0;  // :441 blas_clear_(pcg_s_) happens inside Preconditioner
     Preconditioner(pcg_s_, pcg_s, flop_count, pc_type);  // :445
     flop += flop_count;
 

@@ -89,7 +89,9 @@ class CZ {
   void ensure_hist(int n);
 
   // cz_Poisson.cpp
-  int JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
+  int JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true,
+             bool x_is_zero = false);
+  bool xx_shell_is_zero(const REAL_TYPE* xx) const;
   int RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   REAL_TYPE Fdot1(REAL_TYPE* x, double& flop);
   REAL_TYPE Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop);

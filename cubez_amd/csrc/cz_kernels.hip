@@ -16,6 +16,7 @@
 // planes per chunk), each new element is written once.  No MFMA: 18 flop per 12 bytes is far below the ridge.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -499,6 +500,7 @@ struct Geom2 {
   long long F0a, Fenda;
   int nseg, TJ, S;  // S = TB*MV - 2R
   int par;          // RB: colour 0 = points with (kk + ii + jj + par) even
+  int zero_u;       // the input field is identically zero (a freshly cleared preconditioner vector): u is not read
 };
 
 struct Fin2 {
@@ -579,7 +581,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
     for (int m = 0; m < MV; m++) {
       const int e = t + m * TB;
       f[m] = e1_0 + e;
-      ld[m] = (e < LV) && (f[m] < g.PSV);
+      ld[m] = (e < LV) && (f[m] < g.PSV) && !g.zero_u;
       const long long row = f[m] / R;
       const int kv = (int)(f[m] - row * R);
       unsigned bits1 = 0, bits2 = 0;
@@ -611,9 +613,9 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
       for (int m = 0; m < MV; m++)
         if (t + m * TB < LV) ldsU[R + t + m * TB] = ub[m];
       if (t < R) {
-        ldsU[t] = ldv<V>(Ub, e2_0 + t);
         const long long fh = fb + g.S + R + t;
-        ldsU[R + LV + t] = (fh < g.PSV) ? ldv<V>(Ub, fh) : zerov<V>();
+        ldsU[t] = g.zero_u ? zerov<V>() : ldv<V>(Ub, e2_0 + t);
+        ldsU[R + LV + t] = (fh < g.PSV && !g.zero_u) ? ldv<V>(Ub, fh) : zerov<V>();
       }
     }
     __syncthreads();
@@ -633,7 +635,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
         b1[m] = (ka[m] != 0 && plane_inner) ? ldv<V>(Bq, f[m]) : zerov<V>();
       }
       Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
-      if (more && t < R) {
+      if (more && t < R && !g.zero_u) {
         hlo = ldv<V>(Uc, e2_0 + t);
         const long long fh = fb + g.S + R + t;
         if (fh < g.PSV) hhi = ldv<V>(Uc, fh);
@@ -897,28 +899,56 @@ pivot_k(REAL* PVT, EGeom g, MafArgs ma, int nkp, int nip) {
   (void)nip;
 }
 
-// dot products (cz_blas.f90:361-362, :426): per-point product in REAL, accumulated in double.
+// dot products (cz_blas.f90:361-362, :426): per-point product in REAL, accumulated in double.  A workgroup strides over
+// the planes (few thousand workgroups in all); the last one to finish sums the partials in fixed order into dst[0]
+// (same write-through hand-off as the sweeps: no second launch).
 template <int V, int TWO>
 __global__ void __launch_bounds__(256)
-dot_k(const REAL* X, const REAL* Y, EGeom g, double* __restrict__ partials) {
+dot_k(const REAL* X, const REAL* Y, EGeom g, int nplanes, double* partials, double* dst, unsigned* counter) {
   __shared__ double wsum[4];
+  __shared__ int last_flag;
   const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
   double acc = 0.0;
   if (f < g.Fend) {
-    const long long pv = (long long)(g.jj0 + blockIdx.y) * g.PSV + f;
     const int kv = (int)(f % g.R);
-    const Vec<V> x = ldv<V>(X, pv);
-    Vec<V> y = x;
-    if (TWO) y = ldv<V>(Y, pv);
+    unsigned mk = 0;
 #pragma unroll
     for (int cc = 0; cc < V; cc++) {
       const int kk = kv * V + cc;
-      const REAL tt = x.v[cc] * y.v[cc];
-      if (kk >= g.kk0 && kk <= g.kk1) acc += (double)tt;
+      if (kk >= g.kk0 && kk <= g.kk1) mk |= 1u << cc;
+    }
+    for (int pl = blockIdx.y; pl < nplanes; pl += gridDim.y) {
+      const long long pv = (long long)(g.jj0 + pl) * g.PSV + f;
+      const Vec<V> x = ldv<V>(X, pv);
+      Vec<V> y = x;
+      if (TWO) y = ldv<V>(Y, pv);
+#pragma unroll
+      for (int cc = 0; cc < V; cc++) {
+        const REAL tt = x.v[cc] * y.v[cc];
+        if (mk & (1u << cc)) acc += (double)tt;
+      }
     }
   }
   const double s = block_sum<256>(acc, wsum);
-  if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+  const int nblk = gridDim.x * gridDim.y;
+  const int me = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[me], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<256>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = tot;
+      *counter = 0u;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1179,7 +1209,7 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 // two fused sweeps; returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
 template <int TB, int MV, int RB>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
-                         const int* skip, const Fin2& fin_in, int par) {
+                         const int* skip, const Fin2& fin_in, int par, int zero_u) {
   constexpr int V = VW;
   Geom2 g;
   g.R = b.nkp / V;
@@ -1193,6 +1223,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   g.Fenda = (long long)(ba.ii1 + 1) * g.R;
   g.S = TB * MV - 2 * g.R;
   g.par = par;
+  g.zero_u = zero_u;
   const long long nf = g.Fend - g.F0;
   g.nseg = (int)((nf + g.S - 1) / g.S);
   const int nplanes = b.jj1 - b.jj0 + 1;
@@ -1224,7 +1255,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
 
 template <int RB>
 bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
-                    const Fin2& fin, int par = 0) {
+                    const Fin2& fin, int par = 0, int zero_u = 0) {
   if (!vec_ok(b, {U, B, W})) return false;
   // the stage-1 box may exceed the output box by at most one layer per side
   if (ba.ii0 < b.ii0 - 1 || ba.ii0 > b.ii0 || ba.ii1 > b.ii1 + 1 || ba.ii1 < b.ii1 || ba.jj0 < b.jj0 - 1 || ba.jj0 > b.jj0 ||
@@ -1234,10 +1265,10 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
   const Tuning& tu = ctx.tune;
 #define CZ_INST2(TB_, MV_) \
-  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par);
+  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u);
   CZ_INST2(256, 4) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(1024, 2)
 #undef CZ_INST2
-  return launch_jacobi2_inst<512, 2, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par);
+  return launch_jacobi2_inst<512, 2, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u);
 }
 
 Coef make_coef_omg(REAL omg) {
@@ -1278,25 +1309,21 @@ void launch_dot(const REAL* X, const REAL* Y, const Box& b, double* dst) {
     return;
   }
   const int nplanes = b.jj1 - b.jj0 + 1;
-  size_t nblk;
-  {
   ScopedTimer tm(LBL_DOT);
   if (vec_ok(b, {X, Y})) {
     EGeom e = make_egeom<VW>(b);
-    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
-    nblk = (size_t)grid.x * grid.y;
-    ensure_partials(nblk);
-    hipLaunchKernelGGL((dot_k<VW, TWO>), grid, dim3(256), 0, ctx.stream, X, Y, e, ctx.partials);
+    const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
+    const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));
+    ensure_partials((size_t)gx * gy);
+    hipLaunchKernelGGL((dot_k<VW, TWO>), dim3(gx, gy), dim3(256), 0, ctx.stream, X, Y, e, nplanes, ctx.partials, dst, ctx.counter);
   } else {
     EGeom e = make_egeom<1>(b);
-    dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
-    nblk = (size_t)grid.x * grid.y;
-    ensure_partials(nblk);
-    hipLaunchKernelGGL((dot_k<1, TWO>), grid, dim3(256), 0, ctx.stream, X, Y, e, ctx.partials);
-  }
+    const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
+    const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));
+    ensure_partials((size_t)gx * gy);
+    hipLaunchKernelGGL((dot_k<1, TWO>), dim3(gx, gy), dim3(256), 0, ctx.stream, X, Y, e, nplanes, ctx.partials, dst, ctx.counter);
   }
   HIP_CHECK(hipGetLastError());
-  reduce_partials((int)nblk, dst, 0, nullptr);
 }
 
 double read_scalar(int slot) {
@@ -1632,6 +1659,21 @@ int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const in
     fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
   }
   return launch_jacobi2<0>(u, b, w, make_coef(cf, omg), bx, ba, hist_dev ? flag_dev : skip_flag_dev, fin) ? 1 : 0;
+}
+
+// The first pair of sweeps of a preconditioner solve, whose start vector was just cleared (cz_Poisson.cpp:405-409: blas_clear_
+// then 8 sweeps): the input field is identically zero, so it is neither cleared in memory nor read -- the arithmetic is
+// the same with literal zeros.  `u_shape` is only used for its alignment/geometry checks.  No convergence bookkeeping.
+int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1,
+                                  int g, const CZ_REAL* cf, CZ_REAL omg, double* res_dev) {
+  ensure_init();
+  if (!ctx.tune.fuse_fin) return 0;
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty || g < 2) return 0;
+  const Box ba = idx1 ? make_box(sz, idx1, g) : bx;
+  Fin2 fin;
+  fin.dst = res_dev;
+  return launch_jacobi2<0>(u_shape, b, w, make_coef(cf, omg), bx, ba, nullptr, fin, 0, 1) ? 1 : 0;
 }
 
 // One complete red-black SOR iteration (colour 0 then colour 1, cz_Poisson.cpp:205-209) in one pass over memory, u -> w.

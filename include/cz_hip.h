@@ -161,6 +161,11 @@ int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const in
 int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
                        const CZ_REAL* cf, int ofst, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr,
                        double* hist_dev, int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev);
+/* First pair of a preconditioner solve whose start vector is identically zero (blas_clear_ + 8 sweeps, cz_Poisson.cpp:405-409):
+ * u is neither cleared in memory nor read; u_shape only provides the array geometry/alignment.  Bit-identical to clearing u and
+ * calling czhip_jacobi2_async. */
+int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1,
+                                  int g, const CZ_REAL* cf, CZ_REAL omg, double* res_dev);
 /* The same bookkeeping for a pair whose two sums were all-reduced first (decomposed runs). */
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);
