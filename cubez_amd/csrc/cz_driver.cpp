@@ -715,10 +715,29 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
 
   REAL_TYPE rho_old = 1.0, alpha = 0.0, omega = 1.0, r_omega = -omega;  // :368-371
 
+  // Dot products that directly follow the kernel producing their operand are folded into that kernel (same per-point
+  // REAL products, double accumulation, rounded once to REAL like Fdot1/Fdot2): q.r0 into q = A p_, t_.s and t_.t_ into
+  // t_ = A s_, r.r and the NEXT iteration's rho = r.r0 into r = s - omega t_.
+  MafPtrs mp{d_xc, d_yc, d_zc, pvt};
+  auto fetch2 = [&](double* d_two, REAL_TYPE& a, REAL_TYPE& b2) -> bool {  // all-reduce + D2H of two device doubles
+    if (!Comm_SUM_dev(d_two, 2)) return false;
+    HIP_CHECK(hipMemcpyAsync(h_scal + 2, d_two, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    a = (REAL_TYPE)h_scal[2], b2 = (REAL_TYPE)h_scal[3];
+    return true;
+  };
+  REAL_TYPE rho_next = 0.0;
+
   for (itr = 1; itr < ItrMax; itr++) {  // :373
-    flop_count = 0.0;
-    REAL_TYPE rho = Fdot2(pcg_r, pcg_r0, flop_count);  // :376
-    flop += flop_count;
+    REAL_TYPE rho;
+    if (itr == 1) {
+      flop_count = 0.0;
+      rho = Fdot2(pcg_r, pcg_r0, flop_count);  // :376
+      flop += flop_count;
+    } else {
+      rho = rho_next;  // r.r0 was accumulated while r was written (below)
+      flop += 2.0 * npts();
+    }
     if (fabs(rho) < FLT_MIN) {  // :379-383
       itr = 0;
       break;
@@ -735,13 +754,12 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     Preconditioner(pcg_p_, pcg_p, flop_count, pc_type);  // :409
     flop += flop_count;
 
-    if (maf) calc_ax_maf_async(pcg_q, pcg_p_, size, innerFidx, gc, d_xc, d_yc, d_zc, pvt);  // :417
-    else calc_ax_async(pcg_q, pcg_p_, size, innerFidx, gc, cf);                              // :421
-    flop += (maf ? 63.0 : 13.0) * npts();
-
-    flop_count = 0.0;
-    alpha = rho / Fdot2(pcg_q, pcg_r0, flop_count);  // :427
-    flop += flop_count;
+    // :417/:421 q = A p_  and  :427 q.r0
+    calc_ax_dots_async(pcg_q, pcg_p_, pcg_r0, size, innerFidx, gc, cf, maf ? &mp : nullptr, d_res + 2);
+    flop += (maf ? 63.0 : 13.0) * npts() + 2.0 * npts();
+    REAL_TYPE q_r0, q_q;
+    if (!fetch2(d_res + 2, q_r0, q_q)) return 0;
+    alpha = rho / q_r0;  // :427
 
     REAL_TYPE r_alpha = -alpha;
     triad_async(pcg_s, pcg_q, pcg_r, r_alpha, size, innerFidx, gc);  // :434
@@ -752,25 +770,22 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     Preconditioner(pcg_s_, pcg_s, flop_count, pc_type);  // :445
     flop += flop_count;
 
-    if (maf) calc_ax_maf_async(pcg_t_, pcg_s_, size, innerFidx, gc, d_xc, d_yc, d_zc, pvt);  // :453
-    else calc_ax_async(pcg_t_, pcg_s_, size, innerFidx, gc, cf);                              // :457
-    flop += (maf ? 63.0 : 13.0) * npts();
-
-    flop_count = 0.0;
-    const REAL_TYPE ts = Fdot2(pcg_t_, pcg_s, flop_count);
-    const REAL_TYPE tt = Fdot1(pcg_t_, flop_count);
+    // :453/:457 t_ = A s_  and  :464 t_.s, t_.t_
+    calc_ax_dots_async(pcg_t_, pcg_s_, pcg_s, size, innerFidx, gc, cf, maf ? &mp : nullptr, d_res + 4);
+    flop += (maf ? 63.0 : 13.0) * npts() + 4.0 * npts();
+    REAL_TYPE ts, tt;
+    if (!fetch2(d_res + 4, ts, tt)) return 0;
     omega = ts / tt;  // :464
     r_omega = -omega;
-    flop += flop_count;
 
     bicg2_async(X, pcg_p_, pcg_s_, alpha, omega, size, innerFidx, gc);  // :470
     flop += 4.0 * npts();
-    triad_async(pcg_r, pcg_t_, pcg_s, r_omega, size, innerFidx, gc);  // :476
-    flop += 2.0 * npts();
-
-    flop_count = 0.0;
-    res = Fdot1(pcg_r, flop_count);  // :481
-    flop += flop_count;
+    // :476 r = s - omega t_  with  :481 res = r.r  and the next :376 rho = r.r0
+    triad_dots_async(pcg_r, pcg_t_, pcg_s, pcg_r0, r_omega, size, innerFidx, gc, d_res + 6);
+    flop += 2.0 * npts() + 2.0 * npts();
+    REAL_TYPE rr;
+    if (!fetch2(d_res + 6, rr, rho_next)) return 0;
+    res = rr;
 
     if (!Comm_S(X)) return 0;  // :486
     // :488 all-reduces `res` a second time although Fdot1 already did (an MPI-only double count in the reference,

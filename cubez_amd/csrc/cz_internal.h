@@ -27,6 +27,13 @@ void bicg1_async(CZ_REAL* p, const CZ_REAL* r, const CZ_REAL* q, CZ_REAL beta, C
 void bicg2_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, CZ_REAL b, const int* sz, const int* idx, int g);
 void calc_ax_async(CZ_REAL* ap, const CZ_REAL* p, const int* sz, const int* idx, int g, const CZ_REAL* cf);
 void calc_rk_async(CZ_REAL* r, const CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf);
+struct MafPtrs {
+  const CZ_REAL *xc, *yc, *zc, *pvt;
+};
+void calc_ax_dots_async(CZ_REAL* ap, const CZ_REAL* p, const CZ_REAL* y, const int* sz, const int* idx, int g, const CZ_REAL* cf,
+                        const MafPtrs* maf, double* dots_dev);
+void triad_dots_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, const CZ_REAL* w, CZ_REAL a, const int* sz, const int* idx, int g,
+                      double* dots_dev);
 void dot1_async(const CZ_REAL* p, const int* sz, const int* idx, int g, double* dst_dev);
 void dot2_async(const CZ_REAL* p, const CZ_REAL* q, const int* sz, const int* idx, int g, double* dst_dev);
 void jacobi_maf_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* xc,

@@ -75,6 +75,11 @@ struct Fin {
   int* flag = nullptr;
   int* conv_itr = nullptr;
   unsigned* counter = nullptr;  // arrival ticket, zero before every launch (the last workgroup resets it)
+  // MODE_AX only: fold the dot products that follow the SpMV in BiCGSTAB into it (cz_Poisson.cpp:421-427, 457-464):
+  // dst[0] = sum out*y, dst2[0] = sum out*out over the inner box (per-point products rounded to REAL like blas_dot1/2)
+  int ax_dots = 0;
+  const REAL* doty = nullptr;
+  double* dst2 = nullptr;
 };
 
 // 16-byte global accesses go through a native vector type so that hipcc emits one global_load/store_dwordx4
@@ -197,7 +202,10 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
   int jb = ja + g.TJ - 1;
   if (jb > g.jj1) jb = g.jj1;
 
-  double acc = 0.0;
+  double acc = 0.0, acc2 = 0.0;
+  const bool ax_dots = (MODE == MODE_AX) && fin.ax_dots;
+  const bool ldb = (MODE != MODE_AX) || ax_dots;           // does the step need the second input vector?
+  const REAL* Bsrc = (MODE == MODE_AX) ? fin.doty : B;      // b of the sweep / y of the fused dot products
 
   if (ja <= jb && fb < g.Fend) {
     // per-vector constants of this thread
@@ -266,11 +274,11 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
     }
     if (PF) {
       const REAL* Pn = P + (long long)(ja + 1) * g.PSV * V;
-      const REAL* Bc = B + (long long)ja * g.PSV * V;
+      const REAL* Bc = Bsrc + (long long)ja * g.PSV * V;
 #pragma unroll
       for (int m = 0; m < M; m++) {
         pn[m] = (f[m] < lim_ld) ? ldv<V>(Pn, f[m]) : zerov<V>();
-        if (MODE != MODE_AX) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
+        if (ldb) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
       }
     }
     __syncthreads();
@@ -283,19 +291,19 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
       if (PF) {
         if (more) {
           const REAL* Pnn = Pn + g.PSV * V;
-          const REAL* Bn = B + (long long)(jj + 1) * g.PSV * V;
+          const REAL* Bn = Bsrc + (long long)(jj + 1) * g.PSV * V;
 #pragma unroll
           for (int m = 0; m < M; m++) {
             pnn[m] = (f[m] < lim_ld) ? ldv<V>(Pnn, f[m]) : zerov<V>();
-            if (MODE != MODE_AX) bbn[m] = (f[m] < g.Fend) ? ldv<V>(Bn, f[m]) : zerov<V>();
+            if (ldb) bbn[m] = (f[m] < g.Fend) ? ldv<V>(Bn, f[m]) : zerov<V>();
           }
         }
       } else {
-        const REAL* Bc = B + (long long)jj * g.PSV * V;
+        const REAL* Bc = Bsrc + (long long)jj * g.PSV * V;
 #pragma unroll
         for (int m = 0; m < M; m++) {
           pn[m] = (f[m] < lim_ld) ? ldv<V>(Pn, f[m]) : zerov<V>();
-          if (MODE != MODE_AX) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
+          if (ldb) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
         }
       }
       // halo rows of the next centre plane (only the first R threads; R <= TB in the common case)
@@ -373,6 +381,17 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
             o.v[cc] = bb[m].v[cc] - (ss - c.dd * pp);
           }
         }
+        if (ax_dots) {
+#pragma unroll
+          for (int cc = 0; cc < V; cc++) {
+            const REAL oy = o.v[cc] * bb[m].v[cc];
+            const REAL oo = o.v[cc] * o.v[cc];
+            if (wmask & (1u << cc)) {
+              acc += (double)oy;
+              acc2 += (double)oo;
+            }
+          }
+        }
         if (MODE == MODE_RB) {
           // in place: components of the other colour / outside the box keep their value; a full-vector store
           // of unchanged bits is harmless because every element is owned by exactly one thread.
@@ -429,9 +448,14 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
     }
   }
 
-  if (MODE == MODE_JACOBI || MODE == MODE_RB) {
+  if (MODE == MODE_JACOBI || MODE == MODE_RB || ax_dots) {
     __syncthreads();
     const double s = block_sum<TB>(acc, wsum);
+    double s2 = 0.0;
+    if (ax_dots) {
+      __syncthreads();
+      s2 = block_sum<TB>(acc2, wsum);
+    }
     if (fin.dst == nullptr) {
       if (t == 0) partials[lb] = s;
     } else {
@@ -440,20 +464,30 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
         // write-through (sc1) store of the partial, drained, then the ticket: no L2 write-back fence per workgroup
         // (a release fence here flushes the XCD's dirty p' lines and cost +27 % on the whole sweep, profiles/README.md)
         __hip_atomic_store(&partials[lb], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ax_dots) __hip_atomic_store(&partials[nblk + lb], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *last_flag = (ticket == (unsigned)nblk - 1u);
       }
       __syncthreads();
       if (*last_flag) {
-        double x = 0.0;
+        double x = 0.0, x2 = 0.0;
         // every load of the handed-off partials is an sc1 (agent-scope) load
-        for (int i = t; i < nblk; i += TB) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = t; i < nblk; i += TB) {
+          x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ax_dots) x2 += __hip_atomic_load(&partials[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         const double tot = block_sum<TB>(x, wsum);
+        double tot2 = 0.0;
+        if (ax_dots) {
+          __syncthreads();
+          tot2 = block_sum<TB>(x2, wsum);
+        }
         if (t == 0) {
           double r = fin.accumulate ? fin.dst[0] + tot : tot;
           fin.dst[0] = r;
+          if (ax_dots) fin.dst2[0] = tot2;
           if (fin.do_check) {  // cz_Poisson.cpp:69-77
             r *= fin.res_normal;
             r = sqrt(r);
@@ -951,6 +985,80 @@ dot_k(const REAL* X, const REAL* Y, EGeom g, int nplanes, double* partials, doub
   }
 }
 
+// z = a*x + y on the inner box (blas_triad, cz_blas.f90:297) with the two dot products that follow it in BiCGSTAB folded
+// in: dst[0] = sum z*z (cz_Poisson.cpp:481), dst[1] = sum z*w (the next iteration's rho, :376).  Same structure as dot_k.
+template <int V>
+__global__ void __launch_bounds__(256)
+triad_dots_k(REAL* Z, const REAL* X, const REAL* Y, const REAL* W, REAL a, EGeom g, int nplanes, double* partials, double* dst,
+             unsigned* counter) {
+  __shared__ double wsum[4];
+  __shared__ int last_flag;
+  const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
+  double acc1 = 0.0, acc2 = 0.0;
+  if (f < g.Fend) {
+    const int kv = (int)(f % g.R);
+    unsigned mk = 0;
+#pragma unroll
+    for (int cc = 0; cc < V; cc++) {
+      const int kk = kv * V + cc;
+      if (kk >= g.kk0 && kk <= g.kk1) mk |= 1u << cc;
+    }
+    if (mk != 0) {
+      for (int pl = blockIdx.y; pl < nplanes; pl += gridDim.y) {
+        const long long pv = (long long)(g.jj0 + pl) * g.PSV + f;
+        const Vec<V> x = ldv<V>(X, pv), y = ldv<V>(Y, pv), w = ldv<V>(W, pv);
+        Vec<V> o;
+#pragma unroll
+        for (int cc = 0; cc < V; cc++) {
+          o.v[cc] = a * x.v[cc] + y.v[cc];
+          const REAL zz = o.v[cc] * o.v[cc];
+          const REAL zw = o.v[cc] * w.v[cc];
+          if (mk & (1u << cc)) {
+            acc1 += (double)zz;
+            acc2 += (double)zw;
+          }
+        }
+        if (mk == (1u << V) - 1) {
+          stv<V>(Z, pv, o);
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < V; cc++)
+            if (mk & (1u << cc)) Z[pv * V + cc] = o.v[cc];
+        }
+      }
+    }
+  }
+  const double s1 = block_sum<256>(acc1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<256>(acc2, wsum);
+  const int nblk = gridDim.x * gridDim.y;
+  const int me = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[me], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[nblk + me], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (last_flag) {
+    double x1 = 0.0, x2 = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+      x1 += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      x2 += __hip_atomic_load(&partials[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const double t1 = block_sum<256>(x1, wsum);
+    __syncthreads();
+    const double t2 = block_sum<256>(x2, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = t1;
+      dst[1] = t2;
+      *counter = 0u;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // bc_k (cz_solver.f90:22-191): the sin*sin table is evaluated on the HOST with the host libm -- the same sinf/sin
 // the reference's Fortran calls -- so the Dirichlet data are bit-identical to the reference's; the kernels only
@@ -1144,7 +1252,7 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
     fprintf(stderr, "czhip: k-row of %d elements needs %zu bytes of LDS (>160 KiB)\n", b.nkp, lds);
     exit(1);
   }
-  if (MODE == MODE_JACOBI || MODE == MODE_RB) ensure_partials((size_t)nblk);
+  if (MODE == MODE_JACOBI || MODE == MODE_RB || MODE == MODE_AX) ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stencil_k<V, TB, M, PF, MODE, MAF>),
@@ -1922,6 +2030,50 @@ void calc_ax_async(REAL* ap, const REAL* p, const int* sz, const int* idx, int g
 void calc_rk_async(REAL* r, const REAL* p, const REAL* b, const int* sz, const int* idx, int g, const REAL* cf) {
   const Box bx = make_box(sz, idx, g);
   if (!bx.empty) launch_stencil<MODE_RK>(p, b, r, make_coef(cf, (REAL)0), bx, 0, nullptr, nullptr);
+}
+// SpMV with the two dot products of the result folded in: dots_dev[0] = ap.y, dots_dev[1] = ap.ap
+void calc_ax_dots_async(REAL* ap, const REAL* p, const REAL* y, const int* sz, const int* idx, int g, const REAL* cf,
+                        const MafPtrs* maf, double* dots_dev) {
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty) {
+    HIP_CHECK(hipMemsetAsync(dots_dev, 0, 2 * sizeof(double), ctx.stream));
+    return;
+  }
+  Fin fin;
+  fin.dst = dots_dev, fin.dst2 = dots_dev + 1, fin.ax_dots = 1, fin.doty = y, fin.counter = ctx.counter;
+  if (maf) {
+    MafArgs ma{maf->xc, maf->yc, maf->zc, maf->pvt};
+    launch_stencil_maf<MODE_AX>(p, p, ap, (REAL)0, bx, 0, nullptr, nullptr, fin, ma);
+  } else {
+    launch_stencil<MODE_AX>(p, p, ap, make_coef(cf, (REAL)0), bx, 0, nullptr, nullptr, fin);
+  }
+}
+// z = a*x + y with dots_dev[0] = z.z, dots_dev[1] = z.w
+void triad_dots_async(REAL* z, const REAL* x, const REAL* y, const REAL* w, REAL a, const int* sz, const int* idx, int g,
+                      double* dots_dev) {
+  const Box b = make_box(sz, idx, g);
+  if (b.empty) {
+    HIP_CHECK(hipMemsetAsync(dots_dev, 0, 2 * sizeof(double), ctx.stream));
+    return;
+  }
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  ScopedTimer tm(LBL_EWISE);
+  if (vec_ok(b, {z, x, y, w})) {
+    EGeom e = make_egeom<VW>(b);
+    const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
+    const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));
+    ensure_partials((size_t)2 * gx * gy);
+    hipLaunchKernelGGL((triad_dots_k<VW>), dim3(gx, gy), dim3(256), 0, ctx.stream, z, x, y, w, a, e, nplanes, ctx.partials, dots_dev,
+                       ctx.counter);
+  } else {
+    EGeom e = make_egeom<1>(b);
+    const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
+    const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));
+    ensure_partials((size_t)2 * gx * gy);
+    hipLaunchKernelGGL((triad_dots_k<1>), dim3(gx, gy), dim3(256), 0, ctx.stream, z, x, y, w, a, e, nplanes, ctx.partials, dots_dev,
+                       ctx.counter);
+  }
+  HIP_CHECK(hipGetLastError());
 }
 void dot1_async(const REAL* p, const int* sz, const int* idx, int g, double* dst_dev) {
   launch_dot<0>(p, p, make_box(sz, idx, g), dst_dev);
