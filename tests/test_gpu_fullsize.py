@@ -1,0 +1,121 @@
+"""GPU tests (-m gpu) at BASELINE.json's full single-GPU size, 512^3 (configs[1..3]).
+
+The oracle is affordable for a few sweeps at this size (about 2 s per single-thread sweep), the rest is checked through
+size-independent properties: two independent kernel paths must agree bit for bit, scaling the inputs by a power of two
+must scale the outputs by exactly that power (the sweep is linear and the scaling is exact in binary floating point), and a
+decomposed run must reproduce the single-domain field."""
+import ctypes as C
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import cz_oracle as O
+
+pytestmark = pytest.mark.gpu
+N = 512
+
+
+def _driver(prec, solver, nit, coef, t2):
+    from cubez_amd import CZ
+    cz = CZ(prec, quiet=True)
+    cz.lib.czhip_set_tuning2(0, 0, -1, 1 if t2 else 0)
+    try:
+        assert cz.setup([N, N, N, solver, nit, coef]) == 1
+        itr = cz.solve()
+        out = (itr, cz.history(), cz.field())
+    finally:
+        cz.lib.czhip_set_tuning2(0, 0, -1, 1)
+        cz.close()
+    return out
+
+
+def test_jacobi_512_against_oracle_and_between_paths():
+    """4 sweeps of `cz 512 512 512 jacobi`: fused-pair path == single-sweep path == oracle, bit for bit."""
+    itr_a, hist_a, P_a = _driver("f32", "jacobi", 4, 0.8, t2=True)
+    itr_b, hist_b, P_b = _driver("f32", "jacobi", 4, 0.8, t2=False)
+    assert itr_a == itr_b == 5
+    assert P_a.tobytes() == P_b.tobytes()
+    assert np.allclose(hist_a, hist_b, rtol=1e-12, atol=0)
+    o = O.run((N, N, N), "jacobi", 4, 0.8, kind="oracle", prec="f32", wide=True)
+    assert o.P.tobytes() == P_a.tobytes()
+    assert np.allclose(hist_a, [r for _, r in o.history], rtol=1e-11, atol=0)
+
+
+def test_rbsor_512_fused_iteration_equals_two_colour_launches():
+    itr_a, hist_a, P_a = _driver("f32", "sor2sma", 5, 1.5, t2=True)
+    itr_b, hist_b, P_b = _driver("f32", "sor2sma", 5, 1.5, t2=False)
+    assert itr_a == itr_b == 6
+    assert P_a.tobytes() == P_b.tobytes()
+    assert np.allclose(hist_a, hist_b, rtol=1e-12, atol=0)
+
+
+def test_jacobi_512_fp64_paths_agree():
+    itr_a, hist_a, P_a = _driver("f64", "jacobi", 6, 0.8, t2=True)
+    itr_b, hist_b, P_b = _driver("f64", "jacobi", 6, 0.8, t2=False)
+    assert P_a.tobytes() == P_b.tobytes() and np.allclose(hist_a, hist_b, rtol=1e-13, atol=0)
+
+
+def test_sweep_is_exactly_linear_under_power_of_two_scaling():
+    """jacobi_(2p, 2b) == 2 * jacobi_(p, b) bit for bit, res scales by 4 (random 512^3 inputs, drop-in symbol)."""
+    from cubez_amd import CzHip
+    h = CzHip("f32")
+    sz, idx = [N, N, N], [2, N - 1, 2, N - 1, 2, N - 1]
+    rng = np.random.default_rng(42)
+    shape = (N + 4, N + 4, N + 4)
+    p = rng.uniform(-1, 1, shape).astype(np.float32)
+    b = rng.uniform(-1, 1, shape).astype(np.float32)
+    cf = np.array([1.1, 0.9, 1.05, 0.95, 1.2, 0.8, 6.3], dtype=np.float32)
+    dp, db, dw = h.alloc(sz, p), h.alloc(sz, b), h.alloc(sz)
+    r1 = h.jacobi(dp, sz, idx, cf, 0.8, db, dw)
+    out1 = dp.get()
+    dp.put(p * np.float32(2)), db.put(b * np.float32(2))
+    r2 = h.jacobi(dp, sz, idx, cf, 0.8, db, dw)
+    out2 = dp.get()
+    assert (out1 * np.float32(2)).tobytes() == out2.tobytes()
+    assert abs(r2 - 4.0 * r1) <= 1e-12 * r2
+    # a checksum of checksums: the per-plane sums of the field reproduce the total
+    s_planes = out1.astype(np.float64).sum(axis=(1, 2))
+    assert abs(s_planes.sum() - out1.astype(np.float64).sum()) <= 1e-9 * abs(s_planes).sum()
+    for a in (dp, db, dw):
+        a.free()
+
+
+def test_decomposed_512_equals_single_domain():
+    """`cz 512 512 512 jacobi 6 0.8 1 2 1` (two ranks as threads on this GPU, LOCAL transport) == the single-domain run."""
+    from cubez_amd import CZ, load
+    itr1, hist1, P1 = _driver("f32", "jacobi", 6, 0.8, t2=True)
+    lib = load("f32")
+    lib.cz_comm_local_world.restype = C.c_void_p
+    lib.cz_comm_bootstrap_local.argtypes = [C.c_void_p, C.c_int]
+    lib.cz_comm_local_world_free.argtypes = [C.c_void_p]
+    world = lib.cz_comm_local_world(2)
+    res, errs = [None, None], []
+
+    def work(r):
+        try:
+            lib.cz_comm_bootstrap_local(world, r)
+            cz = CZ("f32", quiet=True)
+            assert cz.setup([N, N, N, "jacobi", 6, 0.8, 1, 2, 1]) == 1
+            itr = cz.solve()
+            res[r] = (itr, cz.history(), cz.field(), cz.local())
+            cz.close()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    assert not errs, errs
+    lib.cz_comm_local_world_free(world)
+    g = 2
+    h1 = hashlib.sha256()
+    h2 = hashlib.sha256()
+    for itr, hist, P, loc in res:
+        assert itr == itr1 and np.allclose(hist, hist1, rtol=1e-12, atol=0)
+        (ni, nj, nk), (hi, hj, hk) = loc["size"], loc["head"]
+        own = P[g:g + nj, g:g + ni, g:g + nk]
+        ref = P1[g + hj - 1:g + hj - 1 + nj, g + hi - 1:g + hi - 1 + ni, g + hk - 1:g + hk - 1 + nk]
+        h1.update(np.ascontiguousarray(own).tobytes()), h2.update(np.ascontiguousarray(ref).tobytes())
+    assert h1.hexdigest() == h2.hexdigest()
