@@ -39,6 +39,7 @@ const char* printMethod(int t) {
     case LS_SOR2SMA: return "SOR2SMA";
     case LS_BICGSTAB: return "PBiCGSTAB";
     case LS_PSOR: return "PSOR";
+    case LS_PCR_RB: return "PCR_RB";
     case LS_JACOBI_MAF: return "JACOBI_MAF";
     case LS_SOR2SMA_MAF: return "SOR2SMA_MAF";
     case LS_BICGSTAB_MAF: return "PBiCGSTAB_MAF";
@@ -64,7 +65,7 @@ CZ::CZ() {
 
 CZ::~CZ() {
   czhip_sync();
-  REAL_TYPE* arrs[] = {WRK, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt};
+  REAL_TYPE* arrs[] = {WRK, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt, MSK};
   if (d_xc) (void)hipFree(d_xc);
   if (d_yc) (void)hipFree(d_yc);
   if (d_zc) (void)hipFree(d_zc);
@@ -105,9 +106,10 @@ void CZ::setStrPre() {
   else if (!strcasecmp(precon.c_str(), "sor2sma")) pc_type = LS_SOR2SMA;
   else if (!strcasecmp(precon.c_str(), "jacobi_maf")) pc_type = LS_JACOBI_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "sor2sma_maf")) pc_type = LS_SOR2SMA_MAF, SW_maf = 1;
+  else if (!strcasecmp(precon.c_str(), "pcr_rb")) pc_type = LS_PCR_RB;
   else if (!strcasecmp(precon.c_str(), "none")) pc_type = LS_NONE;
   else {
-    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | sor2sma | jacobi_maf | sor2sma_maf)\n", precon.c_str());
+    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | sor2sma | pcr_rb | jacobi_maf | sor2sma_maf)\n", precon.c_str());
     exit(0);
   }
 }
@@ -124,6 +126,9 @@ void CZ::setLS(const char* q) {
     ls_type = LS_BICGSTAB;
     hist_name = "pbicgstab.txt";
     setStrPre();
+  } else if (!strcasecmp(q, "pcr_rb")) {  // :707-710, line SOR by parallel cyclic reduction
+    ls_type = LS_PCR_RB;
+    hist_name = "pcr_rb.txt";
   } else if (!strcasecmp(q, "jacobi_maf")) {  // :738-760, the MAF flavours
     ls_type = LS_JACOBI_MAF;
     hist_name = "jacobi_maf.txt";
@@ -258,6 +263,14 @@ int CZ::Setup(int argc, char** argv) {
 
   ItrMax = atoi(argv[5]);  // :330
 
+  if (ls_type == LS_PCR_RB || pc_type == LS_PCR_RB) {
+    if (numProc > 1) {
+      Hostonly_ printf("pcr_rb : single-domain runs only in this build\n");
+      return 0;
+    }
+    MSK = czhip_alloc_s3d(size);            // :242
+    imask_async(MSK, size, innerFidx, gc);  // :389
+  }
   if (SW_maf) {
     // :342-363 one-dimensional grid xc[i] = (i-1)*pitch (local index; the reference adds no brick origin), uploaded once;
     // :369 search_pivot_
@@ -305,6 +318,9 @@ int CZ::Solve() {
     case LS_BICGSTAB_MAF:
       if (0 == (itr = PBiCGSTAB(res, P, RHS, flop, ls_type))) return 0;
       break;
+    case LS_PCR_RB:
+      if (0 == (itr = LSOR_PCR_RB(res, P, RHS, ItrMax, flop, ls_type))) return 0;
+      break;
     default:
       break;
   }
@@ -346,12 +362,15 @@ int CZ::Evaluate(int argc, char** argv) {
 // Bench leg: n more iterations of the stationary solver, with the complete per-iteration work of the checked loop
 // (sweep, residual reduction, convergence bookkeeping) but eps disabled so that nothing is skipped.
 int CZ::Sweeps(int n) {
-  if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA && ls_type != LS_JACOBI_MAF && ls_type != LS_SOR2SMA_MAF)) return 0;
+  if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA && ls_type != LS_JACOBI_MAF && ls_type != LS_SOR2SMA_MAF &&
+                  ls_type != LS_PCR_RB))
+    return 0;
   const double keep = eps;
   eps = -1.0;
   double res = 0.0, flop = 0.0;
   history.clear();
-  if (ls_type == LS_JACOBI || ls_type == LS_JACOBI_MAF) JACOBI(res, P, RHS, n, flop, ls_type);
+  if (ls_type == LS_PCR_RB) LSOR_PCR_RB(res, P, RHS, n, flop, ls_type);
+  else if (ls_type == LS_JACOBI || ls_type == LS_JACOBI_MAF) JACOBI(res, P, RHS, n, flop, ls_type);
   else RBSOR(res, P, RHS, n, flop, ls_type);
   eps = keep;
   sweeps_done += n;
@@ -645,6 +664,47 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   return ret;
 }
 
+// cz_Poisson.cpp:518-611.  Line SOR: every (i,j) column of one checkerboard colour is solved along k by parallel cyclic
+// reduction (pcr_rb_k), colour 0 then colour 1, in place.  Single-domain.
+int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+  (void)s_type;
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  const int n = innerFidx[K_plus] - innerFidx[K_minus] + 1;
+  const int pn = pcr_num_stage(n);  // :535-538
+  if (pn < 0) {
+    printf("error : number of stage\n");
+    exit(0);
+  }
+  if (converge_check) {
+    ensure_hist(itr_max + 2);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+  }
+  int itr;
+  for (itr = 1; itr <= itr_max; itr++) {
+    for (int color = 0; color < 2; color++) pcr_rb_async(X, MSK, B, size, innerFidx, gc, pn, color, ac1, d_res, color);  // :573-578
+    flop += npts() * (12.0 + (pn - 1) * 14.0);
+    if (converge_check) {
+      // the line solves are long launches: a host round trip per iteration is negligible here, so the reference's
+      // sequential test (:584-601) is kept as is
+      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+      HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (h_flag[0]) break;
+    }
+  }
+  if (converge_check) {
+    const int n_exec = itr > itr_max ? itr_max : itr;
+    const size_t base = history.size();
+    history.resize(base + n_exec);
+    HIP_CHECK(hipMemcpy(history.data() + base, d_hist + 1, (size_t)n_exec * sizeof(double), hipMemcpyDeviceToHost));
+    res = history.back();
+  } else {
+    czhip_sync();
+  }
+  return itr;
+}
+
 // cz_Poisson.cpp:239-270.  The reference reduces in REAL on every rank and all-reduces the REAL; here the double
 // partial sums are all-reduced and rounded to REAL once.
 REAL_TYPE CZ::Fdot1(REAL_TYPE* x, double& flop) {
@@ -688,6 +748,9 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
     case LS_SOR2SMA:
     case LS_SOR2SMA_MAF:
       RBSOR(res, xx, bb, lc_max, flop, s_type, false);
+      break;
+    case LS_PCR_RB:
+      LSOR_PCR_RB(res, xx, bb, lc_max, flop, s_type, false);
       break;
     default: {
       const size_t n = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE);

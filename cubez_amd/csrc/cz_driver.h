@@ -13,7 +13,7 @@ typedef CZ_REAL REAL_TYPE;  // cz_Define.h:28-37
 #define GUIDE 2             // cz_Define.h:40
 
 // cz_Define.h:68-89 (only the solvers of the hot path are accepted; the others are rejected by setLS)
-enum LinearSolver { LS_NONE = 0, LS_PSOR = 1, LS_SOR2SMA, LS_BICGSTAB, LS_JACOBI, LS_SOR2SMA_MAF = 12, LS_BICGSTAB_MAF, LS_JACOBI_MAF };
+enum LinearSolver { LS_NONE = 0, LS_PSOR = 1, LS_SOR2SMA, LS_BICGSTAB, LS_JACOBI, LS_PCR_RB = 8, LS_SOR2SMA_MAF = 12, LS_BICGSTAB_MAF, LS_JACOBI_MAF };
 
 // CB_Define_stub.h:64-70 / cz_fparam.fi:10-16
 enum { I_minus = 0, I_plus, J_minus, J_plus, K_minus, K_plus };
@@ -49,6 +49,7 @@ class CZ {
   REAL_TYPE *WRK = nullptr, *P = nullptr, *RHS = nullptr;
   // MAF flavour (cz.h:113-118, cz_Evaluate.cpp:245-253, 342-369): 1-D grid on the device, pivot array
   int SW_maf = 0;
+  REAL_TYPE* MSK = nullptr;  // cz.h:95, cz_Evaluate.cpp:389 (line-SOR solvers)
   REAL_TYPE *d_xc = nullptr, *d_yc = nullptr, *d_zc = nullptr, *pvt = nullptr;
   REAL_TYPE *pcg_p = nullptr, *pcg_p_ = nullptr, *pcg_r = nullptr, *pcg_r0 = nullptr, *pcg_q = nullptr, *pcg_s = nullptr,
             *pcg_s_ = nullptr, *pcg_t_ = nullptr;
@@ -93,6 +94,7 @@ class CZ {
              bool x_is_zero = false);
   bool xx_shell_is_zero(const REAL_TYPE* xx) const;
   int RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
+  int LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   REAL_TYPE Fdot1(REAL_TYPE* x, double& flop);
   REAL_TYPE Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop);
   void Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type);

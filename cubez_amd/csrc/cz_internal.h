@@ -36,6 +36,10 @@ void triad_dots_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, const CZ_R
                       double* dots_dev);
 void dot1_async(const CZ_REAL* p, const int* sz, const int* idx, int g, double* dst_dev);
 void dot2_async(const CZ_REAL* p, const CZ_REAL* q, const int* sz, const int* idx, int g, double* dst_dev);
+int pcr_num_stage(int n);
+void pcr_rb_async(CZ_REAL* x, const CZ_REAL* msk, const CZ_REAL* rhs, const int* sz, const int* idx, int g, int pn, int color,
+                  CZ_REAL omg, double* res_dev, int accumulate);
+void imask_async(CZ_REAL* x, const int* sz, const int* idx, int g);
 void jacobi_maf_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* xc,
                       const CZ_REAL* yc, const CZ_REAL* zc, CZ_REAL omg, double* res_dev, const int* skip, int check, double res_normal,
                       double eps, int itr, double* hist, int* flag, int* conv_itr);

@@ -810,6 +810,167 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Line SOR by parallel cyclic reduction, pcr_rb (cz_solver.f90:497-662).
+// One wave64 per (i,j) column of the active checkerboard colour, four columns per workgroup.  The column's tridiagonal
+// system along k lives in LDS (a, c, d and their successors a1, c1, d1, ping-ponged instead of copied back); lanes
+// stride over k, so every global access is coalesced along the unit-stride axis.  pn-1 reduction stages of stride
+// 2^(p-1), then the 2x2 systems of stride 2^(pn-1), then the relaxation -- operation for operation the reference's
+// arithmetic (serial build: entries outside kst..ked are zero, kept in two pad slots).  sum dp^2 is accumulated in double.
+// ------------------------------------------------------------------------------------------------------------
+struct PcrGeom {
+  int nkp, nip;                 // padded extents
+  int kk0, n;                   // padded index of kst, number of unknowns per column
+  int ii0, ni, jj0, nj;         // inner (i,j) range in padded indices / counts
+  int ist1, jst1;               // 1-based ist, jst (colour rule mod(i+j,2) == color uses 1-based indices)
+  int pn, color;
+  int nhalf;                    // columns of one colour per j row (upper bound)
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, double* partials,
+         double* dst, int accumulate, unsigned* counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
+  REAL* base = reinterpret_cast<REAL*>(smem) + (size_t)wave * 6 * LD;
+  REAL* A[2] = {base, base + 3 * LD};          // [buf][a | c | d]
+  double* wsum = reinterpret_cast<double*>(reinterpret_cast<REAL*>(smem) + (size_t)NW * 6 * LD + 4);
+  wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
+
+  const long long col = (long long)blockIdx.x * NW + wave;  // column ordinal among the colour's columns
+  const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+  bool active = jrow < g.nj;
+  int ii = 0, jj = 0;
+  if (active) {
+    const int j1 = g.jst1 + jrow;
+    int i1 = g.ist1 + 2 * ih;
+    if (((i1 + j1) & 1) != g.color) i1 += 1;   // first i of this colour in the row
+    active = (i1 - g.ist1) < g.ni;
+    ii = g.ii0 + (i1 - g.ist1);
+    jj = g.jj0 + jrow;
+  }
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const size_t c0 = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;  // element (kst, i, j)
+  double acc = 0.0;
+
+  // ---- set-up: coefficients and source term (:545-568)
+  if (active) {
+    REAL* a = A[0];
+    REAL* c = a + LD;
+    REAL* d = c + LD;
+    if (lane == 0) {
+      for (int b = 0; b < 2; b++)
+        for (int v = 0; v < 3; v++) A[b][v * LD] = (REAL)0, A[b][v * LD + n + 1] = (REAL)0;
+    }
+    for (int k = lane; k < n; k += 64) {
+      const size_t e = c0 + k;
+      a[k + 1] = (k == 0) ? (REAL)0 : -r;
+      c[k + 1] = (k == n - 1) ? (REAL)0 : -r;
+      REAL dv = ((X[e - plane] + X[e + plane] + X[e - rowlen] + X[e + rowlen] - RHS[e]) * r) * MSK[e];
+      if (k == 0) dv = (dv + X[e - 1] * r) * MSK[e];
+      if (k == n - 1) dv = (dv + X[e + 1] * r) * MSK[e];
+      d[k + 1] = dv;
+    }
+  }
+  __syncthreads();
+  // ---- PCR stages (:572-595)
+  int cur = 0;
+  for (int p = 1; p <= g.pn - 1; p++) {
+    const int s = 1 << (p - 1);
+    if (active) {
+      const REAL* a = A[cur];
+      const REAL* c = a + LD;
+      const REAL* d = c + LD;
+      REAL* a1 = A[cur ^ 1];
+      REAL* c1 = a1 + LD;
+      REAL* d1 = c1 + LD;
+      for (int k = lane; k < n; k += 64) {
+        const int x = k + 1;
+        const int kl = (k - s >= 0) ? x - s : 0;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL ap = a[x], cp = c[x];
+        const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * c[kl] - cp * a[kr]);
+        a1[x] = -e * ap * a[kl];
+        c1[x] = -e * cp * c[kr];
+        d1[x] = e * (d[x] - ap * d[kl] - cp * d[kr]);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- 2x2 systems of the last stage (:599-616), result into the d slot of the other buffer
+  {
+    const int s = 1 << (g.pn - 1);
+    if (active) {
+      const REAL* a = A[cur];
+      const REAL* c = a + LD;
+      const REAL* d = c + LD;
+      REAL* d1 = A[cur ^ 1] + 2 * LD;
+      for (int k = lane; k < s && k < n; k += 64) {
+        const int x = k + 1;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL cc1 = c[x], aa2 = a[kr], f1 = d[x], f2 = d[kr];
+        const REAL jj2 = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+        const REAL dd1 = (f1 - cc1 * f2) * jj2;
+        const REAL dd2 = (f2 - aa2 * f1) * jj2;
+        d1[x] = dd1;
+        if (kr <= n) d1[kr] = dd2;  // (the reference also stores the k = ked+1 dummy, which nothing reads)
+      }
+    }
+    __syncthreads();
+  }
+  // ---- relaxation (:626-633)
+  if (active) {
+    const REAL* d1 = A[cur ^ 1] + 2 * LD;
+    for (int k = lane; k < n; k += 64) {
+      const size_t e = c0 + k;
+      const REAL pp = X[e];
+      const REAL dp = (d1[k + 1] - pp) * omg * MSK[e];
+      X[e] = pp + dp;
+      const REAL d2 = dp * dp;
+      acc += (double)d2;
+    }
+  }
+  // ---- residual: partial per workgroup, fixed-order sum by the last one (write-through hand-off as in stencil_k)
+  __syncthreads();
+  const double sblk = block_sum<64 * NW>(acc, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 8);
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64 * NW) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<64 * NW>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
+// imask_k (cz_blas.f90:24-104): 1 on the inner box, 0 elsewhere (whole padded array)
+__global__ void __launch_bounds__(256)
+imask_k(REAL* X, int nkp, int nip, int njp, int kk0, int kk1, int ii0, int ii1, int jj0, int jj1) {
+  const size_t n = (size_t)nkp * nip * njp;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int kk = (int)(e % nkp);
+    const size_t r = e / nkp;
+    const int ii = (int)(r % nip), jj = (int)(r / nip);
+    const bool in = kk >= kk0 && kk <= kk1 && ii >= ii0 && ii <= ii1 && jj >= jj0 && jj <= jj1;
+    X[e] = in ? (REAL)1.0 : (REAL)0.0;
+  }
+}
+
 // sum of n partials in a fixed order -> dst[0] (= or +=).  One workgroup: deterministic.
 __global__ void __launch_bounds__(1024)
 reduce_partials_k(const double* __restrict__ partials, int n, double* __restrict__ dst, int accumulate,
@@ -1134,8 +1295,8 @@ struct Ctx {
 };
 thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
 
-enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_COUNT };
-const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2"};
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_COUNT };
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb"};
 
 struct ScopedTimer {
   bool on;
@@ -1546,6 +1707,63 @@ void launch_pivot(REAL* pvt, const Box& b, const MafArgs& ma) {
     dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
     hipLaunchKernelGGL((pivot_k<1>), grid, dim3(256), 0, ctx.stream, pvt, e, ma, b.nkp, b.nip);
   }
+  HIP_CHECK(hipGetLastError());
+}
+}  // namespace
+
+namespace {
+int num_stage(int n) {  // cz.h:293-300
+  int b = 1;
+  for (int i = 1; i < 20; i++) {
+    b *= 2;
+    if (n < b) return i;
+  }
+  return -1;
+}
+
+template <int NW>
+bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, double* res_dev, int accumulate, size_t lds_cap) {
+  const long long ncol = (long long)g.nhalf * g.nj;
+  const unsigned nblk = (unsigned)((ncol + NW - 1) / NW);
+  const size_t lds = (size_t)NW * 6 * (g.n + 2) * sizeof(REAL) + 64 + 16 * sizeof(double);
+  if (lds > lds_cap) return false;
+  ensure_partials(nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  ScopedTimer tm(LBL_PCR);
+  hipLaunchKernelGGL((pcr_rb_k<NW>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.partials, res_dev, accumulate,
+                     ctx.counter);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int color, REAL omg,
+                   double* res_dev, int accumulate) {
+  if (b.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  PcrGeom g;
+  g.nkp = b.nkp, g.nip = b.nip;
+  g.kk0 = b.kk0, g.n = b.kk1 - b.kk0 + 1;
+  g.ii0 = b.ii0, g.ni = b.ii1 - b.ii0 + 1, g.jj0 = b.jj0, g.nj = b.jj1 - b.jj0 + 1;
+  g.ist1 = idx[0], g.jst1 = idx[2];
+  g.pn = pn, g.color = color;
+  g.nhalf = (g.ni + 1) / 2 + 1;
+  // one wave per k-line, NW lines per workgroup; each line keeps 2 x (a, c, d) of n+2 entries in LDS.  Prefer four
+  // lines per group while two groups still fit a CU's 160 KiB, then fall back to fewer lines per group for long lines.
+  if (try_pcr_rb<4>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
+  if (try_pcr_rb<2>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
+  if (try_pcr_rb<1>(x, msk, rhs, g, omg, res_dev, accumulate, 160 * 1024)) return;
+  fprintf(stderr, "czhip: pcr_rb: a k-line of %d unknowns does not fit the 160 KiB of LDS\n", g.n);
+  exit(1);
+}
+
+void launch_imask(REAL* x, const Box& b) {
+  hipLaunchKernelGGL(imask_k, dim3(2048), dim3(256), 0, ctx.stream, x, b.nkp, b.nip, b.njp, b.kk0, b.kk1, b.ii0, b.ii1, b.jj0, b.jj1);
   HIP_CHECK(hipGetLastError());
 }
 }  // namespace
@@ -2006,6 +2224,28 @@ void search_pivot_(CZ_REAL* pvt, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL*
   HIP_CHECK(hipStreamSynchronize(ctx.stream));
 }
 
+// ---- line SOR by PCR, drop-in symbols (cz_Ffunc.h:60-77 pcr_rb_, :440-443 imask_k_).  The six 1-D work arrays of the
+// reference are host scratch of its CPU implementation; the GPU keeps the line systems in LDS and does not touch them.
+void pcr_rb_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a,
+             CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop) {
+  ensure_init();
+  (void)ofst, (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1;
+  const double nk = idx[5] - idx[4] + 1;
+  *flop += (double)((idx[3] - idx[2] + 1) * (idx[1] - idx[0] + 1)) *
+           (nk * 6.0 + nk * (*pn - 1) * 14.0 + (double)(1 << (*pn - 1)) * 9.0 + nk * 6.0 + 6.0) * 0.5;  // cz_solver.f90:523-531
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_pcr_rb(x, msk, rhs, bx, idx, *pn, *color, *omg, ctx.scal_dev + 0, 0);
+  *res += read_scalar(0);
+}
+
+void imask_k_(CZ_REAL* x, int* sz, int* idx, int* g) {
+  ensure_init();
+  Box bx = make_box(sz, idx, *g);
+  launch_imask(x, bx);
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+}
+
 }  // extern "C"
 
 // internal hooks for the driver (cz_driver.cpp): asynchronous forms of the blas kernels
@@ -2081,6 +2321,12 @@ void dot1_async(const REAL* p, const int* sz, const int* idx, int g, double* dst
 void dot2_async(const REAL* p, const REAL* q, const int* sz, const int* idx, int g, double* dst_dev) {
   launch_dot<1>(p, q, make_box(sz, idx, g), dst_dev);
 }
+int pcr_num_stage(int n) { return num_stage(n); }
+void pcr_rb_async(REAL* x, const REAL* msk, const REAL* rhs, const int* sz, const int* idx, int g, int pn, int color, REAL omg,
+                  double* res_dev, int accumulate) {
+  launch_pcr_rb(x, msk, rhs, make_box(sz, idx, g), idx, pn, color, omg, res_dev, accumulate);
+}
+void imask_async(REAL* x, const int* sz, const int* idx, int g) { launch_imask(x, make_box(sz, idx, g)); }
 // MAF flavour, device-resident coordinates (xc|yc|zc and pvt are device pointers)
 void jacobi_maf_async(const REAL* p_in, REAL* p_out, const REAL* b, const int* sz, const int* idx, int g, const REAL* xc,
                       const REAL* yc, const REAL* zc, REAL omg, double* res_dev, const int* skip, int check, double res_normal,

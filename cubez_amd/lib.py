@@ -14,7 +14,7 @@ _LOADED: dict = {}
 ABI_SYMBOLS = [
     "bc_k_", "jacobi_", "psor2sma_core_", "blas_clear_", "blas_copy_", "blas_triad_", "blas_dot1_", "blas_dot2_",
     "blas_bicg_1_", "blas_bicg_2_", "blas_calc_ax_", "blas_calc_rk_",
-    "jacobi_maf_", "psor2sma_core_maf_", "calc_rk_maf_", "calc_ax_maf_", "search_pivot_",
+    "jacobi_maf_", "psor2sma_core_maf_", "calc_rk_maf_", "calc_ax_maf_", "search_pivot_", "pcr_rb_", "imask_k_",
     "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
     "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
     "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async", "czhip_jacobi_checked_async",
@@ -203,6 +203,19 @@ class CzHip:
         (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
         (xk, xp), (yk, yp), (zk, zp) = self._r(x), self._r(y), self._r(z)
         self.lib.search_pivot_(C.c_void_p(pvt.ptr), szp, idxp, C.byref(g), xp, yp, zp)
+
+    def imask_k(self, x, sz, idx):
+        (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
+        self.lib.imask_k_(C.c_void_p(x.ptr), szp, idxp, C.byref(g))
+
+    def pcr_rb(self, sz, idx, pn, ofst, color, x, msk, rhs, omg, res=0.0):
+        (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
+        w = [np.zeros(sz[2] + 4, dtype=self.real) for _ in range(6)]
+        r, fl, pnc, o, c = C.c_double(res), C.c_double(0.0), C.c_int(pn), C.c_int(ofst), C.c_int(color)
+        self.lib.pcr_rb_(szp, idxp, C.byref(g), C.byref(pnc), C.byref(o), C.byref(c), C.c_void_p(x.ptr), C.c_void_p(msk.ptr),
+                         C.c_void_p(rhs.ptr), *[v.ctypes.data_as(C.c_void_p) for v in w], self._s(omg), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
 
     def blas_clear(self, x, sz):
         (_, szp), g = self._i(sz), C.c_int(GUIDE)

@@ -91,6 +91,15 @@ void calc_ax_maf_(CZ_REAL* ap, CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X
 /* cz_Ffunc.h:547-553 <- cz_blas.f90:947-1039  pvt = 1 / max |row entries| */
 void search_pivot_(CZ_REAL* pvt, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z);
 
+/* Line SOR by parallel cyclic reduction.  x, msk, rhs are device arrays; the six work arrays are
+ * the reference's host scratch and are ignored (the line systems live in LDS).  Semantics = the reference's serial build
+ * (its OpenMP form reads uninitialised private work arrays, see oracle/Makefile). */
+/* cz_Ffunc.h:60-77 <- cz_solver.f90:497-662 */
+void pcr_rb_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a,
+             CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop);
+/* cz_Ffunc.h:440-443 <- cz_blas.f90:24-104 */
+void imask_k_(CZ_REAL* x, int* sz, int* idx, int* g);
+
 /* ------------------------------------------------------------------------------------------------
  * Part 2 -- runtime
  * ---------------------------------------------------------------------------------------------- */

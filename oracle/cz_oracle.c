@@ -536,3 +536,86 @@ void oracle_search_pivot(REAL* pvt, const int* sz, const int* idx, const int* gp
         pvt[IDX(k, i, j)] = (REAL)1.0 / ss;
       }
 }
+
+/* ==================================================================================================
+ * Line SOR by parallel cyclic reduction: pcr_rb, cz_solver.f90:497-662.
+ * For every (i,j) column of one checkerboard colour (mod(i+j,2) == color; `ofst` is not used by the reference) the
+ * tridiagonal system along k (a = c = -1/6, unit diagonal) is reduced by pn-1 PCR stages of stride 2^(p-1), the
+ * remaining 2x2 systems of stride 2^(pn-1) are inverted directly, and x is relaxed in place.
+ * Work arrays a, c, d, a1, c1, d1 are (-1:sz(3)+2); entries outside kst..ked are never written and stay 0 (the driver
+ * allocates them zero-filled, cz_Evaluate.cpp:257-262).
+ * ================================================================================================== */
+#define W1(arr, k) arr[(k) + 1]
+
+/* imask_k : cz_blas.f90:24-104   1 on the inner box, 0 elsewhere */
+void oracle_imask_k(REAL* x, const int* sz, const int* idx, const int* gp) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const size_t n = (size_t)(sz[0] + 2 * g) * (size_t)(sz[1] + 2 * g) * (size_t)(sz[2] + 2 * g);
+  for (size_t m = 0; m < n; m++) x[m] = (REAL)0.0;
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) x[IDX(k, i, j)] = (REAL)1.0;
+}
+
+void oracle_pcr_rb(const int* sz, const int* idx, const int* gp, const int* pn_p, const int* ofst, const int* color_p, REAL* x,
+                   const REAL* msk, const REAL* rhs, REAL* a, REAL* c, REAL* d, REAL* a1, REAL* c1, REAL* d1,
+                   const REAL* omg_p, double* res, double* flop) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  (void)ofst;
+  const int pn = *pn_p, color = *color_p;
+  const REAL omg = *omg_p;
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  *flop += (double)((jed - jst + 1) * (ied - ist + 1)) *
+           ((ked - kst + 1) * 6.0 + (ked - kst + 1) * (pn - 1) * 14.0 + (double)(1 << (pn - 1)) * 9.0 + (ked - kst + 1) * 6.0 + 6.0) *
+           0.5; /* :523-531 */
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++) {
+      if ((i + j) % 2 != color) continue; /* :540 */
+      W1(a, kst) = (REAL)0.0;
+      for (int k = kst + 1; k <= ked; k++) W1(a, k) = -r;
+      for (int k = kst; k <= ked - 1; k++) W1(c, k) = -r;
+      W1(c, ked) = (REAL)0.0;
+      for (int k = kst; k <= ked; k++) /* :558-564 */
+        W1(d, k) = ((x[IDX(k, i, j - 1)] + x[IDX(k, i, j + 1)] + x[IDX(k, i - 1, j)] + x[IDX(k, i + 1, j)] - rhs[IDX(k, i, j)]) * r) *
+                   msk[IDX(k, i, j)];
+      W1(d, kst) = (W1(d, kst) + x[IDX(kst - 1, i, j)] * r) * msk[IDX(kst, i, j)]; /* :567-568 */
+      W1(d, ked) = (W1(d, ked) + x[IDX(ked + 1, i, j)] * r) * msk[IDX(ked, i, j)];
+      for (int p = 1; p <= pn - 1; p++) { /* :572-595 */
+        const int s = 1 << (p - 1);
+        for (int k = kst; k <= ked; k++) {
+          const int kl = (k - s > kst - 1) ? k - s : kst - 1;
+          const int kr = (k + s < ked + 1) ? k + s : ked + 1;
+          const REAL ap = W1(a, k), cp = W1(c, k);
+          const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * W1(c, kl) - cp * W1(a, kr));
+          W1(a1, k) = -e * ap * W1(a, kl);
+          W1(c1, k) = -e * cp * W1(c, kr);
+          W1(d1, k) = e * (W1(d, k) - ap * W1(d, kl) - cp * W1(d, kr));
+        }
+        for (int k = kst; k <= ked; k++) {
+          W1(a, k) = W1(a1, k);
+          W1(c, k) = W1(c1, k);
+          W1(d, k) = W1(d1, k);
+        }
+      }
+      { /* :599-616 final 2x2 systems */
+        const int s = 1 << (pn - 1);
+        for (int k = kst; k <= kst + s - 1; k++) {
+          const int kr = (k + s < ked + 1) ? k + s : ked + 1;
+          const REAL cc1 = W1(c, k), aa2 = W1(a, kr), f1 = W1(d, k), f2 = W1(d, kr);
+          const REAL jj = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+          const REAL dd1 = (f1 - cc1 * f2) * jj;
+          const REAL dd2 = (f2 - aa2 * f1) * jj;
+          W1(d1, k) = dd1;
+          W1(d1, kr) = dd2;
+        }
+      }
+      for (int k = kst; k <= ked; k++) { /* :626-633 */
+        const REAL pp = x[IDX(k, i, j)];
+        const REAL dp = (W1(d1, k) - pp) * omg * msk[IDX(k, i, j)];
+        x[IDX(k, i, j)] = pp + dp;
+        *res = *res + (double)(dp * dp);
+      }
+    }
+}

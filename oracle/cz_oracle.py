@@ -39,6 +39,8 @@ def lib_path(kind: str, prec: str) -> str:
         return os.path.join(_HERE, f"liboracle_{prec}.so")
     if kind == "ref":
         return os.path.join(_HERE, "_ref", f"libczref_{prec}.so")
+    if kind == "ref_serial":  # the reference built without OpenMP (pins the PCR line solvers, see oracle/Makefile)
+        return os.path.join(_HERE, "_ref", f"libczref_serial_{prec}.so")
     raise ValueError(kind)
 
 
@@ -216,6 +218,21 @@ class Kernels:
         sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
         self._f("search_pivot")(self._rp(pvt), self._ip(sz), self._ip(idx), C.byref(g), self._rp(x), self._rp(y), self._rp(z))
 
+    # -- line SOR by parallel cyclic reduction (cz_solver.f90:497-662), pinned against the SERIAL reference build
+    def imask_k(self, x, sz, idx):
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        self._f("imask_k")(self._rp(x), self._ip(sz), self._ip(idx), C.byref(g))
+
+    def pcr_rb(self, sz, idx, pn, ofst, color, x, msk, rhs, omg, res=0.0):
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        w = [np.zeros(sz[2] + 4, dtype=self.real) for _ in range(6)]  # WA, WC, WD, WAA, WCC, WDD (cz_Evaluate.cpp:257-262)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        pnc, o, c = C.c_int(pn), C.c_int(ofst), C.c_int(color)
+        self._f("pcr_rb")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), C.byref(o), C.byref(c), self._rp(x), self._rp(msk),
+                          self._rp(rhs), *[self._rp(v) for v in w], self._rs(omg), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
     def exact_t(self, sz, e, dh, org):
         sz, g = _ia(sz), C.c_int(GUIDE)
         org = np.ascontiguousarray(org, dtype=self.real)
@@ -232,6 +249,16 @@ class Kernels:
 # ----------------------------------------------------------------------------------
 # host loops (single domain)
 # ----------------------------------------------------------------------------------
+def get_num_stage(n):
+    """cz.h:293-300: smallest i with n < 2**i."""
+    b = 1
+    for i in range(1, 20):
+        b *= 2
+        if n < b:
+            return i
+    return -1
+
+
 def range_inner_index(size, nID):
     """cz_miscel.cpp:20-52 -> (innerFidx[6], number of inner points)."""
     ist = jst = kst = 2
@@ -337,12 +364,35 @@ class CZ:
             itr += 1
         return itr, res
 
+    # cz_Poisson.cpp:518-611
+    def LSOR_PCR_RB(self, X, B, itr_max, converge_check=True):
+        k, res, itr = self.k, 0.0, 1
+        n = self.idx[5] - self.idx[4] + 1
+        pn = get_num_stage(n)
+        if not hasattr(self, "MSK"):
+            self.MSK = k.alloc(self.size)
+            k.imask_k(self.MSK, self.size, self.idx)  # cz_Evaluate.cpp:389
+        while itr <= itr_max:
+            res = 0.0
+            for color in (0, 1):
+                res = k.pcr_rb(self.size, self.idx, pn, 0, color, X, self.MSK, B, self.ac1, res=res)
+            if converge_check:
+                res = math.sqrt(res * self.res_normal)
+                self.history.append((itr, res))
+                k.bc_k(self.size, X, self.pitch, self.origin, self.nID)
+                if res < self.eps:
+                    break
+            itr += 1
+        return itr, res
+
     # cz_Poisson.cpp:273-322
     def Preconditioner(self, xx, bb, pc):
         if pc in ("jacobi", "jacobi_maf"):
             self.JACOBI(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
         elif pc in ("sor2sma", "sor2sma_maf"):
             self.RBSOR(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
+        elif pc == "pcr_rb":
+            self.LSOR_PCR_RB(xx, bb, LC_MAX, converge_check=False)
         else:
             self.k.blas_copy(xx, bb, self.size)
 
@@ -415,9 +465,12 @@ class CZ:
 
     def error_max(self):
         """debug epilogue, cz_Evaluate.cpp:550-563."""
-        e = self.k.alloc(self.size)
-        self.k.exact_t(self.size, e, self.pitch, self.origin)
-        return self.k.err_t(self.size, self.idx, self.P, e)
+        # the serial reference build rounds exact_t's sinh/sin one ulp differently from the OpenMP build (other vector
+        # math path); the OpenMP build is the reference binary, so its exact_t is the one fixtures hold
+        k = Kernels("ref", self.k.prec) if self.k.kind == "ref_serial" else self.k
+        e = k.alloc(self.size)
+        k.exact_t(self.size, e, self.pitch, self.origin)
+        return k.err_t(self.size, self.idx, self.P, e)
 
 
 def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", with_error=False, wide=False) -> Result:
@@ -428,6 +481,8 @@ def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", wit
         itr, res = cz.JACOBI(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
     elif solver in ("sor2sma", "sor2sma_maf"):
         itr, res = cz.RBSOR(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
+    elif solver == "pcr_rb":
+        itr, res = cz.LSOR_PCR_RB(cz.P, cz.RHS, itr_max)
     elif solver in ("pbicgstab", "pbicgstab_maf"):
         itr, res = cz.PBiCGSTAB(cz.P, cz.RHS, itr_max, precond or "none", maf=solver.endswith("_maf"))
     else:

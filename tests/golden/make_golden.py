@@ -129,6 +129,26 @@ def kernel_vectors(prec):
     out["maf_rk_in"] = rkm.copy()
     k.calc_rk_maf(rkm, p, b, sz, idx, xc, yc, zc, pv)
     out["maf_rk"] = rkm
+    # line SOR by PCR (cz_solver.f90:497-662), from the SERIAL reference build (see oracle/Makefile: the OpenMP form of
+    # these routines reads uninitialised private work arrays)
+    ks = O.Kernels("ref_serial", prec)
+    for (ni, nj, nk) in ((9, 8, 13), (12, 10, 37), (6, 7, 64)):
+        szp = [ni, nj, nk]
+        idp = [2, ni - 1, 2, nj - 1, 2, nk - 1]
+        shp = (nj + 4, ni + 4, nk + 4)
+        xx = rng.uniform(-1.0, 1.0, size=shp).astype(R)
+        rh = rng.uniform(-1.0, 1.0, size=shp).astype(R)
+        mk = rng.uniform(-1.0, 1.0, size=shp).astype(R)
+        ks.imask_k(mk, szp, idp)
+        tag = f"pcr_{ni}x{nj}x{nk}"
+        out[tag + "_x_in"], out[tag + "_rhs"], out[tag + "_msk"] = xx.copy(), rh, mk
+        pn = O.get_num_stage(idp[5] - idp[4] + 1)
+        r = 0.0
+        for color in (0, 1):
+            r = ks.pcr_rb(szp, idp, pn, 0, color, xx, mk, rh, 1.1, res=r)
+            out[tag + f"_x_c{color}"] = xx.copy()
+            out[tag + f"_res_c{color}"] = np.array(r)
+        out[tag + "_flop"] = np.array(ks.last_flop)
     np.savez_compressed(os.path.join(HERE, f"kernels_{prec}.npz"), **out)
 
 
@@ -160,13 +180,19 @@ SOLVER_CASES = [
     ((32, 32, 32), "pbicgstab_maf", 100, 0.8, "jacobi_maf", "f64", None),
     ((32, 32, 32), "pbicgstab_maf", 100, 1.5, "sor2sma_maf", "f64", None),
     ((32, 32, 32), "pbicgstab_maf", 100, 0.8, "jacobi", "f32", None),
+    # line SOR by PCR, serial reference build
+    ((32, 32, 32), "pcr_rb", 40, 1.2, None, "f32", None),
+    ((24, 20, 36), "pcr_rb", 30, 1.1, None, "f64", None),
+    ((64, 64, 64), "pcr_rb", 100000, 1.5, None, "f64", None),
+    ((32, 32, 32), "pbicgstab", 100, 1.2, "pcr_rb", "f64", None),
 ]
 
 
 def solver_cases():
     index = []
     for gsz, solver, itmax, coef, pc, prec, cli in SOLVER_CASES:
-        r = O.run(gsz, solver, itmax, coef, pc, kind="ref", prec=prec, with_error=True)
+        kind = "ref_serial" if "pcr" in solver or (pc and "pcr" in pc) else "ref"
+        r = O.run(gsz, solver, itmax, coef, pc, kind=kind, prec=prec, with_error=True)
         tag = f"{solver}{'_' + pc if pc else ''}_{gsz[0]}x{gsz[1]}x{gsz[2]}_{prec}"
         with open(os.path.join(HERE, f"hist_{tag}.txt"), "w") as f:
             f.write(r.history_text())

@@ -389,3 +389,48 @@ def test_maf_random_boxes_vs_oracle(prec, box):
     o1, o2 = sentinel.copy(), h.alloc(sz, sentinel)
     ko.calc_rk_maf(o1, p, b, sz, idx, xc, yc, zc, pv1), h.calc_rk_maf(o2, dp, db, sz, idx, xc, yc, zc, pv2)
     assert _beq(o2.get(), o1)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_pcr_rb_golden_vectors(prec):
+    """line SOR by parallel cyclic reduction: vectors from the reference's serial build."""
+    g = np.load(os.path.join(GOLDEN, f"kernels_{prec}.npz"))
+    h = _hip(prec)
+    for (ni, nj, nk) in ((9, 8, 13), (12, 10, 37), (6, 7, 64)):
+        sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+        tag = f"pcr_{ni}x{nj}x{nk}"
+        x, rhs = h.alloc(sz, g[tag + "_x_in"]), h.alloc(sz, g[tag + "_rhs"])
+        msk = h.alloc(sz, g[tag + "_x_in"])  # any content: imask_k_ overwrites the whole array
+        h.imask_k(msk, sz, idx)
+        assert _beq(msk.get(), g[tag + "_msk"])
+        pn = O.get_num_stage(idx[5] - idx[4] + 1)
+        r = 0.0
+        for color in (0, 1):
+            r = h.pcr_rb(sz, idx, pn, 0, color, x, msk, rhs, 1.1, res=r)
+            assert _beq(x.get(), g[tag + f"_x_c{color}"]), (tag, color)
+            assert _rel(r, float(g[tag + f"_res_c{color}"])) < 1e-12
+        assert h.last_flop == float(g[tag + "_flop"])
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", [(40, 36, 60), (33, 21, 124), (20, 9, 252), (17, 12, 510), (6, 5, 1020)],
+                         ids=lambda b: "x".join(map(str, b)))
+def test_pcr_rb_random_boxes_vs_oracle(prec, box):
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    x1, dx, dm, dr = x0.copy(), h.alloc(sz, x0), h.alloc(sz, msk), h.alloc(sz, rhs)
+    r1 = r2 = 0.0
+    for it in range(2):
+        for color in (0, 1):
+            r1 = ko.pcr_rb(sz, idx, pn, 0, color, x1, msk, rhs, 1.3, res=r1)
+            r2 = h.pcr_rb(sz, idx, pn, 0, color, dx, dm, dr, 1.3, res=r2)
+            assert _beq(dx.get(), x1), (it, color)
+    assert _rel(r2, r1) < 1e-12

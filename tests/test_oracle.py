@@ -89,6 +89,18 @@ def test_kernels_match_golden(prec):
     k.calc_rk_maf(a, p, b, sz, idx, xc, yc, zc, pv)
     assert _beq(a, g["maf_rk"])
 
+    # line SOR by PCR (fixtures from the reference's serial build)
+    for (ni, nj, nk) in ((9, 8, 13), (12, 10, 37), (6, 7, 64)):
+        szp, idp, tag = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1], f"pcr_{ni}x{nj}x{nk}"
+        xx, mk = g[tag + "_x_in"].copy(), g[tag + "_x_in"].copy()
+        k.imask_k(mk, szp, idp)
+        assert _beq(mk, g[tag + "_msk"])
+        r = 0.0
+        for color in (0, 1):
+            r = k.pcr_rb(szp, idp, O.get_num_stage(idp[5] - idp[4] + 1), 0, color, xx, mk, g[tag + "_rhs"], 1.1, res=r)
+            assert _beq(xx, g[tag + f"_x_c{color}"]) and r == float(g[tag + f"_res_c{color}"])
+        assert k.last_flop == float(g[tag + "_flop"])
+
 
 def test_wide_accumulators_consistent():
     """the *_w entry points return the same REAL result plus a double accumulation of the same terms."""
