@@ -61,6 +61,8 @@ CZ::CZ() {
   HIP_CHECK(hipMemset(d_flag, 0, (2 + 2 * POLL_SLOTS) * sizeof(int)));
   HIP_CHECK(hipHostMalloc(&h_scal, 16 * sizeof(double), hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(&h_flag, 2 * POLL_SLOTS * sizeof(int), hipHostMallocDefault));
+  const char* ov = getenv("CZ_OVERLAP");
+  if (ov) overlap = atoi(ov);
 }
 
 CZ::~CZ() {
@@ -77,6 +79,9 @@ CZ::~CZ() {
   (void)hipHostFree(h_scal);
   (void)hipHostFree(h_flag);
   if (comm) comm_destroy(comm);
+  if (ev_shell) (void)hipEventDestroy(ev_shell);
+  if (ev_comm) (void)hipEventDestroy(ev_comm);
+  if (comm_stream) (void)hipStreamDestroy(comm_stream);
   if (fph) fclose(fph);
 }
 
@@ -241,6 +246,7 @@ int CZ::Setup(int argc, char** argv) {
   }
 
   double sum_r = range_inner_index();  // :222-224
+  plan_overlap();
   if (!Comm_SUM_1(&sum_r)) return 0;
   res_normal = 1.0 / (double)sum_r;
 
@@ -403,6 +409,43 @@ bool CZ::Comm_SUM_1(double* host_val) {
   return true;
 }
 
+// Split of the inner box for overlapped exchanges (pair_plan, cz_kernels.hip); n_shell = 0 when there is nothing to overlap.
+void CZ::plan_overlap() {
+  n_shell = 0;
+  if (numProc == 1 || !overlap) return;
+  n_shell = pair_plan(innerFidx, nID, shell_boxes, interior, interior1);
+  if (n_shell == 0) return;
+  if (!comm_stream) {
+    HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_shell, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
+  }
+}
+
+// One fused pair of sweeps (rb < 0) or one red-black iteration (rb = colour parity) of a decomposed run, src -> dst, with
+// the two-layer exchange of dst hidden behind the interior:
+//   stream      : shell slabs -> [ev_shell] -> interior ------------------------> wait ev_comm -> (all-reduce, test)
+//   comm_stream :                 wait ev_shell -> pack, send/recv, unpack -> [ev_comm]
+// The slabs and the interior write disjoint cells of dst and read only src; the unpack writes ghost cells of dst.
+// Returns false (nothing launched) when the split does not apply; the caller then takes the unsplit path.
+bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip) {
+  if (n_shell == 0) return false;
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  if (!pair_probe(src, dst, B, size, interior, interior1, gc)) return false;
+  pair_shell_async(src, dst, B, size, idx1, shell_boxes, n_shell, gc, cf, ac1, rb, skip);
+  HIP_CHECK(hipEventRecord(ev_shell, st));
+  if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, d_res, 1, skip)) {
+    printf("error : interior launch refused after a successful probe\n");
+    exit(1);
+  }
+  HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_shell, 0));
+  if (!comm_halo2(comm, dst, skip, comm_stream)) return false;
+  HIP_CHECK(hipEventRecord(ev_comm, comm_stream));
+  HIP_CHECK(hipStreamWaitEvent(st, ev_comm, 0));
+  return true;
+}
+
 // Drain the queue and turn the device-side bookkeeping into the loop's return values.
 int CZ::finish_stationary(int itr_max, int first_itr, bool converge_check, double& res) {
   (void)first_itr;
@@ -471,6 +514,13 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
         // not taken (geometry, tuning): do the blas_clear_ the caller skipped (guide cells / faces are zero already)
         const size_t nbytes = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
         HIP_CHECK(hipMemsetAsync(src, 0, nbytes, st));
+      }
+    }
+    if (!done && can_pair && itr + 1 <= itr_max && numProc > 1 && pair_overlapped(src, dst, B, idx1, -1, skip)) {
+      done = 2;  // :58 twice, :63 hidden behind the interior
+      if (converge_check) {
+        if (!Comm_SUM_dev(d_res, 2, skip)) return 0;
+        czhip_check2_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
     }
     if (!done && can_pair && itr + 1 <= itr_max) {
@@ -592,7 +642,17 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   for (itr = 1; itr <= itr_max && !stop; itr++) {
     const bool in_kernel_check = converge_check && numProc == 1;
     bool done = false;
-    if (fused) {
+    if (fused && numProc > 1 && pair_overlapped(buf[cur], buf[cur ^ 1], B, idx1, rb_par(gc, innerFidx, ip), skip)) {
+      flop += 18.0 * npts();
+      if (converge_check) {
+        if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
+        czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+      }
+      cur ^= 1;
+      n_fused++;
+      done = true;
+    }
+    if (fused && !done) {
       REAL_TYPE* src = buf[cur];
       REAL_TYPE* dst = buf[cur ^ 1];
       if (czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,

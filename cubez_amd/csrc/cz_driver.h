@@ -63,6 +63,13 @@ class CZ {
   double solve_seconds = 0.0;
   int sweeps_done = 0;           // stationary-solver iterations executed so far (bench leg)
   CommCtx* comm = nullptr;
+  // decomposed runs: the exchange of a fused pair runs on comm_stream while the interior is being swept
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_shell = nullptr, ev_comm = nullptr;
+  int overlap = 1;               // CZ_OVERLAP=0 turns it off (exchange after the whole sweep, same results)
+  int n_shell = 0;               // shell boxes (cells within two layers of a rank-internal face), 1-based index ranges
+  int shell_boxes[36];
+  int interior[6], interior1[6]; // the rest of the inner box / its first-sweep range
 
   // device-side convergence bookkeeping (cz_Poisson.cpp:67-77 moved to the GPU)
   double* d_res = nullptr;       // [0] sum dp^2 of the current iteration, [1..7] dot products
@@ -104,6 +111,8 @@ class CZ {
   bool Comm_S(REAL_TYPE* X, const int* skip_flag = nullptr);
   bool Comm_S2(REAL_TYPE* X, const int* skip_flag = nullptr);  // two layers + edges (fused Jacobi pairs)
   bool Comm_SUM_dev(double* d_val, int count, const int* skip_flag = nullptr);
+  void plan_overlap();
+  bool pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip);
   bool Comm_SUM_1(double* host_val);
 
   int finish_stationary(int itr_max, int first_itr, bool converge_check, double& res);

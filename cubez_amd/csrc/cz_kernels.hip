@@ -541,6 +541,8 @@ struct Fin2 {
   double* dst = nullptr;   // [0] <- sum of sweep n+1, [1] <- sum of sweep n+2
   int do_check = 0, itr = 0;  // itr = iteration number of sweep n+1
   int single = 0;             // RB: both stages belong to ONE iteration: dst[0] = sum1 + sum2, one bookkeeping step
+  const double* extra = nullptr;  // per-workgroup sums of the shell launch of a split pass (pair_shell_k): n_extra first-stage
+  int n_extra = 0;                // sums followed by n_extra second-stage sums, added to this launch's own
   double res_normal = 0.0, eps = 0.0;
   double* hist = nullptr;
   int* flag = nullptr;
@@ -771,6 +773,10 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
       x1 += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       x2 += __hip_atomic_load(&partials[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    for (int i = t; i < fin.n_extra; i += TB) {  // written by an earlier launch on this stream
+      x1 += fin.extra[i];
+      x2 += fin.extra[fin.n_extra + i];
+    }
     __syncthreads();
     const double t1 = block_sum<TB>(x1, wsum);
     __syncthreads();
@@ -807,6 +813,146 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
       }
       *fin.counter = 0u;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The same two-stage update on thin boxes: the cells a decomposed brick owes its neighbours (two layers behind every
+// rank-internal face).  The driver runs this first, starts the halo exchange on a second stream and lets jacobi2_k
+// work on the interior meanwhile.  A slab two cells thick has no plane to march along, so it is cut into
+// small 3-D tiles instead: a workgroup stages the tile of u with two halo layers in LDS, applies stage 1 to the tile
+// plus one layer (LDS), then stage 2 to the tile.  Tile shapes follow the slab's orientation (long in k wherever k is
+// not the thin axis, so that global accesses stay coalesced).  Same scalar operation sequence as relax_vec<1> => the
+// fields are bit-identical to an unsplit jacobi2_k launch.
+// ------------------------------------------------------------------------------------------------------------
+struct ShellBox {
+  int i0, j0, k0, ni, nj, nk;  // padded 0-based start, extent
+  int kind;                    // tile shape: 0 = 64x4x2 (k,i,j; J slabs), 1 = 64x2x4 (I slabs), 2 = 2x16x16 (K slabs), 3 = 32x4x4
+  int ntk, nti, ntj;           // tiles per axis
+};
+struct ShellTab {
+  int n;
+  ShellBox b[6];
+  int ii0a, ii1a, jj0a, jj1a, kk0a, kk1a;  // stage-1 box of the brick (inner box grown across rank-internal faces)
+  int nkp, nip, njp;
+  int par;
+};
+
+// all tiles of one box that this workgroup takes; the tile shape is a compile-time constant (index arithmetic without divisions)
+template <int RB, int TK, int TI, int TJ>
+__device__ __forceinline__ void shell_tiles(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, const Coef& c,
+                                            const ShellTab& s, const ShellBox& d, REAL* lu, double& acc1, double& acc2) {
+  constexpr int UK = TK + 4, UI = TI + 4, UJ = TJ + 4;  // u tile: two halo layers
+  constexpr int VK = TK + 2, VI = TI + 2, VJ = TJ + 2;  // v tile: one halo layer
+  REAL* lv = lu + UK * UI * UJ;
+  const int t = threadIdx.x;
+  const int si = s.nkp, sj = s.nkp * s.nip;  // a halo'd tile spans < 2^31 elements: 32-bit offsets from the tile origin
+  const int ntiles = d.ntk * d.nti * d.ntj;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tkx = tile % d.ntk, tr = tile / d.ntk;
+    const int K0 = d.k0 + tkx * TK, I0 = d.i0 + (tr % d.nti) * TI, J0 = d.j0 + (tr / d.nti) * TJ;
+    const int ck = min(TK, d.k0 + d.nk - K0), ci = min(TI, d.i0 + d.ni - I0), cj = min(TJ, d.j0 + d.nj - J0);  // clipped core
+    const size_t org = (size_t)(K0 - 2) + (size_t)(I0 - 2) * s.nkp + (size_t)(J0 - 2) * s.nkp * s.nip;  // first cell of the u tile
+    const REAL* __restrict__ Ut = U + org;
+    const REAL* __restrict__ Bt = B + org;
+    REAL* __restrict__ Wt = W + org;
+    // ---- every global read of the tile is issued before the first use (one memory latency per tile, not one per element)
+    constexpr int NU = (UK * UI * UJ + 255) / 256, NV = (VK * VI * VJ + 255) / 256, NO = (TK * TI * TJ + 255) / 256;
+    REAL ru[NU], rb1[NV], rb2[NO];
+#pragma unroll
+    for (int n = 0; n < NU; n++) {
+      const int e = t + n * 256;
+      const int k = e % UK, r = e / UK, i = r % UI, j = r / UI;
+      const int gk = K0 - 2 + k, gi = I0 - 2 + i, gj = J0 - 2 + j;
+      ru[n] = (e < UK * UI * UJ && gk < s.nkp && gi < s.nip && gj < s.njp) ? Ut[k + i * si + j * sj] : (REAL)0;
+    }
+    unsigned in1 = 0;  // bit n: stage 1 applies to this thread's n-th point of the v tile
+#pragma unroll
+    for (int n = 0; n < NV; n++) {
+      const int e = t + n * 256;
+      const int k = e % VK, r = e / VK, i = r % VI, j = r / VI;
+      const int gk = K0 - 1 + k, gi = I0 - 1 + i, gj = J0 - 1 + j;
+      const bool inside = e < VK * VI * VJ && gi >= s.ii0a && gi <= s.ii1a && gj >= s.jj0a && gj <= s.jj1a && gk >= s.kk0a && gk <= s.kk1a &&
+                          !(RB && ((gk + gi + gj + s.par) & 1));
+      rb1[n] = inside ? Bt[(k + 1) + (i + 1) * si + (j + 1) * sj] : (REAL)0;
+      if (inside) in1 |= 1u << n;
+    }
+#pragma unroll
+    for (int n = 0; n < NO; n++) {
+      const int e = t + n * 256;
+      const int k = e % TK, r = e / TK, i = r % TI, j = r / TI;
+      const bool live = e < TK * TI * TJ && k < ck && i < ci && j < cj;
+      rb2[n] = live ? Bt[(k + 2) + (i + 2) * si + (j + 2) * sj] : (REAL)0;
+    }
+#pragma unroll
+    for (int n = 0; n < NU; n++)
+      if (t + n * 256 < UK * UI * UJ) lu[t + n * 256] = ru[n];
+    __syncthreads();
+    // ---- stage 1 on the core plus one layer
+#pragma unroll
+    for (int n = 0; n < NV; n++) {
+      const int e = t + n * 256;
+      if (e >= VK * VI * VJ) continue;
+      const int k = e % VK, r = e / VK, i = r % VI, j = r / VI;
+      const int cu = (k + 1) + UK * ((i + 1) + UI * (j + 1));
+      REAL v = lu[cu];
+      if (in1 & (1u << n)) {
+        const bool core = k >= 1 && k <= ck && i >= 1 && i <= ci && j >= 1 && j <= cj;
+        Vec<1> pc, im, ip, pm, pn, bb;
+        pc.v[0] = v, im.v[0] = lu[cu - UK], ip.v[0] = lu[cu + UK], pm.v[0] = lu[cu - UK * UI], pn.v[0] = lu[cu + UK * UI];
+        bb.v[0] = rb1[n];
+        v = relax_vec<1>(pc, im, ip, pm, pn, lu[cu - 1], lu[cu + 1], bb, c, 1u, core ? 1u : 0u, acc1).v[0];
+      }
+      lv[e] = v;
+    }
+    __syncthreads();
+    // ---- stage 2 on the core
+#pragma unroll
+    for (int n = 0; n < NO; n++) {
+      const int e = t + n * 256;
+      const int k = e % TK, r = e / TK, i = r % TI, j = r / TI;
+      if (e >= TK * TI * TJ || k >= ck || i >= ci || j >= cj) continue;
+      const int gk = K0 + k, gi = I0 + i, gj = J0 + j;
+      const int cv = (k + 1) + VK * ((i + 1) + VI * (j + 1));
+      REAL o = lv[cv];
+      if (!(RB && !((gk + gi + gj + s.par) & 1))) {  // RB: colour 0 passes through stage 2
+        Vec<1> pc, im, ip, pm, pn, bb;
+        pc.v[0] = o, im.v[0] = lv[cv - VK], ip.v[0] = lv[cv + VK], pm.v[0] = lv[cv - VK * VI], pn.v[0] = lv[cv + VK * VI];
+        bb.v[0] = rb2[n];
+        o = relax_vec<1>(pc, im, ip, pm, pn, lv[cv - 1], lv[cv + 1], bb, c, 1u, 1u, acc2).v[0];
+      }
+      Wt[(k + 2) + (i + 2) * si + (j + 2) * sj] = o;
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB>
+__global__ void __launch_bounds__(256)
+pair_shell_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, ShellTab s, double* partials,
+             const int* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[8];
+  const int t = threadIdx.x;
+  const ShellBox d = s.b[blockIdx.y];
+  REAL* lu = reinterpret_cast<REAL*>(smem);
+  double acc1 = 0.0, acc2 = 0.0;
+  switch (d.kind) {  // uniform per workgroup
+    case 0: shell_tiles<RB, 64, 4, 2>(U, B, W, c, s, d, lu, acc1, acc2); break;
+    case 1: shell_tiles<RB, 64, 2, 4>(U, B, W, c, s, d, lu, acc1, acc2); break;
+    case 2: shell_tiles<RB, 2, 16, 16>(U, B, W, c, s, d, lu, acc1, acc2); break;
+    default: shell_tiles<RB, 32, 4, 4>(U, B, W, c, s, d, lu, acc1, acc2); break;
+  }
+  // residuals: one pair of sums per workgroup; the interior launch that follows on the stream adds them to its own
+  const int nblk = gridDim.x * gridDim.y;
+  const int lb = blockIdx.y * gridDim.x + blockIdx.x;
+  const double s1 = block_sum<256>(acc1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<256>(acc2, wsum);
+  if (t == 0) {
+    partials[lb] = s1;
+    partials[nblk + lb] = s2;
   }
 }
 
@@ -1279,6 +1425,8 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   double* partials = nullptr;   // device
+  double* shell_partials = nullptr;  // per-workgroup sums of the last pair_shell_k launch, folded in by the interior launch
+  int shell_pending = 0;
   size_t partials_cap = 0;
   unsigned* counter = nullptr;  // arrival ticket of the in-kernel finalisation
   REAL* xyz = nullptr;           // device copies of the host coordinate arrays X, Y, Z handed to the *_maf_ drop-in symbols
@@ -1295,8 +1443,8 @@ struct Ctx {
 };
 thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
 
-enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_COUNT };
-const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb"};
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_SHELL, LBL_COUNT };
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb", "pair_shell"};
 
 struct ScopedTimer {
   bool on;
@@ -1478,7 +1626,7 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 // two fused sweeps; returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
 template <int TB, int MV, int RB>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
-                         const int* skip, const Fin2& fin_in, int par, int zero_u) {
+                         const int* skip, const Fin2& fin_in, int par, int zero_u, bool probe) {
   constexpr int V = VW;
   Geom2 g;
   g.R = b.nkp / V;
@@ -1505,6 +1653,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   const long long nblk = (long long)nchunk * g.nseg;
   const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double);
   if (lds > 160 * 1024) return false;
+  if (probe) return true;
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1524,7 +1673,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
 
 template <int RB>
 bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
-                    const Fin2& fin, int par = 0, int zero_u = 0) {
+                    const Fin2& fin, int par = 0, int zero_u = 0, bool probe = false) {
   if (!vec_ok(b, {U, B, W})) return false;
   // the stage-1 box may exceed the output box by at most one layer per side
   if (ba.ii0 < b.ii0 - 1 || ba.ii0 > b.ii0 || ba.ii1 > b.ii1 + 1 || ba.ii1 < b.ii1 || ba.jj0 < b.jj0 - 1 || ba.jj0 > b.jj0 ||
@@ -1534,10 +1683,49 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
   const Tuning& tu = ctx.tune;
 #define CZ_INST2(TB_, MV_) \
-  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u);
+  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u, probe);
   CZ_INST2(256, 4) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(1024, 2)
 #undef CZ_INST2
-  return launch_jacobi2_inst<512, 2, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u);
+  return launch_jacobi2_inst<512, 2, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u, probe);
+}
+
+// the shell boxes of a decomposed brick, all in one launch (pair_shell_k); boxes: n x (ist,ied,jst,jed,kst,ked), 1-based
+template <int RB>
+void launch_pair_shell(const REAL* U, const REAL* B, REAL* W, const Coef& c, const int* sz, int g, const Box& ba, const int* boxes, int n,
+                       int par, const int* skip) {
+  ShellTab s;
+  s.n = n;
+  int most_tiles = 0;
+  size_t lds = 0;
+  for (int m = 0; m < n; m++) {
+    const Box b = make_box(sz, boxes + 6 * m, g);
+    if (b.empty || b.ii0 < 2 || b.jj0 < 2 || b.kk0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3 || b.kk1 > b.nkp - 3) {
+      fprintf(stderr, "czhip: pair_shell: box %d is empty or closer than two cells to the array edge\n", m);
+      exit(1);
+    }
+    ShellBox& d = s.b[m];
+    d.i0 = b.ii0, d.j0 = b.jj0, d.k0 = b.kk0;
+    d.ni = b.ii1 - b.ii0 + 1, d.nj = b.jj1 - b.jj0 + 1, d.nk = b.kk1 - b.kk0 + 1;
+    // tile shape by orientation: long in k (coalesced rows) unless k is the thin axis
+    int tk, ti, tj;
+    if (d.nk == 2) d.kind = 2, tk = 2, ti = 16, tj = 16;
+    else if (d.nj == 2) d.kind = 0, tk = 64, ti = 4, tj = 2;
+    else if (d.ni == 2) d.kind = 1, tk = 64, ti = 2, tj = 4;
+    else d.kind = 3, tk = 32, ti = 4, tj = 4;
+    d.ntk = (d.nk + tk - 1) / tk, d.nti = (d.ni + ti - 1) / ti, d.ntj = (d.nj + tj - 1) / tj;
+    most_tiles = std::max(most_tiles, d.ntk * d.nti * d.ntj);
+    lds = std::max(lds, sizeof(REAL) * ((size_t)(tk + 4) * (ti + 4) * (tj + 4) + (size_t)(tk + 2) * (ti + 2) * (tj + 2)));
+  }
+  s.ii0a = ba.ii0, s.ii1a = ba.ii1, s.jj0a = ba.jj0, s.jj1a = ba.jj1, s.kk0a = ba.kk0, s.kk1a = ba.kk1;
+  s.nkp = ba.nkp, s.nip = ba.nip, s.njp = ba.njp;
+  s.par = par;
+  const unsigned gx = (unsigned)std::min(most_tiles, 2048);
+  {
+    ScopedTimer tm(LBL_SHELL);
+    hipLaunchKernelGGL((pair_shell_k<RB>), dim3(gx, (unsigned)n), dim3(256), lds, ctx.stream, U, B, W, c, s, ctx.shell_partials, skip);
+  }
+  HIP_CHECK(hipGetLastError());
+  ctx.shell_pending = (int)(gx * n);
 }
 
 Coef make_coef_omg(REAL omg) {
@@ -1801,6 +1989,7 @@ int czhip_init(int device) {
   HIP_CHECK(hipMemset(ctx.counter, 0, 64));
   ctx.ready = true;
   ensure_partials(65536);
+  HIP_CHECK(hipMalloc(&ctx.shell_partials, (size_t)2 * 2048 * 6 * sizeof(double)));
   if (const char* ff = getenv("CZHIP_FUSE_FIN")) ctx.tune.fuse_fin = atoi(ff);
   if (const char* t2 = getenv("CZHIP_T2")) {  // "enable[,threads,mv,tj]"
     int en = 1, a = 0, b2 = 0, c2 = -1;
@@ -1821,6 +2010,7 @@ void czhip_finalize(void) {
   for (auto& kv : ctx.bc_tabs) (void)hipFree(kv.second);
   ctx.bc_tabs.clear();
   (void)hipFree(ctx.partials);
+  (void)hipFree(ctx.shell_partials);
   (void)hipFree(ctx.scal_dev);
   (void)hipHostFree(ctx.scal_host);
   (void)hipStreamDestroy(ctx.stream);
@@ -2020,6 +2210,20 @@ int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int
     fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
   }
   return launch_jacobi2<1>(u, b, w, make_coef(cf, omg), bx, ba, hist_dev ? flag_dev : skip_flag_dev, fin, rb_parity(g, idx, ofst, 0)) ? 1 : 0;
+}
+
+// The fused pass split the way a decomposed brick runs it: the slabs behind the faces with nID[f] >= 0 first
+// (pair_shell_k), then the interior (jacobi2_k) -- same result as the unsplit launch.  rb_ofst < 0: two Jacobi sweeps,
+// res_dev[0..1]; rb_ofst >= 0: one red-black iteration with that ofst, res_dev[0].  Returns 0 when nothing was launched.
+int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1,
+                           const int* nID, int g, const CZ_REAL* cf, CZ_REAL omg, int rb_ofst, double* res_dev) {
+  ensure_init();
+  int boxes[36], in0[6], in1[6];
+  const int n = czhip_internal::pair_plan(idx, nID, boxes, in0, in1);
+  if (n == 0 || !czhip_internal::pair_probe(u, w, b, sz, in0, in1, g)) return 0;
+  const int rb = rb_ofst >= 0 ? rb_parity(g, idx, rb_ofst, 0) : -1;
+  czhip_internal::pair_shell_async(u, w, b, sz, idx1 ? idx1 : idx, boxes, n, g, cf, omg, rb, nullptr);
+  return czhip_internal::pair_box_async(u, w, b, sz, in0, in1, g, cf, omg, rb, res_dev, 1, nullptr);
 }
 
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable) {
@@ -2366,6 +2570,67 @@ void search_pivot_async(REAL* pvt, const int* sz, const int* idx, int g, const R
   MafArgs ma{xc, yc, zc, nullptr};
   launch_pivot(pvt, bx, ma);
 }
+// ---- a fused pair of sweeps split into shell + interior launches (decomposed runs).  rb < 0: two Jacobi
+// sweeps, res_dev[0..1]; rb >= 0: one red-black iteration with colour parity `rb` (rb_par), res_dev[0].
+int rb_par(int g, const int* idx, int ofst) { return rb_parity(g, idx, ofst, 0); }
+
+// Split of an inner box for overlapped exchanges: the cells within two layers of a rank-internal face (nID[f] >= 0; what
+// the neighbours receive as their two ghost layers) form up to six disjoint slabs -- J faces first (contiguous planes), then
+// I, then K -- and the rest is the interior.  Returns the number of slabs (0: nothing to split or the box is too thin);
+// boxes: n x (ist,ied,jst,jed,kst,ked); interior1 = first-sweep range of the interior.
+int pair_plan(const int* O, const int* nID, int* boxes, int* interior, int* interior1) {
+  for (int a = 0; a < 3; a++) {
+    interior[2 * a] = O[2 * a] + (nID[2 * a] >= 0 ? 2 : 0);
+    interior[2 * a + 1] = O[2 * a + 1] - (nID[2 * a + 1] >= 0 ? 2 : 0);
+    if (interior[2 * a + 1] - interior[2 * a] + 1 < 2) return 0;
+  }
+  for (int f = 0; f < 6; f++) interior1[f] = interior[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
+  int n = 0;
+  auto add = [&](int i0, int i1, int j0, int j1, int k0, int k1) {
+    int* b = boxes + 6 * n++;
+    b[0] = i0, b[1] = i1, b[2] = j0, b[3] = j1, b[4] = k0, b[5] = k1;
+  };
+  const int* I = interior;
+  if (nID[2] >= 0) add(O[0], O[1], O[2], O[2] + 1, O[4], O[5]);
+  if (nID[3] >= 0) add(O[0], O[1], O[3] - 1, O[3], O[4], O[5]);
+  if (nID[0] >= 0) add(O[0], O[0] + 1, I[2], I[3], O[4], O[5]);
+  if (nID[1] >= 0) add(O[1] - 1, O[1], I[2], I[3], O[4], O[5]);
+  if (nID[4] >= 0) add(I[0], I[1], I[2], I[3], O[4], O[4] + 1);
+  if (nID[5] >= 0) add(I[0], I[1], I[2], I[3], O[5] - 1, O[5]);
+  return n;
+}
+
+int pair_probe(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g) {
+  ensure_init();
+  if (!ctx.tune.fuse_fin || g < 2) return 0;
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty) return 0;
+  const Box ba = make_box(sz, idx1, g);
+  return launch_jacobi2<0>(u, b, w, Coef(), bx, ba, nullptr, Fin2(), 0, 0, true) ? 1 : 0;
+}
+
+void pair_shell_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx1_brick, const int* boxes, int n, int g,
+                      const REAL* cf, REAL omg, int rb, const int* skip) {
+  ensure_init();
+  const Box ba = make_box(sz, idx1_brick, g);
+  if (rb >= 0) launch_pair_shell<1>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, rb, skip);
+  else launch_pair_shell<0>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, 0, skip);
+}
+
+int pair_box_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g, const REAL* cf,
+                   REAL omg, int rb, double* res_dev, int with_shell, const int* skip) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, g);
+  const Box ba = make_box(sz, idx1, g);
+  Fin2 fin;
+  fin.dst = res_dev;
+  fin.single = rb >= 0;
+  if (with_shell) fin.extra = ctx.shell_partials, fin.n_extra = ctx.shell_pending;
+  ctx.shell_pending = 0;
+  if (rb >= 0) return launch_jacobi2<1>(u, b, w, make_coef(cf, omg), bx, ba, skip, fin, rb) ? 1 : 0;
+  return launch_jacobi2<0>(u, b, w, make_coef(cf, omg), bx, ba, skip, fin) ? 1 : 0;
+}
+
 void copy_shell_async(REAL* dst, const REAL* src, const int* sz, const int* idx, int g) {
   ensure_init();
   const int nkp = sz[2] + 2 * g, nip = sz[0] + 2 * g, njp = sz[1] + 2 * g;

@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
     "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
     "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async", "czhip_jacobi_checked_async",
-    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_use_t2", "czhip_rbsor2_async", "czhip_jacobi2_from_zero_async", "czhip_check2_async",
+    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_use_t2", "czhip_rbsor2_async", "czhip_jacobi2_from_zero_async", "czhip_check2_async", "czhip_pair_split_async",
     "cz_create", "cz_destroy", "cz_evaluate", "cz_setup", "cz_solve", "cz_sweeps", "cz_result_iter", "cz_result_res",
     "cz_history", "cz_field", "cz_local_size", "cz_error_max", "cz_set_quiet", "cz_last_solve_seconds", "cz_kernel_ms",
     "cz_set_debug", "czhip_timing", "czhip_timing_read",
@@ -114,33 +114,61 @@ class CzHip:
         self.lib.czhip_sync()
 
     # -- part 3 (two fused sweeps)
-    def jacobi2(self, u, w, b, sz, idx, cf, omg):
+    def jacobi2(self, u, w, b, sz, idx, cf, omg, idx1=None, read=True):
         """u -> w = two Jacobi sweeps in one launch; returns (launched, res_first, res_second)."""
         (_, szp), (_, idxp), (_, cfp) = self._i(sz), self._i(idx), self._r(cf)
+        idx1p = self._i(idx1)[1] if idx1 is not None else None
         if not hasattr(self, "_dres"):
             self._dres = self.lib.czhip_alloc_s3d((C.c_int * 3)(4, 4, 4))
         self.lib.czhip_jacobi2_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                  C.c_void_p, self.creal, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
-        ok = self.lib.czhip_jacobi2_async(u.ptr, w.ptr, b.ptr, szp, idxp, None, GUIDE, cfp, float(omg), self._dres, 0.0, 0.0, 0,
+        ok = self.lib.czhip_jacobi2_async(u.ptr, w.ptr, b.ptr, szp, idxp, idx1p, GUIDE, cfp, float(omg), self._dres, 0.0, 0.0, 0,
                                           None, None, None, None)
+        if not read:
+            return bool(ok), None, None
         out = (C.c_double * 2)()
         self.lib.czhip_d2h(out, self._dres, 16)
         return bool(ok), out[0], out[1]
 
-    def rbsor2(self, u, w, b, sz, idx, cf, ofst, omg):
+    def rbsor2(self, u, w, b, sz, idx, cf, ofst, omg, idx1=None):
         """u -> w = one red-black iteration (colour 0 then 1) in one launch; returns (launched, res)."""
         (_, szp), (_, idxp), (_, cfp) = self._i(sz), self._i(idx), self._r(cf)
+        idx1p = self._i(idx1)[1] if idx1 is not None else None
         if not hasattr(self, "_dres"):
             self._dres = self.lib.czhip_alloc_s3d((C.c_int * 3)(4, 4, 4))
         self.lib.czhip_rbsor2_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                 C.c_void_p, C.c_int, self.creal, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        ok = self.lib.czhip_rbsor2_async(u.ptr, w.ptr, b.ptr, szp, idxp, None, GUIDE, cfp, int(ofst), float(omg), self._dres, 0.0,
+        ok = self.lib.czhip_rbsor2_async(u.ptr, w.ptr, b.ptr, szp, idxp, idx1p, GUIDE, cfp, int(ofst), float(omg), self._dres, 0.0,
                                          0.0, 0, None, None, None, None)
         out = (C.c_double * 2)()
         self.lib.czhip_d2h(out, self._dres, 16)
         return bool(ok), out[0]
+
+    def pair_split(self, u, w, b, sz, idx, idx1, nID, cf, omg, rb_ofst=-1, read=True):
+        """the fused pass as shell slabs + interior (what a decomposed brick runs); returns (launched, res0, res1)."""
+        (_, szp), (_, idxp), (_, idx1p), (_, nidp), (_, cfp) = self._i(sz), self._i(idx), self._i(idx1), self._i(nID), self._r(cf)
+        if not hasattr(self, "_dres"):
+            self._dres = self.lib.czhip_alloc_s3d((C.c_int * 3)(4, 4, 4))
+        self.lib.czhip_pair_split_async.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_void_p, self.creal, C.c_int, C.c_void_p]
+        ok = self.lib.czhip_pair_split_async(u.ptr, w.ptr, b.ptr, szp, idxp, idx1p, nidp, GUIDE, cfp, float(omg), int(rb_ofst), self._dres)
+        if not read:  # leave the queue running (timing loops)
+            return bool(ok), None, None
+        out = (C.c_double * 2)()
+        self.lib.czhip_d2h(out, self._dres, 16)
+        return bool(ok), out[0], out[1]
+
+    def timing(self, enable: bool):
+        """HIP-event timing of the library's launches, per label (czhip_timing)."""
+        self.lib.czhip_timing(1 if enable else 0)
+
+    def timing_read(self, label: str):
+        """(number of launches, total ms) recorded under `label` since timing was enabled."""
+        tot = C.c_double(0.0)
+        self.lib.czhip_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+        n = self.lib.czhip_timing_read(label.encode(), C.byref(tot))
+        return n, tot.value
 
     def set_tuning2(self, threads=0, mv=0, tj=-1, enable=-1) -> bool:
         return self.lib.czhip_set_tuning2(int(threads), int(mv), int(tj), int(enable)) == 0

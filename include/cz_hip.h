@@ -170,6 +170,13 @@ int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const in
 int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
                        const CZ_REAL* cf, int ofst, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr,
                        double* hist_dev, int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev);
+/* The fused pass split the way a decomposed brick runs it (replaces the reference's "sweep, then Comm_S",
+ * cz_Poisson.cpp:58-63): first the slabs two cells thick behind every face with nID[f] >= 0 (the cells the neighbours
+ * receive), then the interior, so that the exchange can start after the first launch.  Same result as the unsplit op.
+ * rb_ofst < 0: two Jacobi sweeps, res_dev[0..1]; rb_ofst >= 0: one red-black iteration (ofst), res_dev[0].
+ * Returns 0 (nothing launched) when there is no internal face, the box is too thin or the geometry is unsupported. */
+int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1,
+                           const int* nID, int g, const CZ_REAL* cf, CZ_REAL omg, int rb_ofst, double* res_dev);
 /* First pair of a preconditioner solve whose start vector is identically zero (blas_clear_ + 8 sweeps, cz_Poisson.cpp:405-409):
  * u is neither cleared in memory nor read; u_shape only provides the array geometry/alignment.  Bit-identical to clearing u and
  * calling czhip_jacobi2_async. */

@@ -23,8 +23,10 @@ def _single(prec, gsz, solver, itmax, coef, pc=None):
     return out
 
 
-def _decomposed(prec, gsz, solver, itmax, coef, div, pc=None):
+def _decomposed(prec, gsz, solver, itmax, coef, div, pc=None, overlap=1):
+    import os
     from cubez_amd import CZ, load
+    os.environ["CZ_OVERLAP"] = str(overlap)  # read by the driver when a CZ is created
     lib = load(prec)
     import ctypes as C
     lib.cz_comm_local_world.restype = C.c_void_p
@@ -43,7 +45,8 @@ def _decomposed(prec, gsz, solver, itmax, coef, div, pc=None):
             cz.timing(True)
             itr = cz.solve()
             loc = cz.local()
-            loc["fused_pairs"] = cz.timing_read("jacobi2")[0]
+            loc["fused_pairs"] = cz.timing_read("jacobi2")[0] + cz.timing_read("rbsor2")[0]
+            loc["shell_launches"] = cz.timing_read("pair_shell")[0]
             cz.timing(False)
             results[r] = (itr, cz.res, cz.history(), cz.field(), loc)
             cz.close()
@@ -55,6 +58,7 @@ def _decomposed(prec, gsz, solver, itmax, coef, div, pc=None):
     [t.join(timeout=300) for t in th]
     assert not errors, errors
     assert all(r is not None for r in results)
+    os.environ.pop("CZ_OVERLAP")
     lib.cz_comm_local_world_free(world)
     # assemble the global field from the owned cells of every brick
     g = 2
@@ -75,23 +79,31 @@ CASES = [
     ("f32", (40, 36, 44), "sor2sma", 20, 1.5, (1, 2, 1)),
     ("f32", (41, 37, 45), "sor2sma", 15, 1.5, (2, 2, 2)),    # odd heads: colour offset per brick
     ("f64", (36, 40, 44), "sor2sma", 20, 1.4, (2, 1, 2)),
+    ("f32", (48, 36, 44), "jacobi", 12, 0.8, (3, 1, 1)),     # middle brick: both faces of an axis border a rank
+    ("f32", (40, 48, 44), "sor2sma", 9, 1.5, (1, 3, 1)),
+    ("f64", (36, 40, 54), "jacobi", 10, 0.8, (1, 1, 3)),
 ]
 
 
+@pytest.mark.parametrize("overlap", [1, 0], ids=["overlap", "serial"])
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[2]}_{c[0]}_{'x'.join(map(str, c[5]))}" for c in CASES])
-def test_decomposed_equals_single_domain(case):
+def test_decomposed_equals_single_domain(case, overlap):
+    """overlap: shell slabs first, two-layer exchange on a second stream behind the interior sweep; serial: exchange after
+    the whole sweep.  Both must reproduce the single-domain run."""
     prec, gsz, solver, itmax, coef, div = case
     itr1, res1, hist1, P1 = _single(prec, gsz, solver, itmax, coef)
-    results, G = _decomposed(prec, gsz, solver, itmax, coef, div)
+    results, G = _decomposed(prec, gsz, solver, itmax, coef, div, overlap=overlap)
     g = 2
     inner = (slice(g, -g),) * 3
     assert G[inner].tobytes() == P1[inner].tobytes()
     for itr, res, hist, P, loc in results:
         assert itr == itr1
         assert np.allclose(hist, hist1, rtol=1e-12, atol=0)
-        if solver == "jacobi" and (loc["size"][2] + 4) % (4 if prec == "f32" else 2) == 0:
+        if (loc["size"][2] + 4) % (4 if prec == "f32" else 2) == 0:
             # aligned bricks take the two-sweeps-per-pass kernel with the two-layer exchange
-            assert loc["fused_pairs"] == itmax // 2, loc
+            npass = itmax // 2 if solver == "jacobi" else itmax
+            assert loc["fused_pairs"] == npass, loc
+            assert loc["shell_launches"] == (npass if overlap else 0), loc
 
 
 def test_rccl_one_rank_selftest():

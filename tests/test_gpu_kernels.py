@@ -434,3 +434,40 @@ def test_pcr_rb_random_boxes_vs_oracle(prec, box):
             r2 = h.pcr_rb(sz, idx, pn, 0, color, dx, dm, dr, 1.3, res=r2)
             assert _beq(dx.get(), x1), (it, color)
     assert _rel(r2, r1) < 1e-12
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("rb", [-1, 0, 1], ids=["jacobi_pair", "rb_ofst0", "rb_ofst1"])
+def test_pair_split_equals_unsplit(prec, rb):
+    """shell slabs + interior (what a decomposed brick launches so that the exchange overlaps the interior)
+    == the unsplit fused pass, bit for bit, for every pattern of rank-internal faces."""
+    h = _hip(prec)
+    R = np.float32 if prec == "f32" else np.float64
+    ni, nj, nk = 28, 22, 36
+    sz = [ni, nj, nk]
+    rng = np.random.default_rng(77 + rb)
+    shape = (nj + 4, ni + 4, nk + 4)
+    u0, b0 = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    w0 = rng.uniform(-1, 1, shape).astype(R)  # what must survive outside the output box
+    cf = [1.1, 0.9, 1.05, 0.95, 1.2, 0.8, 6.3]
+    du, db = h.alloc(sz, u0), h.alloc(sz, b0)
+    patterns = [[0] * 6, [1] * 6, [0, 1, 1, 0, 0, 1], [1, 0, 0, 0, 0, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 1, 1], [1, 1, 0, 0, 0, 0]]
+    n = [ni, ni, nj, nj, nk, nk]
+    for pat in patterns:
+        nID = [(3 if v else -1) for v in pat]
+        idx = [(1 if v else 2) if f % 2 == 0 else (n[f] if v else n[f] - 1) for f, v in enumerate(pat)]
+        idx1 = [idx[f] + ((1 if f % 2 else -1) if v else 0) for f, v in enumerate(pat)]
+        dw1, dw2 = h.alloc(sz, w0), h.alloc(sz, w0)
+        if rb < 0:
+            ok1, r1a, r1b = h.jacobi2(du, dw1, db, sz, idx, cf, 0.8, idx1=idx1)
+        else:
+            ok1, r1a = h.rbsor2(du, dw1, db, sz, idx, cf, rb, 1.3, idx1=idx1)
+            r1b = 0.0
+        assert ok1
+        ok2, r2a, r2b = h.pair_split(du, dw2, db, sz, idx, idx1, nID, cf, 0.8 if rb < 0 else 1.3, rb_ofst=rb)
+        assert ok2 == any(pat)
+        if not ok2:
+            continue
+        assert _beq(dw2.get(), dw1.get()), pat
+        assert _rel(r2a, r1a) < 1e-12 and (rb >= 0 or _rel(r2b, r1b) < 1e-12)
+        assert du.get().tobytes() == u0.tobytes()
