@@ -101,3 +101,38 @@ def first_sweep_range(idx, nID):
     """index range of the FIRST sweep of a fused pair: one layer into the ghost cells across rank-internal faces
     (CZ::JACOBI / RBSOR, idx1)."""
     return [idx[f] + ((1 if f & 1 else -1) if nID[f] >= 0 else 0) for f in range(6)]
+
+
+def pair_plan(idx, nID):
+    """Mirror of pair_plan() in cz_kernels.hip: split of the inner box of a brick for overlapped exchanges.
+    -> (shell boxes, interior, interior1): the cells within two layers of a rank-internal face as up to six disjoint
+    (ist,ied,jst,jed,kst,ked) slabs (J faces, then I, then K), the rest of the inner box and its first-sweep range.
+    ([], None, None) when there is no internal face or the brick is too thin."""
+    interior = list(idx)
+    for a in range(3):
+        interior[2 * a] = idx[2 * a] + (2 if nID[2 * a] >= 0 else 0)
+        interior[2 * a + 1] = idx[2 * a + 1] - (2 if nID[2 * a + 1] >= 0 else 0)
+        if interior[2 * a + 1] - interior[2 * a] + 1 < 2:
+            return [], None, None
+    O, I = idx, interior
+    boxes = []
+    if nID[2] >= 0:
+        boxes.append([O[0], O[1], O[2], O[2] + 1, O[4], O[5]])
+    if nID[3] >= 0:
+        boxes.append([O[0], O[1], O[3] - 1, O[3], O[4], O[5]])
+    if nID[0] >= 0:
+        boxes.append([O[0], O[0] + 1, I[2], I[3], O[4], O[5]])
+    if nID[1] >= 0:
+        boxes.append([O[1] - 1, O[1], I[2], I[3], O[4], O[5]])
+    if nID[4] >= 0:
+        boxes.append([I[0], I[1], I[2], I[3], O[4], O[4] + 1])
+    if nID[5] >= 0:
+        boxes.append([I[0], I[1], I[2], I[3], O[5] - 1, O[5]])
+    if not boxes:
+        return [], None, None
+    return boxes, interior, first_sweep_range(interior, nID)
+
+
+def sub_first_sweep_range(box, idx1):
+    """first-sweep range of a sub-box of the brick: the box grown by one layer, inside the brick's own first-sweep range."""
+    return [max(box[f] - 1, idx1[f]) if f % 2 == 0 else min(box[f] + 1, idx1[f]) for f in range(6)]

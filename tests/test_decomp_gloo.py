@@ -156,7 +156,7 @@ def test_gloo_decomposed_equals_single_domain(case):
     assert G[g:-g, g:-g, g:-g].tobytes() == ref.P[g:-g, g:-g, g:-g].tobytes()
 
 
-def _rank_pairs(rank, world, port, gsz, div, solver, npairs, coef, prec, q):
+def _rank_pairs(rank, world, port, gsz, div, solver, npairs, coef, prec, q, split=False):
     """the decomposed FUSED-PAIR algorithm of the GPU driver with the oracle doing the arithmetic: two ghost layers +
     edges exchanged once per pair (or per red-black iteration), first sweep / first colour also applied to ghost layer 1."""
     os.environ["OMP_NUM_THREADS"] = "1"
@@ -174,7 +174,7 @@ def _rank_pairs(rank, world, port, gsz, div, solver, npairs, coef, prec, q):
         P, RHS, WRK = k.alloc(size), k.alloc(size), k.alloc(size)
         msgs = decomp.exchange_boxes(size, div, rank, depth=2, edges=True)
 
-        def halo2(X):
+        def halo2_start(X):
             reqs, recvs = [], []
             for tag, m in enumerate(msgs):
                 send = torch.from_numpy(np.ascontiguousarray(X[m["send"]]))
@@ -185,10 +185,31 @@ def _rank_pairs(rank, world, port, gsz, div, solver, npairs, coef, prec, q):
                 reqs.append(dist.isend(send, dst=m["peer"], tag=stag))
                 reqs.append(dist.irecv(recv, src=m["peer"], tag=rtag))
                 recvs.append((m["recv"], recv))
+            return reqs, recvs
+
+        def halo2_finish(X, pending):
+            reqs, recvs = pending
             for r in reqs:
                 r.wait()
             for sl, recv in recvs:
                 X[sl] = recv.numpy()
+
+        def halo2(X):
+            halo2_finish(X, halo2_start(X))
+
+        def sweep2(X, box, box1):
+            """the fused pass on one index box (in place on X)"""
+            if solver == "jacobi":
+                k.jacobi(X, size, box1, cf, coef, RHS, WRK)   # sweep n+1 incl. ghost layer 1 (redundant with the neighbour)
+                k.jacobi(X, size, box, cf, coef, RHS, WRK)    # sweep n+2 on the owned inner box
+            else:
+                # same global colouring whatever the box's kst is
+                k.psor2sma_core(X, size, box1, cf, (ofst + idx[4] + box1[4]) % 2, 0, coef, RHS)
+                k.psor2sma_core(X, size, box, cf, (ofst + idx[4] + box[4]) % 2, 1, coef, RHS)
+
+        def view(box):
+            ist, ied, jst, jed, kst, ked = box
+            return (slice(jst + 1, jed + 2), slice(ist + 1, ied + 2), slice(kst + 1, ked + 2))
 
         Pg = k.alloc(gsz)
         k.bc_k(gsz, Pg, pitch, np.zeros(3, dtype=R), [-1] * 6)
@@ -199,32 +220,47 @@ def _rank_pairs(rank, world, port, gsz, div, solver, npairs, coef, prec, q):
         RHS[own] = Pg[glob]
         halo2(P), halo2(RHS)
         ofst = decomp.rb_offset(head, idx, world)
-        ofst1 = (ofst + idx[4] + idx1[4]) % 2   # same global colouring for the grown box (its kst may differ)
+        shell, interior, interior1 = decomp.pair_plan(idx, nID) if split else ([], None, None)
         for _ in range(npairs):
-            if solver == "jacobi":
-                k.jacobi(P, size, idx1, cf, coef, RHS, WRK)   # sweep n+1 incl. ghost layer 1 (redundant with the neighbour)
-                k.jacobi(P, size, idx, cf, coef, RHS, WRK)    # sweep n+2 on the owned inner box
-            else:
-                k.psor2sma_core(P, size, idx1, cf, ofst1, 0, coef, RHS)  # colour 0 incl. ghost layer 1
-                k.psor2sma_core(P, size, idx, cf, ofst, 1, coef, RHS)    # colour 1 on the owned inner box
-            halo2(P)
+            if not shell:
+                sweep2(P, idx, idx1)
+                halo2(P)
+                continue
+            # the overlapped form (CZ::pair_overlapped): shell slabs, exchange started, interior, exchange finished
+            Pn = P.copy()
+            Pn[view(idx)] = np.nan
+            for box in shell:
+                T = P.copy()
+                sweep2(T, box, decomp.sub_first_sweep_range(box, idx1))
+                Pn[view(box)] = T[view(box)]
+            for m in msgs:
+                assert not np.isnan(Pn[m["send"]]).any(), "a cell to be sent is not in the shell"
+            pending = halo2_start(Pn)
+            T = P.copy()
+            sweep2(T, interior, interior1)
+            Pn[view(interior)] = T[view(interior)]
+            halo2_finish(Pn, pending)
+            assert not np.isnan(Pn[view(idx)]).any(), "shell + interior do not cover the inner box"
+            P[...] = Pn
         q.put((rank, size, head, P))
     finally:
         dist.destroy_process_group()
 
 
 PAIR_CASES = [("jacobi", (20, 18, 22), (1, 2, 1), 5, 0.8, "f32"), ("jacobi", (21, 19, 23), (2, 2, 1), 4, 0.8, "f32"),
-              ("sor2sma", (21, 19, 23), (2, 1, 2), 6, 1.5, "f32"), ("jacobi", (12, 13, 14), (2, 2, 2), 3, 0.8, "f64")]
+              ("sor2sma", (21, 19, 23), (2, 1, 2), 6, 1.5, "f32"), ("jacobi", (12, 13, 14), (2, 2, 2), 3, 0.8, "f64"),
+              ("sor2sma", (24, 12, 13), (3, 1, 1), 4, 1.5, "f64")]
 
 
+@pytest.mark.parametrize("split", [False, True], ids=["unsplit", "shell_first"])
 @pytest.mark.parametrize("case", PAIR_CASES, ids=[f"{c[0]}_{'x'.join(map(str, c[2]))}_{c[5]}" for c in PAIR_CASES])
-def test_gloo_fused_pairs_with_two_layer_exchange(case):
+def test_gloo_fused_pairs_with_two_layer_exchange(case, split):
     solver, gsz, div, npairs, coef, prec = case
     world = div[0] * div[1] * div[2]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_pairs, args=(r, world, port, gsz, div, solver, npairs, coef, prec, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_pairs, args=(r, world, port, gsz, div, solver, npairs, coef, prec, q, split)) for r in range(world)]
     [p.start() for p in procs]
     outs = [q.get(timeout=240) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
