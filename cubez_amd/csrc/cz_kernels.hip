@@ -1104,6 +1104,214 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// pcr_rb, fast form.  The matrix of every k-line is the same (a = c = -1/6, zero at the ends; cz_solver.f90:545-556), so
+// the a/c recurrences of the reduction and the reciprocals e = 1/(1 - ap*c(kl) - cp*a(kr)) (:572-595), and cc1/aa2/jj of
+// the final 2x2 systems (:599-616), are identical for all lines: pcr_coef_k evaluates them ONCE, with the reference's
+// operations in the reference's order, into a table; the per-line work that remains is the right-hand side
+//     d1(k) = e * (d(k) - ap*d(kl) - cp*d(kr))
+// -- the very expression of :590 with the very same operand values, hence the same bits -- without the division and the
+// two coefficient updates (14 -> 5 flop per entry and stage).  pcr_rb2_k keeps the table in LDS, is persistent (the table
+// is loaded once per workgroup), gives each wave L lines at a time (one table read serves L lines) and synchronises
+// waves individually (a line never leaves its wave).
+// ------------------------------------------------------------------------------------------------------------
+// table layout: stage p = 1..pn-1: [e | ap | cp] x n entries each, then the final stage: [jj | cc1 | aa2] x nfin entries
+__global__ void __launch_bounds__(256)
+pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, LD = n + 2;
+  REAL* A[2] = {reinterpret_cast<REAL*>(smem), reinterpret_cast<REAL*>(smem) + 2 * LD};  // [buf][a | c]
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  for (int k = t; k < n; k += 256) {
+    A[0][k + 1] = (k == 0) ? (REAL)0 : -r;
+    A[0][LD + k + 1] = (k == n - 1) ? (REAL)0 : -r;
+  }
+  if (t == 0)
+    for (int b = 0; b < 2; b++)
+      for (int v = 0; v < 2; v++) A[b][v * LD] = (REAL)0, A[b][v * LD + n + 1] = (REAL)0;
+  __syncthreads();
+  int cur = 0;
+  for (int p = 1; p <= pn - 1; p++) {
+    const int s = 1 << (p - 1);
+    const REAL* a = A[cur];
+    const REAL* c = a + LD;
+    REAL* a1 = A[cur ^ 1];
+    REAL* c1 = a1 + LD;
+    REAL* T = tab + (size_t)(p - 1) * 3 * n;
+    for (int k = t; k < n; k += 256) {
+      const int x = k + 1;
+      const int kl = (k - s >= 0) ? x - s : 0;
+      const int kr = (k + s <= n - 1) ? x + s : n + 1;
+      const REAL ap = a[x], cp = c[x];
+      const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * c[kl] - cp * a[kr]);
+      a1[x] = -e * ap * a[kl];
+      c1[x] = -e * cp * c[kr];
+      T[k] = e, T[n + k] = ap, T[2 * n + k] = cp;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  {
+    const int s = 1 << (pn - 1);
+    const REAL* a = A[cur];
+    const REAL* c = a + LD;
+    REAL* F = tab + (size_t)(pn - 1) * 3 * n;
+    for (int k = t; k < nfin; k += 256) {
+      const int x = k + 1;
+      const int kr = (k + s <= n - 1) ? x + s : n + 1;
+      const REAL cc1 = c[x], aa2 = a[kr];
+      F[k] = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+      F[nfin + k] = cc1;
+      F[2 * nfin + k] = aa2;
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // the lanes of ONE wave hand data to each other through LDS: order the accesses, no workgroup barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NW, int L>
+__global__ void __launch_bounds__(64 * NW)
+pcr_rb2_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, const REAL* __restrict__ tab,
+          int tab_len, int nfin, double* partials, double* dst, int accumulate, unsigned* counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
+  REAL* T = reinterpret_cast<REAL*>(smem);
+  REAL* D = T + tab_len + (size_t)wave * 2 * L * LD;  // [buf][line][LD]
+  double* wsum = reinterpret_cast<double*>(T + tab_len + (size_t)NW * 2 * L * LD + 4);
+  wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
+
+  for (int i = threadIdx.x; i < tab_len; i += 64 * NW) T[i] = tab[i];
+  if (lane < 2 * L) D[lane * LD] = (REAL)0, D[lane * LD + n + 1] = (REAL)0;
+  __syncthreads();
+
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const long long ncol = (long long)g.nhalf * g.nj;
+  const long long ngroups = (ncol + L - 1) / L;
+  double acc = 0.0;
+  for (long long q = (long long)blockIdx.x * NW + wave; q < ngroups; q += (long long)gridDim.x * NW) {
+    size_t c0[L];
+    bool act[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const long long col = q * L + l;  // column ordinal among the colour's columns
+      const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+      act[l] = jrow < g.nj;
+      int ii = 0, jj = 0;
+      if (act[l]) {
+        const int j1 = g.jst1 + jrow;
+        int i1 = g.ist1 + 2 * ih;
+        if (((i1 + j1) & 1) != g.color) i1 += 1;  // first i of this colour in the row
+        act[l] = (i1 - g.ist1) < g.ni;
+        ii = g.ii0 + (i1 - g.ist1);
+        jj = g.jj0 + jrow;
+      }
+      c0[l] = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;  // element (kst, i, j)
+    }
+    // ---- source term (:558-568)
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      REAL* d = D + l * LD;
+      for (int k = lane; k < n; k += 64) {
+        REAL dv = (REAL)0;
+        if (act[l]) {
+          const size_t e = c0[l] + k;
+          const REAL mk = MSK[e];
+          dv = ((X[e - plane] + X[e + plane] + X[e - rowlen] + X[e + rowlen] - RHS[e]) * r) * mk;
+          if (k == 0) dv = (dv + X[e - 1] * r) * mk;
+          if (k == n - 1) dv = (dv + X[e + 1] * r) * mk;
+        }
+        d[k + 1] = dv;
+      }
+    }
+    wave_lds_sync();
+    // ---- PCR stages (:572-595), right-hand side only
+    int cur = 0;
+    for (int p = 1; p <= g.pn - 1; p++) {
+      const int s = 1 << (p - 1);
+      const REAL* Tp = T + (size_t)(p - 1) * 3 * n;
+      const REAL* dc = D + (size_t)cur * L * LD;
+      REAL* dn = D + (size_t)(cur ^ 1) * L * LD;
+      for (int k = lane; k < n; k += 64) {
+        const int x = k + 1;
+        const int kl = (k - s >= 0) ? x - s : 0;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL e = Tp[k], ap = Tp[n + k], cp = Tp[2 * n + k];
+#pragma unroll
+        for (int l = 0; l < L; l++) dn[l * LD + x] = e * (dc[l * LD + x] - ap * dc[l * LD + kl] - cp * dc[l * LD + kr]);
+      }
+      wave_lds_sync();
+      cur ^= 1;
+    }
+    // ---- 2x2 systems of the last stage (:599-616)
+    {
+      const int s = 1 << (g.pn - 1);
+      const REAL* F = T + (size_t)(g.pn - 1) * 3 * n;
+      const REAL* dc = D + (size_t)cur * L * LD;
+      REAL* dn = D + (size_t)(cur ^ 1) * L * LD;
+      for (int k = lane; k < nfin; k += 64) {
+        const int x = k + 1;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL jj2 = F[k], cc1 = F[nfin + k], aa2 = F[2 * nfin + k];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const REAL f1 = dc[l * LD + x], f2 = dc[l * LD + kr];
+          const REAL dd1 = (f1 - cc1 * f2) * jj2;
+          const REAL dd2 = (f2 - aa2 * f1) * jj2;
+          dn[l * LD + x] = dd1;
+          if (kr <= n) dn[l * LD + kr] = dd2;
+        }
+      }
+      wave_lds_sync();
+    }
+    // ---- relaxation (:626-633)
+    {
+      const REAL* d1 = D + (size_t)(cur ^ 1) * L * LD;
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        if (!act[l]) continue;
+        for (int k = lane; k < n; k += 64) {
+          const size_t e = c0[l] + k;
+          const REAL pp = X[e];
+          const REAL dp = (d1[l * LD + k + 1] - pp) * omg * MSK[e];
+          X[e] = pp + dp;
+          const REAL d2 = dp * dp;
+          acc += (double)d2;
+        }
+      }
+    }
+    wave_lds_sync();  // the next group's source term overwrites buffer 0
+  }
+  // ---- residual: partial per workgroup, fixed-order sum by the last one (write-through hand-off as in stencil_k)
+  __syncthreads();
+  const double sblk = block_sum<64 * NW>(acc, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64 * NW) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<64 * NW>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
 // imask_k (cz_blas.f90:24-104): 1 on the inner box, 0 elsewhere (whole padded array)
 __global__ void __launch_bounds__(256)
 imask_k(REAL* X, int nkp, int nip, int njp, int kk0, int kk1, int ii0, int ii1, int jj0, int jj1) {
@@ -1412,6 +1620,7 @@ copy_shell_k(REAL* __restrict__ dst, const REAL* __restrict__ src, int nkp, int 
 struct Tuning {
   int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
   int fuse_fin = 1;
+  int pcr_fast = 1, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k); variant = NW*10+L
   #ifdef CZ_REAL_IS_DOUBLE
   int t2_threads = 1024, t2_mv = 2, t2_tj = 64;  // best of tools/tune_jacobi2.py at 512^3 FP64 (profiles/r01)
 #else
@@ -1425,6 +1634,9 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   double* partials = nullptr;   // device
+  REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
+  int pcr_tab_n = 0, pcr_tab_pn = 0;
+  size_t pcr_tab_cap = 0;
   double* shell_partials = nullptr;  // per-workgroup sums of the last pair_shell_k launch, folded in by the interior launch
   int shell_pending = 0;
   size_t partials_cap = 0;
@@ -1928,6 +2140,62 @@ bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, 
   return true;
 }
 
+template <int NW, int L>
+bool try_pcr_rb2_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate, int tab_len,
+                      int nfin) {
+  const size_t lds = ((size_t)tab_len + (size_t)NW * 2 * L * (g.n + 2) + 8) * sizeof(REAL) + 32 * sizeof(double);
+  if (lds > 160 * 1024) return false;
+  const long long ncol = (long long)g.nhalf * g.nj;
+  const long long ngroups = (ncol + L - 1) / L;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(32 / NW)));
+  const unsigned nblk = (unsigned)std::min<long long>((ngroups + NW - 1) / NW, (long long)ctx.num_cu * per_cu);
+  ensure_partials(nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb2_k<NW, L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  ScopedTimer tm(LBL_PCR);
+  hipLaunchKernelGGL((pcr_rb2_k<NW, L>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.pcr_tab, tab_len, nfin,
+                     ctx.partials, res_dev, accumulate, ctx.counter);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// fast form: coefficient table (computed once per line length) + persistent right-hand-side-only kernel
+bool try_pcr_rb2(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate) {
+  const int n = g.n, pn = g.pn;
+  if (pn < 2 || pn > 20) return false;
+  const int s = 1 << (pn - 1);
+  const int nfin = std::min(s, n);
+  const int tab_len = (pn - 1) * 3 * n + 3 * nfin;
+  const size_t fixed = ((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double);
+  const size_t per_line = (size_t)2 * (n + 2) * sizeof(REAL);
+  if (fixed + 4 * per_line > 160 * 1024) return false;  // table + four lines must fit
+  if (ctx.pcr_tab_n != n || ctx.pcr_tab_pn != pn) {
+    if ((size_t)tab_len > ctx.pcr_tab_cap) {
+      if (ctx.pcr_tab) {
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        HIP_CHECK(hipFree(ctx.pcr_tab));
+      }
+      HIP_CHECK(hipMalloc(&ctx.pcr_tab, (size_t)tab_len * sizeof(REAL)));
+      ctx.pcr_tab_cap = tab_len;
+    }
+    hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), (size_t)4 * (n + 2) * sizeof(REAL), ctx.stream, ctx.pcr_tab, n, pn, nfin);
+    HIP_CHECK(hipGetLastError());
+    ctx.pcr_tab_n = n, ctx.pcr_tab_pn = pn;
+  }
+  const int v = ctx.tune.pcr_variant;
+  // measured at 512^3 FP32 (profiles/r01/pcr_variants.txt): waves per CU matter most, 16 x 1 line beats 8 x 2 lines
+  if (v == 0 || v == 161)
+    if (try_pcr_rb2_inst<16, 1>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin)) return true;
+  if (v == 0 || v == 82)
+    if (try_pcr_rb2_inst<8, 2>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin)) return true;
+  if (v == 0 || v == 81)
+    if (try_pcr_rb2_inst<8, 1>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin)) return true;
+  return try_pcr_rb2_inst<4, 1>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin);
+}
+
 void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int color, REAL omg,
                    double* res_dev, int accumulate) {
   if (b.empty) {
@@ -1941,6 +2209,7 @@ void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, cons
   g.ist1 = idx[0], g.jst1 = idx[2];
   g.pn = pn, g.color = color;
   g.nhalf = (g.ni + 1) / 2 + 1;
+  if (ctx.tune.pcr_fast && try_pcr_rb2(x, msk, rhs, g, omg, res_dev, accumulate)) return;
   // one wave per k-line, NW lines per workgroup; each line keeps 2 x (a, c, d) of n+2 entries in LDS.  Prefer four
   // lines per group while two groups still fit a CU's 160 KiB, then fall back to fewer lines per group for long lines.
   if (try_pcr_rb<4>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
@@ -1996,6 +2265,11 @@ int czhip_init(int device) {
     const int n = sscanf(t2, "%d,%d,%d,%d", &en, &a, &b2, &c2);
     if (n >= 1) czhip_set_tuning2(n >= 2 ? a : 0, n >= 3 ? b2 : 0, n >= 4 ? c2 : -1, en);
   }
+  if (const char* pc = getenv("CZHIP_PCR")) {  // "fast[,variant]"
+    int f = 1, v = 0;
+    sscanf(pc, "%d,%d", &f, &v);
+    ctx.tune.pcr_fast = f, ctx.tune.pcr_variant = v;
+  }
   const char* tu = getenv("CZHIP_TUNING");  // "threads,m,tj,pf"
   if (tu) {
     int a = 0, b = 0, c = 0, d = -1;
@@ -2011,6 +2285,7 @@ void czhip_finalize(void) {
   ctx.bc_tabs.clear();
   (void)hipFree(ctx.partials);
   (void)hipFree(ctx.shell_partials);
+  if (ctx.pcr_tab) (void)hipFree(ctx.pcr_tab);
   (void)hipFree(ctx.scal_dev);
   (void)hipHostFree(ctx.scal_host);
   (void)hipStreamDestroy(ctx.stream);
