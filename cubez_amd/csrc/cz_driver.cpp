@@ -22,6 +22,7 @@
 
 #include <cfloat>
 #include <chrono>
+#include <cstdint>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -359,8 +360,24 @@ int CZ::Evaluate(int argc, char** argv) {
   }
   if (debug_mode == 1) {  // :550-563
     int loc[3];
+    // fileout_t_ has a body only in the reference's -D_aurora_=1 build (cz_utility.f90:33-44); here CZ_SPH=1 asks for the files
+    const char* sph = getenv("CZ_SPH");
+    const bool dump = sph && atoi(sph) != 0;
+    char fname[32];
+    if (dump) {
+      snprintf(fname, sizeof(fname), "p_%05d.sph", myRank);  // :553-554
+      std::vector<REAL_TYPE> p((size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE));
+      Field(p.data());
+      if (!WriteSph(fname, p.data())) return 0;
+    }
     double errmax = ErrorMax(loc);
     if (!quiet) Hostonly_ printf("\nError max = %e at (%d %d %d)\n\n", errmax, loc[0], loc[1], loc[2]);
+    if (dump) {
+      snprintf(fname, sizeof(fname), "e_%05d.sph", myRank);  // :560-561
+      std::vector<REAL_TYPE> e;
+      Exact(e);
+      if (!WriteSph(fname, e.data())) return 0;
+    }
   }
   return 1;
 }
@@ -927,6 +944,80 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
 void CZ::Field(REAL_TYPE* host) const {
   const size_t n = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE);
   czhip_d2h(host, P, n * sizeof(REAL_TYPE));
+}
+
+// fileout_t (cz_utility.f90:17-47, the -D_aurora_=1 body): a Fortran sequential unformatted file -- every record framed
+// by its byte length (4-byte integer) -- holding (1,1) | (ix,jx,kx) | org | (dh,dh,dh) | (0, 0.0) | s(1:kx,1:ix,1:jx) with
+// i fastest, then j, then k.  `s` is the padded host copy of a field.
+bool CZ::WriteSph(const char* fname, const REAL_TYPE* s) const {
+  FILE* fp = fopen(fname, "wb");
+  if (!fp) {
+    printf("\tSorry, can't open '%s' file. Write failed.\n", fname);
+    return false;
+  }
+  const int g = GUIDE, ix = size[0], jx = size[1], kx = size[2];
+  const size_t nk = kx + 2 * g, ni = ix + 2 * g;
+  auto rec = [&](const void* a, size_t na, const void* b = nullptr, size_t nb = 0) {
+    const int32_t len = (int32_t)(na + nb);
+    fwrite(&len, 4, 1, fp);
+    fwrite(a, 1, na, fp);
+    if (b) fwrite(b, 1, nb, fp);
+    fwrite(&len, 4, 1, fp);
+  };
+  const int32_t one[2] = {1, 1}, dims[3] = {ix, jx, kx}, nn = 0;
+  const REAL_TYPE dh3[3] = {pitch[0], pitch[0], pitch[0]}, rtime = 0;
+  rec(one, sizeof(one));
+  rec(dims, sizeof(dims));
+  rec(origin, 3 * sizeof(REAL_TYPE));
+  rec(dh3, sizeof(dh3));
+  rec(&nn, 4, &rtime, sizeof(REAL_TYPE));
+  const size_t nbytes = (size_t)ix * jx * kx * sizeof(REAL_TYPE);
+  if (nbytes > 0x7ffffff7u) {
+    printf("\t'%s': the field record exceeds the 2 GiB a 4-byte record length can frame. Write failed.\n", fname);
+    fclose(fp);
+    return false;
+  }
+  const int32_t len = (int32_t)nbytes;
+  fwrite(&len, 4, 1, fp);
+  std::vector<REAL_TYPE> slab((size_t)ix * jx);
+  for (int k = 1; k <= kx; k++) {
+    for (int j = 1; j <= jx; j++)
+      for (int i = 1; i <= ix; i++)
+        slab[(size_t)(j - 1) * ix + (i - 1)] = s[(size_t)(k + g - 1) + (size_t)(i + g - 1) * nk + (size_t)(j + g - 1) * nk * ni];
+    fwrite(slab.data(), sizeof(REAL_TYPE), slab.size(), fp);
+  }
+  fwrite(&len, 4, 1, fp);
+  const bool ok = !ferror(fp);
+  fclose(fp);
+  return ok;
+}
+
+// exact_t (cz_utility.f90:52-82) on the host: the analytic solution on the whole brick (1..ix, 1..jx, 1..kx), padded layout
+void CZ::Exact(std::vector<REAL_TYPE>& e) const {
+  const int g = GUIDE;
+  const size_t nk = size[2] + 2 * g, ni = size[0] + 2 * g, nj = size[1] + 2 * g;
+  e.assign(nk * ni * nj, (REAL_TYPE)0);
+  volatile REAL_TYPE one = 1.0, two = 2.0;
+#ifdef CZ_REAL_IS_DOUBLE
+  const REAL_TYPE r2 = sqrt(two), pi = 2.0 * asin(one);
+#else
+  const REAL_TYPE r2 = sqrtf(two), pi = 2.0f * asinf(one);
+#endif
+  const REAL_TYPE dh = pitch[0];
+  for (int j = 1; j <= size[1]; j++)
+    for (int i = 1; i <= size[0]; i++)
+      for (int k = 1; k <= size[2]; k++) {
+        const REAL_TYPE x = G_origin[0] + dh * (REAL_TYPE)(head[0] - 1 + i - 1);
+        const REAL_TYPE y = G_origin[1] + dh * (REAL_TYPE)(head[1] - 1 + j - 1);
+        const REAL_TYPE z = G_origin[2] + dh * (REAL_TYPE)(head[2] - 1 + k - 1);
+#ifdef CZ_REAL_IS_DOUBLE
+        e[(size_t)(k + g - 1) + (size_t)(i + g - 1) * nk + (size_t)(j + g - 1) * nk * ni] =
+            sin(pi * x) * sin(pi * y) / sinh(r2 * pi) * (sinh(r2 * pi * z) - sinh(r2 * pi * (z - (REAL_TYPE)1.0)));
+#else
+        e[(size_t)(k + g - 1) + (size_t)(i + g - 1) * nk + (size_t)(j + g - 1) * nk * ni] =
+            sinf(pi * x) * sinf(pi * y) / sinhf(r2 * pi) * (sinhf(r2 * pi * z) - sinhf(r2 * pi * (z - (REAL_TYPE)1.0)));
+#endif
+      }
 }
 
 // Debug epilogue (cz_Evaluate.cpp:550-563): exact_t_ + err_t_ of cz_utility.f90:52-129 restated on the host

@@ -88,6 +88,8 @@ class CZ {
   int Sweeps(int n);
   double ErrorMax(int loc[3]);          //   :550-563
   void Field(REAL_TYPE* host) const;
+  bool WriteSph(const char* fname, const REAL_TYPE* padded_host_field) const;  // cz_utility.f90:17-47
+  void Exact(std::vector<REAL_TYPE>& e) const;                                   // cz_utility.f90:52-82
 
  private:
   void setLS(const char* q);                                   // cz_Evaluate.cpp:684-803

@@ -41,6 +41,8 @@ def lib_path(kind: str, prec: str) -> str:
         return os.path.join(_HERE, "_ref", f"libczref_{prec}.so")
     if kind == "ref_serial":  # the reference built without OpenMP (pins the PCR line solvers, see oracle/Makefile)
         return os.path.join(_HERE, "_ref", f"libczref_serial_{prec}.so")
+    if kind == "ref_sph":  # cz_utility.f90 with -D_aurora_=1: the .sph writer (fileout_t)
+        return os.path.join(_HERE, "_ref", f"libczref_sph_{prec}.so")
     raise ValueError(kind)
 
 
@@ -233,6 +235,16 @@ class Kernels:
         self.last_flop = fl.value
         return r.value
 
+    def fileout_t(self, sz, s, dh, org, fname):
+        """cz_utility.f90:17-47 (reference build with -D_aurora_=1 only): writes the .sph file `fname` (<= 20 characters)."""
+        assert self.kind == "ref_sph" and len(fname) <= 20
+        sz, g = _ia(sz), C.c_int(GUIDE)
+        org = np.ascontiguousarray(org, dtype=self.real)
+        name = fname.encode().ljust(20)
+        f = self._f("fileout_t")
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]  # hidden length last
+        f(self._ip(sz), C.byref(g), self._rp(s), self._rs(dh), self._rp(org), name, 20)
+
     def exact_t(self, sz, e, dh, org):
         sz, g = _ia(sz), C.c_int(GUIDE)
         org = np.ascontiguousarray(org, dtype=self.real)
@@ -244,6 +256,27 @@ class Kernels:
         loc = np.zeros(3, dtype=np.int32)
         self._f("err_t")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(d), self._rp(p), self._rp(e), self._ip(loc))
         return d.value, tuple(int(v) for v in loc)
+
+
+def sph_bytes(sz, s, dh, org):
+    """Restatement of fileout_t (cz_utility.f90:33-44): the bytes of the Fortran sequential unformatted file.
+    Records (each framed by its byte length as a 4-byte integer before and after): (1, 1) | (ix, jx, kx) | org(1:3) |
+    (dh, dh, dh) | (nn = 0, rtime = 0.0) | s(1:kx, 1:ix, 1:jx) written with i fastest, then j, then k.  Reals have the
+    width of the build (4 or 8 bytes), integers are 4 bytes."""
+    ni, nj, nk = (int(v) for v in sz)
+    R = s.dtype.type
+    g = GUIDE
+
+    def rec(*parts):
+        body = b"".join(np.ascontiguousarray(p).tobytes() for p in parts)
+        n = np.int32(len(body)).tobytes()
+        return n + body + n
+
+    core = s[g:g + nj, g:g + ni, g:g + nk]          # [j, i, k]
+    data = np.ascontiguousarray(core.transpose(2, 0, 1))  # [k, j, i]: i fastest
+    i4 = np.int32
+    return (rec(np.array([1, 1], dtype=i4)) + rec(np.array([ni, nj, nk], dtype=i4)) + rec(np.asarray(org, dtype=R)) +
+            rec(np.array([dh, dh, dh], dtype=R)) + rec(np.array([0], dtype=i4), np.array([0.0], dtype=R)) + rec(data))
 
 
 # ----------------------------------------------------------------------------------

@@ -149,6 +149,18 @@ def kernel_vectors(prec):
             out[tag + f"_x_c{color}"] = xx.copy()
             out[tag + f"_res_c{color}"] = np.array(r)
         out[tag + "_flop"] = np.array(ks.last_flop)
+    # .sph field file: the reference's writer, cz_utility.f90 built with -D_aurora_=1
+    if O.have("ref_sph", prec):
+        kw = O.Kernels("ref_sph", prec)
+        szs = [5, 4, 6]
+        fld = rng.uniform(-1, 1, (szs[1] + 4, szs[0] + 4, szs[2] + 4)).astype(R)
+        cwd = os.getcwd()
+        os.chdir(HERE)
+        try:
+            kw.fileout_t(szs, fld, 0.25, [0.5, 0.25, 0.125], f"sph_small_{prec}.sph")
+        finally:
+            os.chdir(cwd)
+        out["sph_in"] = fld
     np.savez_compressed(os.path.join(HERE, f"kernels_{prec}.npz"), **out)
 
 

@@ -13,10 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 CASES = {c["tag"]: c for c in json.load(open(os.path.join(GOLDEN, "solver_cases.json")))}
 
 
-def _run(prec, args, cwd):
+def _run(prec, args, cwd, env=None):
     exe = os.path.join(ROOT, "cubez_amd", f"cz_{prec}")
     assert os.path.exists(exe), "build the CLI: make -C cubez_amd/csrc"
-    return subprocess.run([exe] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True, timeout=300)
+    return subprocess.run([exe] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, **(env or {})))
 
 
 def test_usage_on_wrong_argc(tmp_path):
@@ -57,3 +58,28 @@ def test_cli_matches_reference_run(tmp_path, tag):
     assert abs(float(m.group(1)) - c["errmax"]) <= 1e-5 * c["errmax"]
     if not c["solver"].startswith("pbicgstab"):
         assert [int(m.group(i)) for i in (2, 3, 4)] == c["errloc"]
+
+
+@pytest.mark.parametrize("tag", ["jacobi_32x32x32_f32", "sor2sma_32x32x32_f64"])
+def test_cli_writes_the_reference_sph_files(tmp_path, tag):
+    """debug epilogue (cz_Evaluate.cpp:553-561): p_00000.sph / e_00000.sph, the format of fileout_t (cz_utility.f90:33-44,
+    compiled into the reference only with -D_aurora_=1; CZ_SPH=1 here).  Fields are bit-identical => so are the files."""
+    import numpy as np
+    from oracle import cz_oracle as O
+    c = CASES[tag]
+    r = _run(c["prec"], list(c["gsz"]) + [c["solver"], c["itr_max"], c["coef"]], tmp_path, env={"CZ_SPH": "1"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    k = O.Kernels("oracle", c["prec"])
+    R = k.real
+    pitch = R(1.0 / float(R(c["gsz"][2] - 1)))  # cz_Evaluate.cpp:88, as oracle/cz_oracle.py
+    org = np.zeros(3, dtype=R)
+    P = np.load(os.path.join(GOLDEN, c["field"]))
+    assert open(os.path.join(tmp_path, "p_00000.sph"), "rb").read() == O.sph_bytes(c["gsz"], P, pitch, org)
+    e = k.alloc(c["gsz"])
+    k.exact_t(c["gsz"], e, pitch, org)
+    assert open(os.path.join(tmp_path, "e_00000.sph"), "rb").read() == O.sph_bytes(c["gsz"], e, pitch, org)
+
+
+def test_cli_writes_no_sph_by_default(tmp_path):
+    r = _run("f32", [16, 16, 16, "jacobi", 4, 0.8], tmp_path)
+    assert r.returncode == 0 and not [f for f in os.listdir(tmp_path) if f.endswith(".sph")]

@@ -182,3 +182,14 @@ def test_oracle_vs_reference_random_boxes(prec):
         for nid in ([-1] * 6, [0, 1, -1, -1, 2, -1]):
             ko.bc_k(sz, a1, 0.125, [0.1, 0.2, 0.3], nid), kr.bc_k(sz, a2, 0.125, [0.1, 0.2, 0.3], nid)
             assert _beq(a1, a2)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_sph_writer_restatement_matches_the_reference_file(prec):
+    """.sph field file (cz_utility.f90:17-47, written by the reference built with -D_aurora_=1): the restatement used to check
+    the GPU driver's p_00000.sph / e_00000.sph produces the reference's bytes."""
+    g = np.load(os.path.join(GOLDEN, f"kernels_{prec}.npz"))
+    R = np.float32 if prec == "f32" else np.float64
+    want = open(os.path.join(GOLDEN, f"sph_small_{prec}.sph"), "rb").read()
+    got = O.sph_bytes([5, 4, 6], g["sph_in"], R(0.25), np.array([0.5, 0.25, 0.125], dtype=R))
+    assert got == want
