@@ -19,12 +19,15 @@
 #include "cz_driver.h"
 
 #include <strings.h>
+#include <unistd.h>
 
 #include <cfloat>
 #include <chrono>
 #include <cstdint>
 #include <cmath>
 #include <cstring>
+#include <ctime>
+#include <algorithm>
 #include <vector>
 
 #include "cz_comm.h"
@@ -310,6 +313,7 @@ int CZ::Solve() {
   double res = 0.0, flop = 0.0;
   int itr = 0;
   history.clear();
+  if (profile) czhip_timing(1);  // restart the section timers (the reference's PM.start/stop around the kernels)
   czhip_sync();
   const double t0 = now_s();
   switch (ls_type) {  // :415-488
@@ -357,6 +361,17 @@ int CZ::Evaluate(int argc, char** argv) {
       printf("\n\tGPU time = %.6f s   %.1f MLUPS\n", solve_seconds, lups / solve_seconds * 1e-6);
     else
       printf("\n\tGPU time = %.6f s\n", solve_seconds);
+  }
+  if (profile) {  // :506-545 (PMlib report; rank 0 writes, the others' sections are assumed alike)
+    Hostonly_ {
+      FILE* fp = fopen("profiling.txt", "w");
+      if (!fp) {
+        printf("\tSorry, can't open 'profiling.txt' file. Write failed.\n");
+        return 0;
+      }
+      WriteProfile(fp);
+      fclose(fp);
+    }
   }
   if (debug_mode == 1) {  // :550-563
     int loc[3];
@@ -946,6 +961,80 @@ void CZ::Field(REAL_TYPE* host) const {
   czhip_d2h(host, P, n * sizeof(REAL_TYPE));
 }
 
+// profiling.txt (cz_Evaluate.cpp:506-545).  The reference prints PMlib's "Basic Report" (PMlib 6.4.x is a third-party
+// library that is not part of the reference tree); this is the same table -- one line per measured section with call
+// count, accumulated time, share, time per call, operation count and rate -- filled from the library's HIP-event timing
+// of its launches (czhip_timing), under the reference's section labels (cz_miscel.cpp:177-262) where a launch maps to one.
+void CZ::WriteProfile(FILE* fp) const {
+  struct Sec {
+    const char* label;   // reference label (or the nearest description)
+    const char* lib;     // czhip_timing label
+    double flop_per_call;
+  };
+  const double n = npts();
+  const bool maf = SW_maf != 0;
+  const int kn = innerFidx[K_plus] - innerFidx[K_minus] + 1;
+  const int pn = pcr_num_stage(kn);
+  const double pcr_flop = (n / kn) * (kn * 6.0 + kn * (pn - 1) * 14.0 + (double)(1 << (pn > 0 ? pn - 1 : 0)) * 9.0 + kn * 6.0 + 6.0) * 0.5;
+  const Sec secs[] = {
+      {maf ? "JACOBI_MAF_kernel" : "JACOBI_kernel", "jacobi", (maf ? 66.0 : 18.0) * n},
+      {"JACOBI_kernel x2 (fused pair)", "jacobi2", 36.0 * n},
+      {maf ? "SOR2SMA_MAF_kernel" : "SOR2SMA_kernel", "rbsor", (maf ? 33.0 : 9.0) * n},
+      {"SOR2SMA_kernel x2 (both colours)", "rbsor2", 18.0 * n},
+      {"Shell slabs of a fused pass", "pair_shell", 0.0},
+      {"PCR_RB", "pcr_rb", pcr_flop},
+      {"Blas_AX", "calc_ax", (maf ? 63.0 : 13.0) * n},
+      {"Blas_Residual", "calc_rk", (maf ? 63.0 : 14.0) * n},
+      {"Dot1 / Dot2", "dot", 2.0 * n},
+      {"Blas_TRIAD / BiCG_1 / BiCG_2", "ewise", 0.0},
+      {"Residual reduction", "reduce", 0.0},
+  };
+  char host[256] = "unknown";
+  gethostname(host, sizeof(host) - 1);
+  time_t now = time(nullptr);
+  char date[64];
+  strftime(date, sizeof(date), "%Y/%m/%d : %H:%M:%S", localtime(&now));
+  double tot_ms = 0.0;
+  struct Row {
+    const Sec* s;
+    int calls;
+    double ms;
+  };
+  std::vector<Row> rows;
+  for (const Sec& s : secs) {
+    double ms = 0.0;
+    const int c = czhip_timing_read(s.lib, &ms);
+    if (c == 0) continue;
+    rows.push_back({&s, c, ms});
+    tot_ms += ms;
+  }
+  std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.ms > b.ms; });  // time cost order
+  fprintf(fp, "\n# PMlib Basic Report -------------------------------------------------------\n\n");
+  fprintf(fp, "\tTiming Statistics Report (PMlib layout; sections timed with HIP events on the GPU stream)\n");
+  fprintf(fp, "\tHost name : %s\n\tDate      : %s\n\n\tCubeZ hot path on %s\n\n", host, date, czhip_arch());
+  fprintf(fp, "\tParallel Mode:   %d process%s x 1 GPU\n\n", numProc, numProc > 1 ? "es" : "");
+  fprintf(fp, "\tTotal execution time            = %e [sec]\n", solve_seconds);
+  fprintf(fp, "\tTotal time of measured sections = %e [sec]\n\n", tot_ms * 1e-3);
+  fprintf(fp, "\tExclusive sections statistics per process and total job.\n\n");
+  fprintf(fp, "\tSection                          |  call  |        accumulated time[sec]           | [flop counts]\n");
+  fprintf(fp, "\tLabel                            |        |      avr   avr[%%]     sdv    avr/call  |      avr       sdv   speed\n");
+  fprintf(fp, "\t---------------------------------+--------+----------------------------------------+----------------------------\n");
+  double tot_flop = 0.0;
+  for (const Row& r : rows) {
+    const double sec = r.ms * 1e-3, flop = r.s->flop_per_call * r.calls;
+    tot_flop += flop;
+    fprintf(fp, "\t%-33s: %8d   %9.3e %6.2f  %8.2e  %9.3e    %9.3e  %8.2e  %7.2f %s\n", r.s->label, r.calls, sec,
+            tot_ms > 0 ? 100.0 * r.ms / tot_ms : 0.0, 0.0, sec / r.calls, flop, 0.0, sec > 0 ? flop / sec * 1e-12 : 0.0, "Tflops");
+  }
+  fprintf(fp, "\t---------------------------------+--------+----------------------------------------+----------------------------\n");
+  fprintf(fp, "\t%-33s  %8s   %9.3e %37s %9.3e  %8s  %7.2f %s\n", "Sections per process", "", tot_ms * 1e-3, "", tot_flop, "",
+          tot_ms > 0 ? tot_flop / (tot_ms * 1e-3) * 1e-12 : 0.0, "Tflops");
+  fprintf(fp, "\t---------------------------------+--------+----------------------------------------+----------------------------\n");
+  fprintf(fp, "\t%-33s  %8s   %9.3e %37s %9.3e  %8s  %7.2f %s\n\n", "Sections total job", "", tot_ms * 1e-3, "", tot_flop * numProc, "",
+          tot_ms > 0 ? tot_flop * numProc / (tot_ms * 1e-3) * 1e-12 : 0.0, "Tflops");
+  fprintf(fp, "\tInclusive section: %s  = %e [sec] (host wall clock around the solver loop)\n", printMethod(ls_type), solve_seconds);
+}
+
 // fileout_t (cz_utility.f90:17-47, the -D_aurora_=1 body): a Fortran sequential unformatted file -- every record framed
 // by its byte length (4-byte integer) -- holding (1,1) | (ix,jx,kx) | org | (dh,dh,dh) | (0, 0.0) | s(1:kx,1:ix,1:jx) with
 // i fastest, then j, then k.  `s` is the padded host copy of a field.
@@ -1091,6 +1180,7 @@ void cz_local_size(const cz_handle* h, int* size3, int* head3, int* nID6, int* i
 double cz_error_max(cz_handle* h, int* loc3) { return h->cz.ErrorMax(loc3); }
 void cz_set_quiet(cz_handle* h, int q) { h->cz.quiet = q != 0; }
 void cz_set_debug(cz_handle* h, int m) { h->cz.debug_mode = m; }
+void cz_set_profile(cz_handle* h, int on) { h->cz.profile = on != 0; }
 double cz_last_solve_seconds(const cz_handle* h) { return h->cz.solve_seconds; }
 double cz_kernel_ms(const cz_handle* h, const char* label) {
   (void)h;

@@ -56,6 +56,7 @@ class CZ {
 
   // ---- build-specific state
   bool quiet = false;
+  bool profile = false;          // write profiling.txt after the solve (the cz command line turns it on; CZ_PROFILE=0 off)
   bool set_up = false;
   int result_itr = 0;
   double result_res = 0.0;
@@ -88,6 +89,7 @@ class CZ {
   int Sweeps(int n);
   double ErrorMax(int loc[3]);          //   :550-563
   void Field(REAL_TYPE* host) const;
+  void WriteProfile(FILE* fp) const;                                             // cz_Evaluate.cpp:506-545
   bool WriteSph(const char* fname, const REAL_TYPE* padded_host_field) const;  // cz_utility.f90:17-47
   void Exact(std::vector<REAL_TYPE>& e) const;                                   // cz_utility.f90:52-82
 

@@ -1652,10 +1652,13 @@ struct Ctx {
   bool timing = false;
   struct Ev { hipEvent_t a, b; int label; };
   std::vector<Ev> ev_used, ev_free;
+  double t_acc[16] = {0};       // per label: time [ms] and launches of events already folded (long runs)
+  long long t_cnt[16] = {0};
 };
 thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
 
 enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_SHELL, LBL_COUNT };
+static_assert(LBL_COUNT <= 16, "Ctx::t_acc / t_cnt hold 16 labels");
 const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb", "pair_shell"};
 
 struct ScopedTimer {
@@ -1677,6 +1680,20 @@ struct ScopedTimer {
     if (!on) return;
     HIP_CHECK(hipEventRecord(ev.b, ctx.stream));
     ctx.ev_used.push_back(ev);
+    if (ctx.ev_used.size() >= 4096) fold_events(2048);
+  }
+  // long runs: turn the oldest recorded pairs into per-label sums and recycle their events (they completed long ago)
+  static void fold_events(size_t n) {
+    for (size_t i = 0; i < n; i++) {
+      Ctx::Ev& e = ctx.ev_used[i];
+      HIP_CHECK(hipEventSynchronize(e.b));
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+      ctx.t_acc[e.label] += ms;
+      ctx.t_cnt[e.label]++;
+      ctx.ev_free.push_back(e);
+    }
+    ctx.ev_used.erase(ctx.ev_used.begin(), ctx.ev_used.begin() + n);
   }
 };
 
@@ -2353,6 +2370,7 @@ void czhip_timing(int enable) {
   HIP_CHECK(hipStreamSynchronize(ctx.stream));
   for (auto& e : ctx.ev_used) ctx.ev_free.push_back(e);
   ctx.ev_used.clear();
+  for (int l = 0; l < 16; l++) ctx.t_acc[l] = 0.0, ctx.t_cnt[l] = 0;
   ctx.timing = enable != 0;
 }
 
@@ -2362,8 +2380,12 @@ int czhip_timing_read(const char* label, double* total_ms) {
   int want = -1;
   for (int l = 0; l < LBL_COUNT; l++)
     if (!strcmp(kLabelNames[l], label)) want = l;
-  double tot = 0.0;
-  int n = 0;
+  if (want < 0) {
+    if (total_ms) *total_ms = 0.0;
+    return 0;
+  }
+  double tot = ctx.t_acc[want];
+  int n = (int)ctx.t_cnt[want];
   for (auto& e : ctx.ev_used) {
     if (e.label != want) continue;
     float ms = 0.f;

@@ -73,6 +73,10 @@ int main(int argc, char* argv[]) {
 
   cz_handle* cz = cz_create();
   cz_set_debug(cz, 1);  // main.cpp:38-42: debug mode is hard-wired on
+  {
+    const char* pf = getenv("CZ_PROFILE");  // profiling.txt (cz_Evaluate.cpp:506-545) unless CZ_PROFILE=0
+    cz_set_profile(cz, pf ? atoi(pf) : 1);
+  }
   if (0 == cz_evaluate(cz, argc, argv)) {  // main.cpp:45-52
     if (myRank == 0) printf("\n\tSolver error.\n\n");
     return -1;

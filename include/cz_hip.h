@@ -222,6 +222,7 @@ double cz_last_solve_seconds(const cz_handle*);
 double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
 
 void cz_set_debug(cz_handle*, int mode);      /* main.cpp:38-42: 1 = run the analytic-error epilogue in cz_evaluate */
+void cz_set_profile(cz_handle*, int on);      /* cz_Evaluate.cpp:506-545: 1 = cz_evaluate writes profiling.txt (PMlib-style section report) */
 
 /* ------------------------------------------------------------------------------------------------
  * Part 5 -- multi-GPU bootstrap (replaces MPI_Init / CBrick set-up, main.cpp:33-35, cz_Evaluate.cpp:103-159).

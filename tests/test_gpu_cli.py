@@ -83,3 +83,25 @@ def test_cli_writes_the_reference_sph_files(tmp_path, tag):
 def test_cli_writes_no_sph_by_default(tmp_path):
     r = _run("f32", [16, 16, 16, "jacobi", 4, 0.8], tmp_path)
     assert r.returncode == 0 and not [f for f in os.listdir(tmp_path) if f.endswith(".sph")]
+
+
+def test_cli_writes_the_section_report(tmp_path):
+    """profiling.txt (cz_Evaluate.cpp:506-545): PMlib's basic-report table, sections under the reference's labels."""
+    r = _run("f64", [32, 32, 32, "pbicgstab", 50, 0.8, "jacobi"], tmp_path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    txt = open(os.path.join(tmp_path, "profiling.txt")).read()
+    assert "# PMlib Basic Report" in txt and "Total execution time" in txt
+    rows = {}
+    for ln in txt.splitlines():
+        m = re.match(r"\t(.{33}): +(\d+) +([0-9.e+-]+) +([0-9.]+) ", ln)
+        if m:
+            rows[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)), float(m.group(4)))
+    assert {"Blas_AX", "Dot1 / Dot2", "Blas_Residual"} <= set(rows), rows
+    assert rows["Blas_AX"][0] == 2 * 9            # two SpMV per iteration, 9 iterations (golden: Iter = 9)
+    assert rows["Blas_Residual"][0] == 1          # r = b - Ax once
+    assert abs(sum(v[2] for v in rows.values()) - 100.0) < 0.5
+
+
+def test_cli_profile_can_be_switched_off(tmp_path):
+    r = _run("f32", [16, 16, 16, "jacobi", 4, 0.8], tmp_path, env={"CZ_PROFILE": "0"})
+    assert r.returncode == 0 and not os.path.exists(os.path.join(tmp_path, "profiling.txt"))
