@@ -29,7 +29,7 @@ ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--n", type=int, default=512, help="cells per GPU and axis")
-ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab", "pcr_rb"])
+ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor"])
 ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "sor2sma"])
 ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
 ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +57,7 @@ if world not in DIVS:
 div = DIVS[world]
 n = args.n
 gsz = [n * div[0], n * div[1], n * div[2]]
-coef = 1.2 if args.solver == "pcr_rb" else 1.5 if (args.solver == "sor2sma" or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
+coef = 1.2 if args.solver in ("pcr_rb", "psor") else 1.5 if (args.solver == "sor2sma" or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
 
 if torch.cuda.is_available():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -114,7 +114,7 @@ else:
     barrier()
     dt = time.perf_counter() - t0
 _jl = args.solver == "jacobi" or (args.solver == "pbicgstab" and args.precond == "jacobi")
-nk, kern_ms = cz.timing_read("jacobi" if _jl else "pcr_rb" if args.solver == "pcr_rb" else "rbsor")
+nk, kern_ms = cz.timing_read("jacobi" if _jl else args.solver if args.solver in ("pcr_rb", "psor") else "rbsor")
 nk2, kern2_ms = cz.timing_read("jacobi2" if _jl else "rbsor2")  # fused: 2 sweeps / both colours per launch
 cz.timing(False)
 
@@ -140,6 +140,10 @@ if rank == 0:
         # i/j neighbours (1 word): 5 words x half the points
         alg_bytes_per_launch = my_points * word * 5 // 2
         kernel_name, tkey = "pcr_rb_k (one colour of k-line solves per launch)", f"pcr_rb_{n}_{args.prec}"
+    if args.solver == "psor":
+        # one sweep (all tile-hyperplane launches together): p read and written in place, b read: 3 words per point
+        alg_bytes_per_launch = my_points * word * 3
+        kernel_name, tkey = "psor_tile_k (one lexicographic sweep = 3N/16-2 tile-hyperplane launches)", f"psor_{n}_{args.prec}"
     if nk2 > nk:  # the dominant kernel is the fused one: 2 Jacobi sweeps (2 x 3 words) or both RB colours (2 x 2 words)
         nk, kern_ms, alg_bytes_per_launch = nk2, kern2_ms, 2 * alg_bytes_per_launch
         if jac_like:
@@ -186,7 +190,7 @@ if rank == 0:
         out["config"]["step"] = "one BiCGSTAB iteration: 2 x 8 preconditioner sweeps, 2 SpMV, 5 dots, 4 axpy-type updates (cz_Poisson.cpp:373-500)"
         # 76 words per point and iteration with the Jacobi preconditioner
         out["roofline"]["iteration_algorithmic_GBps"] = my_points * word * (76 if args.precond == "jacobi" else 92) * args.steps / dt / 1e9
-    if world == 1 and not args.no_cpu_baseline and not bicg and args.solver != "pcr_rb":
+    if world == 1 and not args.no_cpu_baseline and not bicg and args.solver not in ("pcr_rb", "psor"):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--n", str(n), "--solver", args.solver,
                                 "--prec", args.prec, "--seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)

@@ -44,6 +44,7 @@ const char* printMethod(int t) {
     case LS_BICGSTAB: return "PBiCGSTAB";
     case LS_PSOR: return "PSOR";
     case LS_PCR_RB: return "PCR_RB";
+    case LS_PSOR_MAF: return "PSOR_MAF";
     case LS_JACOBI_MAF: return "JACOBI_MAF";
     case LS_SOR2SMA_MAF: return "SOR2SMA_MAF";
     case LS_BICGSTAB_MAF: return "PBiCGSTAB_MAF";
@@ -116,9 +117,11 @@ void CZ::setStrPre() {
   else if (!strcasecmp(precon.c_str(), "jacobi_maf")) pc_type = LS_JACOBI_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "sor2sma_maf")) pc_type = LS_SOR2SMA_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "pcr_rb")) pc_type = LS_PCR_RB;
+  else if (!strcasecmp(precon.c_str(), "psor")) pc_type = LS_PSOR;
+  else if (!strcasecmp(precon.c_str(), "psor_maf")) pc_type = LS_PSOR_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "none")) pc_type = LS_NONE;
   else {
-    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | sor2sma | pcr_rb | jacobi_maf | sor2sma_maf)\n", precon.c_str());
+    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | psor | sor2sma | pcr_rb | jacobi_maf | psor_maf | sor2sma_maf)\n", precon.c_str());
     exit(0);
   }
 }
@@ -135,6 +138,13 @@ void CZ::setLS(const char* q) {
     ls_type = LS_BICGSTAB;
     hist_name = "pbicgstab.txt";
     setStrPre();
+  } else if (!strcasecmp(q, "psor")) {  // :691-694, lexicographic point SOR
+    ls_type = LS_PSOR;
+    hist_name = "psor.txt";
+  } else if (!strcasecmp(q, "psor_maf")) {  // :748-751
+    ls_type = LS_PSOR_MAF;
+    hist_name = "psor_maf.txt";
+    SW_maf = 1;
   } else if (!strcasecmp(q, "pcr_rb")) {  // :707-710, line SOR by parallel cyclic reduction
     ls_type = LS_PCR_RB;
     hist_name = "pcr_rb.txt";
@@ -273,6 +283,11 @@ int CZ::Setup(int argc, char** argv) {
 
   ItrMax = atoi(argv[5]);  // :330
 
+  if ((ls_type == LS_PSOR || ls_type == LS_PSOR_MAF || pc_type == LS_PSOR || pc_type == LS_PSOR_MAF) && numProc > 1) {
+    // a lexicographic sweep is one wavefront through the whole grid; this build does not pipeline it across ranks
+    Hostonly_ printf("psor : single-domain runs only in this build\n");
+    return 0;
+  }
   if (ls_type == LS_PCR_RB || pc_type == LS_PCR_RB) {
     if (numProc > 1) {
       Hostonly_ printf("pcr_rb : single-domain runs only in this build\n");
@@ -331,6 +346,10 @@ int CZ::Solve() {
       break;
     case LS_PCR_RB:
       if (0 == (itr = LSOR_PCR_RB(res, P, RHS, ItrMax, flop, ls_type))) return 0;
+      break;
+    case LS_PSOR:
+    case LS_PSOR_MAF:
+      if (0 == (itr = PSOR(res, P, RHS, ItrMax, flop, ls_type))) return 0;
       break;
     default:
       break;
@@ -401,13 +420,14 @@ int CZ::Evaluate(int argc, char** argv) {
 // (sweep, residual reduction, convergence bookkeeping) but eps disabled so that nothing is skipped.
 int CZ::Sweeps(int n) {
   if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA && ls_type != LS_JACOBI_MAF && ls_type != LS_SOR2SMA_MAF &&
-                  ls_type != LS_PCR_RB))
+                  ls_type != LS_PCR_RB && ls_type != LS_PSOR && ls_type != LS_PSOR_MAF))
     return 0;
   const double keep = eps;
   eps = -1.0;
   double res = 0.0, flop = 0.0;
   history.clear();
-  if (ls_type == LS_PCR_RB) LSOR_PCR_RB(res, P, RHS, n, flop, ls_type);
+  if (ls_type == LS_PSOR || ls_type == LS_PSOR_MAF) PSOR(res, P, RHS, n, flop, ls_type);
+  else if (ls_type == LS_PCR_RB) LSOR_PCR_RB(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_JACOBI || ls_type == LS_JACOBI_MAF) JACOBI(res, P, RHS, n, flop, ls_type);
   else RBSOR(res, P, RHS, n, flop, ls_type);
   eps = keep;
@@ -756,6 +776,45 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   return ret;
 }
 
+// cz_Poisson.cpp:95-146.  Lexicographic point SOR, in place; one sweep = the launches of psor_async (tile hyperplanes).
+int CZ::PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+  const bool maf = (s_type == LS_PSOR_MAF);  // :108-114
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  const int* skip = nullptr;
+  if (converge_check) {
+    ensure_hist(itr_max + 2);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    skip = d_flag;
+  }
+  hipEvent_t ev[POLL_SLOTS];
+  int npoll = 0;
+  bool stop = false;
+  int itr;
+  for (itr = 1; itr <= itr_max && !stop; itr++) {
+    psor_async(X, B, size, innerFidx, gc, cf, maf ? d_xc : nullptr, d_yc, d_zc, ac1, d_res, 0, skip);  // :108-122
+    flop += (maf ? 66.0 : 18.0) * npts();
+    if (converge_check) {
+      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);  // :128-141 on the device
+      if (itr % POLL_EVERY == 0 && itr < itr_max) {  // lagging, non-blocking view of the flag (as in RBSOR)
+        const int slot = npoll % POLL_SLOTS;
+        if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
+        HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev[slot], st));
+        npoll++;
+        if (npoll >= 3) {
+          const int old = (npoll - 3) % POLL_SLOTS;
+          HIP_CHECK(hipEventSynchronize(ev[old]));
+          if (h_flag[2 * old] != 0) stop = true;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
+  return finish_stationary(itr_max, 1, converge_check, res);
+}
+
 // cz_Poisson.cpp:518-611.  Line SOR: every (i,j) column of one checkerboard colour is solved along k by parallel cyclic
 // reduction (pcr_rb_k), colour 0 then colour 1, in place.  Single-domain.
 int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
@@ -843,6 +902,10 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
       break;
     case LS_PCR_RB:
       LSOR_PCR_RB(res, xx, bb, lc_max, flop, s_type, false);
+      break;
+    case LS_PSOR:
+    case LS_PSOR_MAF:
+      PSOR(res, xx, bb, lc_max, flop, s_type, false);
       break;
     default: {
       const size_t n = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE);
@@ -983,6 +1046,7 @@ void CZ::WriteProfile(FILE* fp) const {
       {"SOR2SMA_kernel x2 (both colours)", "rbsor2", 18.0 * n},
       {"Shell slabs of a fused pass", "pair_shell", 0.0},
       {"PCR_RB", "pcr_rb", pcr_flop},
+      {maf ? "SOR_MAF_kernel" : "SOR_kernel", "psor", (maf ? 66.0 : 18.0) * n},
       {"Blas_AX", "calc_ax", (maf ? 63.0 : 13.0) * n},
       {"Blas_Residual", "calc_rk", (maf ? 63.0 : 14.0) * n},
       {"Dot1 / Dot2", "dot", 2.0 * n},

@@ -1105,6 +1105,91 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// psor / psor_maf (cz_solver.f90:207-269, cz_maf.f90:23-112): lexicographic in-place SOR.  In the
+// order (j outer, i, k inner) an update sees the NEW values of its k-1, i-1, j-1 neighbours and the OLD ones of k+1, i+1,
+// j+1, so all points of a hyperplane k+i+j = const are independent: the sweep is a wavefront, and what one thread of the
+// reference computes can be reproduced bit for bit in parallel.  Two levels: the box is cut into T^3 tiles, the tiles of
+// one tile-hyperplane tk+ti+tj = H are independent (one launch per H, 3N/T - 2 launches per sweep); inside a tile, staged
+// in LDS with one halo layer (new values from the tiles before, old values from the tiles after), thread (i,j) owns a
+// column and updates k = h - i - j at step h (3T - 2 barrier-separated steps).
+// ------------------------------------------------------------------------------------------------------------
+struct PsorGeom {
+  int nkp, nip, njp;
+  int kk0, kk1, ii0, ii1, jj0, jj1;  // inner box, padded 0-based
+  int ntk, nti, ntj;                 // tiles per axis
+};
+
+template <int T, int MAF>
+__global__ void __launch_bounds__(T * T)
+psor_tile_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorGeom g, int H, double* __restrict__ tile_partials,
+            const int* __restrict__ skip, MafArgs ma) {
+  if (skip != nullptr && *skip != 0) return;
+  const int ti = blockIdx.x, tj = blockIdx.y, tk = H - ti - tj;
+  if (tk < 0 || tk >= g.ntk) return;  // uniform per workgroup
+  constexpr int L1 = T + 2, L2 = (T + 2) * (T + 2);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[T * T / 64 + 2];
+  REAL* lp = reinterpret_cast<REAL*>(smem);  // p tile with one halo layer: [j][i][k]
+  REAL* lb = lp + L2 * L1;                   // b tile
+  const int t = threadIdx.x;
+  const int K0 = g.kk0 + tk * T, I0 = g.ii0 + ti * T, J0 = g.jj0 + tj * T;  // first cell of the tile
+  const size_t si = (size_t)g.nkp, sj = (size_t)g.nkp * g.nip;
+  for (int e = t; e < L2 * L1; e += T * T) {
+    const int k = e % L1, r = e / L1, i = r % L1, j = r / L1;
+    const int gk = K0 - 1 + k, gi = I0 - 1 + i, gj = J0 - 1 + j;
+    lp[e] = (gk < g.nkp && gi < g.nip && gj < g.njp) ? P[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
+  }
+  for (int e = t; e < T * T * T; e += T * T) {
+    const int k = e % T, r = e / T, i = r % T, j = r / T;
+    const int gk = K0 + k, gi = I0 + i, gj = J0 + j;
+    lb[e] = (gk <= g.kk1 && gi <= g.ii1 && gj <= g.jj1) ? B[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
+  }
+  const int i = t % T, j = t / T;
+  const int gi = I0 + i, gj = J0 + j;
+  const bool col_in = gi <= g.ii1 && gj <= g.jj1;
+  REAL XG = 0, XGG = 0, YE = 0, YEE = 0;
+  if (MAF && col_in) {  // padded index == index into xc / yc / zc for g = 2 (see MafArgs)
+    const REAL xm = ma.xc[gi - 1], x0 = ma.xc[gi], xp = ma.xc[gi + 1];
+    const REAL ym = ma.yc[gj - 1], y0 = ma.yc[gj], yp = ma.yc[gj + 1];
+    XG = (REAL)0.5 * (xp - xm), XGG = xp - (REAL)2.0 * x0 + xm;
+    YE = (REAL)0.5 * (yp - ym), YEE = yp - (REAL)2.0 * y0 + ym;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int h = 0; h <= 3 * T - 3; h++) {
+    const int k = h - i - j;
+    if (k >= 0 && k < T && col_in && K0 + k <= g.kk1) {
+      const int x = (k + 1) + L1 * (i + 1) + L2 * (j + 1);
+      const REAL pp = lp[x];
+      const REAL bb = lb[k + T * (i + T * j)];
+      if (MAF) {
+        const int gk = K0 + k;
+        const REAL zm = ma.zc[gk - 1], z0 = ma.zc[gk], zp = ma.zc[gk + 1];
+        const MafW w = maf_weights(XG, XGG, YE, YEE, (REAL)0.5 * (zp - zm), zp - (REAL)2.0 * z0 + zm);
+        const REAL rp = w.w1 * lp[x + L1] + w.w2 * lp[x - L1] + w.w3 * lp[x + L2] + w.w4 * lp[x - L2] + w.w5 * lp[x + 1] +
+                        w.w6 * lp[x - 1] + bb;  // cz_maf.f90:93-99
+        const REAL dp = (rp / w.dd - pp) * c.omg;
+        lp[x] = pp + dp;
+        const REAL d2 = dp * dp;
+        acc += (double)d2;
+      } else {
+        Vec<1> pc, im, ip, pm, pn, bv;
+        pc.v[0] = pp, im.v[0] = lp[x - L1], ip.v[0] = lp[x + L1], pm.v[0] = lp[x - L2], pn.v[0] = lp[x + L2], bv.v[0] = bb;
+        lp[x] = relax_vec<1>(pc, im, ip, pm, pn, lp[x - 1], lp[x + 1], bv, c, 1u, 1u, acc).v[0];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < T * T * T; e += T * T) {
+    const int k = e % T, r = e / T, i2 = r % T, j2 = r / T;
+    const int gk = K0 + k, gi2 = I0 + i2, gj2 = J0 + j2;
+    if (gk <= g.kk1 && gi2 <= g.ii1 && gj2 <= g.jj1) P[(size_t)gk + (size_t)gi2 * si + (size_t)gj2 * sj] = lp[(k + 1) + L1 * (i2 + 1) + L2 * (j2 + 1)];
+  }
+  const double sblk = block_sum<T * T>(acc, wsum);
+  if (t == 0) tile_partials[(size_t)tk + (size_t)g.ntk * (ti + (size_t)g.nti * tj)] = sblk;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // pcr_rb, fast form.  The matrix of every k-line is the same (a = c = -1/6, zero at the ends; cz_solver.f90:545-556), so
 // the a/c recurrences of the reduction and the reciprocals e = 1/(1 - ap*c(kl) - cp*a(kr)) (:572-595), and cc1/aa2/jj of
 // the final 2x2 systems (:599-616), are identical for all lines: pcr_coef_k evaluates them ONCE, with the reference's
@@ -1657,9 +1742,9 @@ struct Ctx {
 };
 thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
 
-enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_SHELL, LBL_COUNT };
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_SHELL, LBL_PSOR, LBL_COUNT };
 static_assert(LBL_COUNT <= 16, "Ctx::t_acc / t_cnt hold 16 labels");
-const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb", "pair_shell"};
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb", "pair_shell", "psor"};
 
 struct ScopedTimer {
   bool on;
@@ -2236,6 +2321,38 @@ void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, cons
   exit(1);
 }
 
+// one lexicographic SOR sweep (psor / psor_maf): a launch per tile hyperplane, then the fixed-order sum of the tile partials
+void launch_psor(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* res_dev, int accumulate, const int* skip,
+                 const MafArgs* ma) {
+  if (bx.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  constexpr int T = 16;
+  PsorGeom g;
+  g.nkp = bx.nkp, g.nip = bx.nip, g.njp = bx.njp;
+  g.kk0 = bx.kk0, g.kk1 = bx.kk1, g.ii0 = bx.ii0, g.ii1 = bx.ii1, g.jj0 = bx.jj0, g.jj1 = bx.jj1;
+  g.ntk = (bx.kk1 - bx.kk0 + T) / T, g.nti = (bx.ii1 - bx.ii0 + T) / T, g.ntj = (bx.jj1 - bx.jj0 + T) / T;
+  const size_t ntiles = (size_t)g.ntk * g.nti * g.ntj;
+  ensure_partials(ntiles);
+  const size_t lds = ((size_t)(T + 2) * (T + 2) * (T + 2) + (size_t)T * T * T) * sizeof(REAL);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&psor_tile_k<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&psor_tile_k<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  {
+    ScopedTimer tm(LBL_PSOR);
+    for (int H = 0; H <= g.ntk + g.nti + g.ntj - 3; H++) {
+      if (ma) hipLaunchKernelGGL((psor_tile_k<T, 1>), dim3(g.nti, g.ntj), dim3(T * T), lds, ctx.stream, p, b, c, g, H, ctx.partials, skip, *ma);
+      else hipLaunchKernelGGL((psor_tile_k<T, 0>), dim3(g.nti, g.ntj), dim3(T * T), lds, ctx.stream, p, b, c, g, H, ctx.partials, skip, MafArgs());
+    }
+  }
+  HIP_CHECK(hipGetLastError());
+  reduce_partials((int)ntiles, res_dev, accumulate, skip);
+}
+
 void launch_imask(REAL* x, const Box& b) {
   hipLaunchKernelGGL(imask_k, dim3(2048), dim3(256), 0, ctx.stream, x, b.nkp, b.nip, b.njp, b.kk0, b.kk1, b.ii0, b.ii1, b.jj0, b.jj1);
   HIP_CHECK(hipGetLastError());
@@ -2694,6 +2811,30 @@ void psor2sma_core_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_RE
   *res += read_scalar(0);
 }
 
+void psor_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, CZ_REAL* omg, CZ_REAL* b, double* res, double* flop) {
+  ensure_init();
+  *flop += 18.0 * npts(idx);  // cz_solver.f90:237-240
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_psor(p, b, make_coef(cf, *omg), bx, ctx.scal_dev + 0, 0, nullptr, nullptr);
+  *res += read_scalar(0);
+}
+
+void psor_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, CZ_REAL* omg, CZ_REAL* b, double* res,
+               double* flop) {
+  ensure_init();
+  *flop += 66.0 * npts(idx);  // cz_maf.f90:50-53
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  if (bx.g != 2) {
+    fprintf(stderr, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2), cz_maf.f90:36-38)\n");
+    exit(1);
+  }
+  const MafArgs ma = upload_xyz(sz, *g, X, Y, Z, nullptr);
+  launch_psor(p, b, make_coef_omg(*omg), bx, ctx.scal_dev + 0, 0, nullptr, &ma);
+  *res += read_scalar(0);
+}
+
 void calc_rk_maf_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z,
                   CZ_REAL* pvt, double* flop) {
   ensure_init();
@@ -2849,6 +2990,18 @@ void rbsor_maf_async(REAL* p, const REAL* b, const int* sz, const int* idx, int 
   if (check) ck.enabled = 1, ck.itr = itr, ck.res_normal = res_normal, ck.eps = eps, ck.hist = hist, ck.flag = flag, ck.conv_itr = conv_itr;
   sweep_async<MODE_RB>(p, p, b, bx, make_coef_omg(omg), rb_parity(g, idx, ofst, color), res_dev, accumulate, check ? flag : skip, ck,
                        &ma);
+}
+// one psor / psor_maf sweep (xc == nullptr: constant coefficients cf), res_dev[0] = or += sum dp^2
+void psor_async(REAL* p, const REAL* b, const int* sz, const int* idx, int g, const REAL* cf, const REAL* xc, const REAL* yc,
+                const REAL* zc, REAL omg, double* res_dev, int accumulate, const int* skip) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, g);
+  if (xc) {
+    MafArgs ma{xc, yc, zc, nullptr};
+    launch_psor(p, b, make_coef_omg(omg), bx, res_dev, accumulate, skip, &ma);
+  } else {
+    launch_psor(p, b, make_coef(cf, omg), bx, res_dev, accumulate, skip, nullptr);
+  }
 }
 void calc_ax_maf_async(REAL* ap, const REAL* p, const int* sz, const int* idx, int g, const REAL* xc, const REAL* yc, const REAL* zc,
                        const REAL* pvt) {

@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
     "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
     "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async", "czhip_jacobi_checked_async",
-    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_use_t2", "czhip_rbsor2_async", "czhip_jacobi2_from_zero_async", "czhip_check2_async", "czhip_pair_split_async",
+    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_use_t2", "czhip_rbsor2_async", "czhip_jacobi2_from_zero_async", "czhip_check2_async", "czhip_pair_split_async", "psor_", "psor_maf_",
     "cz_create", "cz_destroy", "cz_evaluate", "cz_setup", "cz_solve", "cz_sweeps", "cz_result_iter", "cz_result_res",
     "cz_history", "cz_field", "cz_local_size", "cz_error_max", "cz_set_quiet", "cz_last_solve_seconds", "cz_kernel_ms",
     "cz_set_debug", "cz_set_profile", "czhip_timing", "czhip_timing_read",
@@ -202,6 +202,21 @@ class CzHip:
         r, fl = C.c_double(res), C.c_double(0.0)
         self.lib.jacobi_maf_(C.c_void_p(p.ptr), szp, idxp, C.byref(g), xp, yp, zp, self._s(omg), C.c_void_p(b.ptr), C.byref(r),
                              C.c_void_p(wk2.ptr), tmp.ctypes.data_as(C.c_void_p), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def psor(self, p, sz, idx, cf, omg, b, res=0.0):
+        (_, szp), (_, idxp), (_, cfp), g = self._i(sz), self._i(idx), self._r(cf), C.c_int(GUIDE)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self.lib.psor_(C.c_void_p(p.ptr), szp, idxp, C.byref(g), cfp, self._s(omg), C.c_void_p(b.ptr), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def psor_maf(self, p, sz, idx, x, y, z, omg, b, res=0.0):
+        (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
+        (xk, xp), (yk, yp), (zk, zp) = self._r(x), self._r(y), self._r(z)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self.lib.psor_maf_(C.c_void_p(p.ptr), szp, idxp, C.byref(g), xp, yp, zp, self._s(omg), C.c_void_p(b.ptr), C.byref(r), C.byref(fl))
         self.last_flop = fl.value
         return r.value
 

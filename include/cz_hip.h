@@ -88,6 +88,13 @@ void calc_rk_maf_(CZ_REAL* r, CZ_REAL* p, CZ_REAL* b, int* sz, int* idx, int* g,
 /* cz_Ffunc.h:536-545 <- cz_blas.f90:845-934   ap = (sum w*p_nb - dd*p) * pvt */
 void calc_ax_maf_(CZ_REAL* ap, CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, CZ_REAL* pvt,
                   double* flop);
+/* Lexicographic point SOR.  Semantics = ONE thread of the reference (its PARALLEL DO makes the result
+ * depend on the thread count); computed as a two-level hyperplane wavefront, bit-identical to the sequential loop. */
+/* cz_Ffunc.h:38-46 <- cz_solver.f90:207-269 */
+void psor_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* cf, CZ_REAL* omg, CZ_REAL* b, double* res, double* flop);
+/* cz_Ffunc.h:184-194 <- cz_maf.f90:23-112 */
+void psor_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z, CZ_REAL* omg, CZ_REAL* b, double* res,
+               double* flop);
 /* cz_Ffunc.h:547-553 <- cz_blas.f90:947-1039  pvt = 1 / max |row entries| */
 void search_pivot_(CZ_REAL* pvt, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ_REAL* Z);
 

@@ -475,6 +475,74 @@ void oracle_psor2sma_core_maf(REAL* p, const int* sz, const int* idx, const int*
   oracle_psor2sma_core_maf_w(p, sz, idx, gp, x, y, z, ofst, color, omg, b, res, tmp, flop, NULL);
 }
 
+/* ---- psor : cz_solver.f90:207-269.  Lexicographic in-place SOR (j outer, i, k inner): every update sees the new values of
+ * its k-1, i-1, j-1 neighbours and the old ones of k+1, i+1, j+1.  SERIAL semantics: the reference's PARALLEL DO makes the
+ * result depend on the thread count; this is what one thread computes. */
+void oracle_psor_w(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* cf, const REAL* omg_p, const REAL* b,
+                   double* res, double* flop, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL c1 = cf[0], c2 = cf[1], c3 = cf[2], c4 = cf[3], c5 = cf[4], c6 = cf[5], dd = cf[6];
+  const REAL omg = *omg_p;
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  *flop += 18.0 * NPTS;
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        const REAL pp = p[IDX(k, i, j)];
+        const REAL bb = b[IDX(k, i, j)];
+        const REAL ss = c1 * p[IDX(k, i + 1, j)] + c2 * p[IDX(k, i - 1, j)] + c3 * p[IDX(k, i, j + 1)] + c4 * p[IDX(k, i, j - 1)] +
+                        c5 * p[IDX(k + 1, i, j)] + c6 * p[IDX(k - 1, i, j)];
+        const REAL dp = ((ss - bb) / dd - pp) * omg;
+        p[IDX(k, i, j)] = pp + dp;
+        const REAL d2 = dp * dp;
+        res1 = res1 + d2;
+        resw += (double)d2;
+      }
+  *res = *res + (double)res1;
+  if (res_wide) *res_wide += resw;
+}
+
+void oracle_psor(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* cf, const REAL* omg, const REAL* b, double* res,
+                 double* flop) {
+  oracle_psor_w(p, sz, idx, gp, cf, omg, b, res, flop, NULL);
+}
+
+/* ---- psor_maf : cz_maf.f90:23-112, same ordering */
+void oracle_psor_maf_w(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y, const REAL* z,
+                       const REAL* omg_p, const REAL* b, double* res, double* flop, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const REAL omg = *omg_p;
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  *flop += 66.0 * NPTS;
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++)
+      for (int k = kst; k <= ked; k++) {
+        const REAL bb = b[IDX(k, i, j)];
+        const REAL pp = p[IDX(k, i, j)];
+        MAF_COEF;
+        const REAL dd = (REAL)2.0 * (C1 + C2 + C3);
+        const REAL rp = (C1 + (REAL)0.5 * C7) * p[IDX(k, i + 1, j)] + (C1 - (REAL)0.5 * C7) * p[IDX(k, i - 1, j)] +
+                        (C2 + (REAL)0.5 * C8) * p[IDX(k, i, j + 1)] + (C2 - (REAL)0.5 * C8) * p[IDX(k, i, j - 1)] +
+                        (C3 + (REAL)0.5 * C9) * p[IDX(k + 1, i, j)] + (C3 - (REAL)0.5 * C9) * p[IDX(k - 1, i, j)] + bb;
+        const REAL dp = (rp / dd - pp) * omg;
+        p[IDX(k, i, j)] = pp + dp;
+        const REAL d2 = dp * dp;
+        res1 = res1 + d2;
+        resw += (double)d2;
+      }
+  *res = *res + (double)res1;
+  if (res_wide) *res_wide += resw;
+}
+
+void oracle_psor_maf(REAL* p, const int* sz, const int* idx, const int* gp, const REAL* x, const REAL* y, const REAL* z,
+                     const REAL* omg, const REAL* b, double* res, double* flop) {
+  oracle_psor_maf_w(p, sz, idx, gp, x, y, z, omg, b, res, flop, NULL);
+}
+
 /* ---- calc_rk_maf : cz_blas.f90:738-832   r = (b + dd*p - sum w*p_nb) * pvt */
 void oracle_calc_rk_maf(REAL* r, const REAL* p, const REAL* b, const int* sz, const int* idx, const int* gp, const REAL* x,
                         const REAL* y, const REAL* z, const REAL* pvt, double* flop) {

@@ -120,6 +120,34 @@ class Kernels:
         self.last_flop = fl.value
         return r.value
 
+    def psor(self, p, sz, idx, cf, omg, b, res=0.0, wide=None):
+        """lexicographic in-place SOR, one thread (cz_solver.f90:207-269)"""
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        cf = np.ascontiguousarray(cf, dtype=self.real)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        args = [self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(cf), self._rs(omg), self._rp(b), C.byref(r), C.byref(fl)]
+        if wide is not None:
+            assert self.kind == "oracle"
+            self.lib.oracle_psor_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("psor")(*args)
+        self.last_flop = fl.value
+        return r.value
+
+    def psor_maf(self, p, sz, idx, x, y, z, omg, b, res=0.0, wide=None):
+        """cz_maf.f90:23-112"""
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        args = [self._rp(p), self._ip(sz), self._ip(idx), C.byref(g), self._rp(x), self._rp(y), self._rp(z), self._rs(omg), self._rp(b),
+                C.byref(r), C.byref(fl)]
+        if wide is not None:
+            assert self.kind == "oracle"
+            self.lib.oracle_psor_maf_w(*args, wide.ctypes.data_as(_c_dbl_p))
+        else:
+            self._f("psor_maf")(*args)
+        self.last_flop = fl.value
+        return r.value
+
     def blas_clear(self, x, sz):
         sz, g = _ia(sz), C.c_int(GUIDE)
         self._f("blas_clear")(self._rp(x), self._ip(sz), C.byref(g))
@@ -397,6 +425,26 @@ class CZ:
             itr += 1
         return itr, res
 
+    # cz_Poisson.cpp:95-146
+    def PSOR(self, X, B, itr_max, converge_check=True, maf=False):
+        k, res, itr = self.k, 0.0, 1
+        while itr <= itr_max:
+            w = np.zeros(1) if self.wide else None
+            if maf:
+                res = k.psor_maf(X, self.size, self.idx, self.xc, self.yc, self.zc, self.ac1, B, res=0.0, wide=w)
+            else:
+                res = k.psor(X, self.size, self.idx, self.cf, self.ac1, B, res=0.0, wide=w)
+            if self.wide:
+                res = float(w[0])
+            if converge_check:
+                res = math.sqrt(res * self.res_normal)
+                self.history.append((itr, res))
+                k.bc_k(self.size, X, self.pitch, self.origin, self.nID)
+                if res < self.eps:
+                    break
+            itr += 1
+        return itr, res
+
     # cz_Poisson.cpp:518-611
     def LSOR_PCR_RB(self, X, B, itr_max, converge_check=True):
         k, res, itr = self.k, 0.0, 1
@@ -424,6 +472,8 @@ class CZ:
             self.JACOBI(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
         elif pc in ("sor2sma", "sor2sma_maf"):
             self.RBSOR(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
+        elif pc in ("psor", "psor_maf"):
+            self.PSOR(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
         elif pc == "pcr_rb":
             self.LSOR_PCR_RB(xx, bb, LC_MAX, converge_check=False)
         else:
@@ -514,6 +564,8 @@ def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", wit
         itr, res = cz.JACOBI(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
     elif solver in ("sor2sma", "sor2sma_maf"):
         itr, res = cz.RBSOR(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
+    elif solver in ("psor", "psor_maf"):
+        itr, res = cz.PSOR(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
     elif solver == "pcr_rb":
         itr, res = cz.LSOR_PCR_RB(cz.P, cz.RHS, itr_max)
     elif solver in ("pbicgstab", "pbicgstab_maf"):

@@ -122,6 +122,13 @@ def kernel_vectors(prec):
             out[f"maf_rb{ofst}_p_c{color}"] = ps.copy()
             out[f"maf_rb{ofst}_res_c{color}"] = np.array(r)
     apm = rnd()
+    # psor / psor_maf: lexicographic in-place SOR, ONE thread
+    pp_ = p.copy()
+    out["psor_res"] = np.array(k.psor(pp_, sz, idx, cf, OMG, b, res=0.125))
+    out["psor_p"], out["psor_flop"] = pp_, np.array(k.last_flop)
+    pp_ = p.copy()
+    out["maf_psor_res"] = np.array(k.psor_maf(pp_, sz, idx, xc, yc, zc, OMG, b, res=0.125))
+    out["maf_psor_p"], out["maf_psor_flop"] = pp_, np.array(k.last_flop)
     out["maf_ax_in"] = apm.copy()
     k.calc_ax_maf(apm, p, sz, idx, xc, yc, zc, pv)
     out["maf_ax"] = apm
@@ -192,6 +199,12 @@ SOLVER_CASES = [
     ((32, 32, 32), "pbicgstab_maf", 100, 0.8, "jacobi_maf", "f64", None),
     ((32, 32, 32), "pbicgstab_maf", 100, 1.5, "sor2sma_maf", "f64", None),
     ((32, 32, 32), "pbicgstab_maf", 100, 0.8, "jacobi", "f32", None),
+    # lexicographic point SOR, one thread
+    ((32, 32, 32), "psor", 40, 1.1, None, "f32", None),
+    ((24, 20, 36), "psor", 30, 1.3, None, "f64", None),
+    ((64, 64, 64), "psor", 100000, 1.5, None, "f64", None),
+    ((32, 32, 32), "psor_maf", 30, 1.1, None, "f32", None),
+    ((32, 32, 32), "pbicgstab", 100, 1.2, "psor", "f64", None),
     # line SOR by PCR, serial reference build
     ((32, 32, 32), "pcr_rb", 40, 1.2, None, "f32", None),
     ((24, 20, 36), "pcr_rb", 30, 1.1, None, "f64", None),

@@ -471,3 +471,48 @@ def test_pair_split_equals_unsplit(prec, rb):
         assert _beq(dw2.get(), dw1.get()), pat
         assert _rel(r2a, r1a) < 1e-12 and (rb >= 0 or _rel(r2b, r1b) < 1e-12)
         assert du.get().tobytes() == u0.tobytes()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_psor_golden_vectors(prec):
+    """lexicographic point SOR: vectors from ONE thread of the reference."""
+    g = np.load(os.path.join(GOLDEN, f"kernels_{prec}.npz"))
+    h = _hip(prec)
+    sz, idx, cf, omg = list(g["sz"]), list(g["idx"]), g["cf"], float(g["omg"])
+    p, b = h.alloc(sz, g["in_p"]), h.alloc(sz, g["in_b"])
+    r = h.psor(p, sz, idx, cf, omg, b, res=0.125)
+    assert _beq(p.get(), g["psor_p"]) and _rel(r, float(g["psor_res"])) < (1e-3 if prec == "f32" else 1e-12)
+    assert h.last_flop == float(g["psor_flop"])
+    p = h.alloc(sz, g["in_p"])
+    r = h.psor_maf(p, sz, idx, g["maf_x"], g["maf_y"], g["maf_z"], omg, b, res=0.125)
+    assert _beq(p.get(), g["maf_psor_p"]) and _rel(r, float(g["maf_psor_res"])) < (1e-3 if prec == "f32" else 1e-12)
+    assert h.last_flop == float(g["maf_psor_flop"])
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", [(16, 16, 16), (18, 18, 18), (33, 17, 50), (70, 41, 90), (5, 64, 7)], ids=lambda b: "x".join(map(str, b)))
+def test_psor_random_boxes_vs_oracle(prec, box):
+    """tile-hyperplane wavefront == the sequential loop, bit for bit; tiles that overhang the box, one-tile and many-tile boxes,
+    sub-boxes that do not start at 2."""
+    ni, nj, nk = box
+    sz = [ni, nj, nk]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni * 7 + nj * 3 + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    p0, b0 = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    cf = [1.1, 0.9, 1.05, 0.95, 1.2, 0.8, 6.3]
+    xc, yc, zc = (np.cumsum(rng.uniform(0.5, 1.5, n + 4)).astype(R) for n in (ni, nj, nk))
+    for idx in ([2, ni - 1, 2, nj - 1, 2, nk - 1], [1, ni, 1, nj, 1, nk], [3, ni - 2, 2, nj - 1, 4, nk - 1]):
+        p1, dp, db = p0.copy(), h.alloc(sz, p0), h.alloc(sz, b0)
+        w = np.zeros(1)
+        ko.psor(p1, sz, idx, cf, 1.2, b0, wide=w)
+        r = h.psor(dp, sz, idx, cf, 1.2, db)
+        assert _beq(dp.get(), p1), idx
+        assert _rel(r, float(w[0])) < 1e-12
+        p1, dp = p0.copy(), h.alloc(sz, p0)
+        w = np.zeros(1)
+        ko.psor_maf(p1, sz, idx, xc, yc, zc, 1.2, b0, wide=w)
+        r = h.psor_maf(dp, sz, idx, xc, yc, zc, 1.2, db)
+        assert _beq(dp.get(), p1), idx
+        assert _rel(r, float(w[0])) < 1e-12

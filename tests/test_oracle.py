@@ -89,6 +89,13 @@ def test_kernels_match_golden(prec):
     k.calc_rk_maf(a, p, b, sz, idx, xc, yc, zc, pv)
     assert _beq(a, g["maf_rk"])
 
+    # lexicographic point SOR, one thread
+    pp = g["in_p"].copy()
+    assert k.psor(pp, sz, idx, cf, omg, b, res=0.125) == float(g["psor_res"]) and _beq(pp, g["psor_p"])
+    assert k.last_flop == float(g["psor_flop"])
+    pp = g["in_p"].copy()
+    assert k.psor_maf(pp, sz, idx, xc, yc, zc, omg, b, res=0.125) == float(g["maf_psor_res"]) and _beq(pp, g["maf_psor_p"])
+
     # line SOR by PCR (fixtures from the reference's serial build)
     for (ni, nj, nk) in ((9, 8, 13), (12, 10, 37), (6, 7, 64)):
         szp, idp, tag = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1], f"pcr_{ni}x{nj}x{nk}"
