@@ -44,6 +44,10 @@ const char* printMethod(int t) {
     case LS_BICGSTAB: return "PBiCGSTAB";
     case LS_PSOR: return "PSOR";
     case LS_PCR_RB: return "PCR_RB";
+    case LS_PCR: return "PCR";
+    case LS_PCR_ESA: return "PCR_ESA";
+    case LS_PCR_RB_ESA: return "PCR_RB_ESA";
+    case LS_PCR_J_ESA: return "PCR_J_ESA";
     case LS_PSOR_MAF: return "PSOR_MAF";
     case LS_JACOBI_MAF: return "JACOBI_MAF";
     case LS_SOR2SMA_MAF: return "SOR2SMA_MAF";
@@ -117,11 +121,14 @@ void CZ::setStrPre() {
   else if (!strcasecmp(precon.c_str(), "jacobi_maf")) pc_type = LS_JACOBI_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "sor2sma_maf")) pc_type = LS_SOR2SMA_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "pcr_rb")) pc_type = LS_PCR_RB;
+  else if (!strcasecmp(precon.c_str(), "pcr_rb_esa")) pc_type = LS_PCR_RB_ESA;  // :585-587
+  else if (!strcasecmp(precon.c_str(), "pcr_j_esa")) pc_type = LS_PCR_J_ESA;    // :588-590 (CZ::Preconditioner has no case for it: acts as none)
+  else if (!strcasecmp(precon.c_str(), "pcr")) pc_type = LS_PCR;                // :591-593
   else if (!strcasecmp(precon.c_str(), "psor")) pc_type = LS_PSOR;
   else if (!strcasecmp(precon.c_str(), "psor_maf")) pc_type = LS_PSOR_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "none")) pc_type = LS_NONE;
   else {
-    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | psor | sor2sma | pcr_rb | jacobi_maf | psor_maf | sor2sma_maf)\n", precon.c_str());
+    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | psor | sor2sma | pcr | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf)\n", precon.c_str());
     exit(0);
   }
 }
@@ -145,6 +152,18 @@ void CZ::setLS(const char* q) {
     ls_type = LS_PSOR_MAF;
     hist_name = "psor_maf.txt";
     SW_maf = 1;
+  } else if (!strcasecmp(q, "pcr_rb_esa")) {  // :712-716
+    ls_type = LS_PCR_RB_ESA;
+    hist_name = "pcr_rb_esa.txt";
+  } else if (!strcasecmp(q, "pcr_j_esa")) {  // :718-722
+    ls_type = LS_PCR_J_ESA;
+    hist_name = "pcr_j_esa.txt";
+  } else if (!strcasecmp(q, "pcr")) {  // :724-727
+    ls_type = LS_PCR;
+    hist_name = "pcr.txt";
+  } else if (!strcasecmp(q, "pcr_esa")) {  // :734-737
+    ls_type = LS_PCR_ESA;
+    hist_name = "pcr_esa.txt";
   } else if (!strcasecmp(q, "pcr_rb")) {  // :707-710, line SOR by parallel cyclic reduction
     ls_type = LS_PCR_RB;
     hist_name = "pcr_rb.txt";
@@ -288,9 +307,10 @@ int CZ::Setup(int argc, char** argv) {
     Hostonly_ printf("psor : single-domain runs only in this build\n");
     return 0;
   }
-  if (ls_type == LS_PCR_RB || pc_type == LS_PCR_RB) {
+  auto is_line = [](int t) { return t == LS_PCR || t == LS_PCR_ESA || t == LS_PCR_RB || t == LS_PCR_RB_ESA || t == LS_PCR_J_ESA; };
+  if (is_line(ls_type) || is_line(pc_type)) {
     if (numProc > 1) {
-      Hostonly_ printf("pcr_rb : single-domain runs only in this build\n");
+      Hostonly_ printf("line SOR (pcr*) : single-domain runs only in this build\n");
       return 0;
     }
     MSK = czhip_alloc_s3d(size);            // :242
@@ -350,6 +370,12 @@ int CZ::Solve() {
     case LS_PSOR:
     case LS_PSOR_MAF:
       if (0 == (itr = PSOR(res, P, RHS, ItrMax, flop, ls_type))) return 0;
+      break;
+    case LS_PCR:
+    case LS_PCR_ESA:
+    case LS_PCR_RB_ESA:
+    case LS_PCR_J_ESA:
+      if (0 == (itr = LSOR_PCR_VARIANT(res, P, RHS, ItrMax, flop, ls_type))) return 0;
       break;
     default:
       break;
@@ -420,13 +446,16 @@ int CZ::Evaluate(int argc, char** argv) {
 // (sweep, residual reduction, convergence bookkeeping) but eps disabled so that nothing is skipped.
 int CZ::Sweeps(int n) {
   if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA && ls_type != LS_JACOBI_MAF && ls_type != LS_SOR2SMA_MAF &&
-                  ls_type != LS_PCR_RB && ls_type != LS_PSOR && ls_type != LS_PSOR_MAF))
+                  ls_type != LS_PCR_RB && ls_type != LS_PSOR && ls_type != LS_PSOR_MAF && ls_type != LS_PCR && ls_type != LS_PCR_ESA &&
+                  ls_type != LS_PCR_RB_ESA && ls_type != LS_PCR_J_ESA))
     return 0;
   const double keep = eps;
   eps = -1.0;
   double res = 0.0, flop = 0.0;
   history.clear();
-  if (ls_type == LS_PSOR || ls_type == LS_PSOR_MAF) PSOR(res, P, RHS, n, flop, ls_type);
+  if (ls_type == LS_PCR || ls_type == LS_PCR_ESA || ls_type == LS_PCR_RB_ESA || ls_type == LS_PCR_J_ESA)
+    LSOR_PCR_VARIANT(res, P, RHS, n, flop, ls_type);
+  else if (ls_type == LS_PSOR || ls_type == LS_PSOR_MAF) PSOR(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_PCR_RB) LSOR_PCR_RB(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_JACOBI || ls_type == LS_JACOBI_MAF) JACOBI(res, P, RHS, n, flop, ls_type);
   else RBSOR(res, P, RHS, n, flop, ls_type);
@@ -815,6 +844,60 @@ int CZ::PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double&
   return finish_stationary(itr_max, 1, converge_check, res);
 }
 
+// cz_Poisson.cpp:621-742 (pcr_rb_esa), :745-826 (pcr), :910-1005 (pcr_esa), :1008-1095 (pcr_j_esa): the line-SOR variants that end
+// in 4x4 systems and / or visit the columns in another order; one loop, the variant picks order and final stage.
+int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  const int n = innerFidx[K_plus] - innerFidx[K_minus] + 1;
+  const int pn = pcr_num_stage(n);
+  if (pn < 0) {
+    printf("error : number of stage\n");
+    exit(0);
+  }
+  const int final4 = (s_type == LS_PCR_J_ESA) ? 0 : 1;
+  const int order = (s_type == LS_PCR_RB_ESA) ? 0 : (s_type == LS_PCR_J_ESA) ? 2 : 1;
+  const int stages = final4 ? pn - 2 : pn - 1;
+  const double fin = final4 ? (double)(1 << (pn - 2)) * (s_type == LS_PCR ? 74.0 : 78.0) : (double)(1 << (pn - 1)) * 9.0;
+  const int* skip = nullptr;
+  if (converge_check) {
+    ensure_hist(itr_max + 2);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    skip = d_flag;
+  }
+  (void)skip;
+  int itr;
+  for (itr = 1; itr <= itr_max; itr++) {
+    if (order == 0) {
+      for (int color = 0; color < 2; color++)
+        pcr_variant_async(X, nullptr, MSK, B, size, innerFidx, gc, pn, 0, color, final4, ac1, d_res, color);  // :685-690
+    } else if (order == 1) {
+      pcr_variant_async(X, nullptr, MSK, B, size, innerFidx, gc, pn, 1, 0, final4, ac1, d_res, 0);  // :783-786, :966-969
+    } else {
+      pcr_variant_async(X, WRK, MSK, B, size, innerFidx, gc, pn, 2, 0, final4, ac1, d_res, 0);  // :1061-1064
+      copy_inner_async(X, WRK, size, innerFidx, gc);
+    }
+    flop += (npts() / n) * (n * 6.0 + n * (double)stages * 14.0 + fin + n * 6.0 + 6.0);
+    if (converge_check) {
+      // long launches: a host round trip per iteration is negligible, the reference's sequential test is kept as is
+      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+      HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (h_flag[0]) break;
+    }
+  }
+  if (converge_check) {
+    const int n_exec = itr > itr_max ? itr_max : itr;
+    const size_t base = history.size();
+    history.resize(base + n_exec);
+    HIP_CHECK(hipMemcpy(history.data() + base, d_hist + 1, (size_t)n_exec * sizeof(double), hipMemcpyDeviceToHost));
+    res = history.back();
+  } else {
+    czhip_sync();
+  }
+  return itr;
+}
+
 // cz_Poisson.cpp:518-611.  Line SOR: every (i,j) column of one checkerboard colour is solved along k by parallel cyclic
 // reduction (pcr_rb_k), colour 0 then colour 1, in place.  Single-domain.
 int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
@@ -906,6 +989,10 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
     case LS_PSOR:
     case LS_PSOR_MAF:
       PSOR(res, xx, bb, lc_max, flop, s_type, false);
+      break;
+    case LS_PCR:
+    case LS_PCR_RB_ESA:  // (LS_PCR_J_ESA has no case in the reference either, cz_Poisson.cpp:282-321: it falls to the copy)
+      LSOR_PCR_VARIANT(res, xx, bb, lc_max, flop, s_type, false);
       break;
     default: {
       const size_t n = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE);

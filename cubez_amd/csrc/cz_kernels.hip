@@ -1200,9 +1200,11 @@ psor_tile_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorGeom g
 // is loaded once per workgroup), gives each wave L lines at a time (one table read serves L lines) and synchronises
 // waves individually (a line never leaves its wave).
 // ------------------------------------------------------------------------------------------------------------
-// table layout: stage p = 1..pn-1: [e | ap | cp] x n entries each, then the final stage: [jj | cc1 | aa2] x nfin entries
+// table layout: stage p = 1..nstage: [e | ap | cp] x n entries each, then the final stage x nfin entries:
+//   final4 = 0 (pcr_rb, pcr_j_esa): nstage = pn-1, 2x2 systems (:599-616): [jj | cc1 | aa2]
+//   final4 = 1 (pcr, pcr_esa, pcr_rb_esa): nstage = pn-2, 4x4 systems by Cramer's rule (:787-842): [inv_detA | cc1 | cc2 | cc3 | aa2 | aa3 | aa4]
 __global__ void __launch_bounds__(256)
-pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin) {
+pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin, int final4) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x, LD = n + 2;
   REAL* A[2] = {reinterpret_cast<REAL*>(smem), reinterpret_cast<REAL*>(smem) + 2 * LD};  // [buf][a | c]
@@ -1216,7 +1218,8 @@ pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin) {
       for (int v = 0; v < 2; v++) A[b][v * LD] = (REAL)0, A[b][v * LD + n + 1] = (REAL)0;
   __syncthreads();
   int cur = 0;
-  for (int p = 1; p <= pn - 1; p++) {
+  const int nstage = final4 ? pn - 2 : pn - 1;
+  for (int p = 1; p <= nstage; p++) {
     const int s = 1 << (p - 1);
     const REAL* a = A[cur];
     const REAL* c = a + LD;
@@ -1236,11 +1239,11 @@ pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin) {
     __syncthreads();
     cur ^= 1;
   }
-  {
+  const REAL* a = A[cur];
+  const REAL* c = a + LD;
+  REAL* F = tab + (size_t)nstage * 3 * n;
+  if (!final4) {
     const int s = 1 << (pn - 1);
-    const REAL* a = A[cur];
-    const REAL* c = a + LD;
-    REAL* F = tab + (size_t)(pn - 1) * 3 * n;
     for (int k = t; k < nfin; k += 256) {
       const int x = k + 1;
       const int kr = (k + s <= n - 1) ? x + s : n + 1;
@@ -1248,6 +1251,16 @@ pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin) {
       F[k] = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
       F[nfin + k] = cc1;
       F[2 * nfin + k] = aa2;
+    }
+  } else {
+    const int s = 1 << (pn - 2);
+    for (int k = t; k < nfin; k += 256) {
+      const int x = k + 1;
+      const int kl = (k + s <= n - 1) ? x + s : n + 1, km = (k + 2 * s <= n - 1) ? x + 2 * s : n + 1, kr = (k + 3 * s <= n - 1) ? x + 3 * s : n + 1;
+      const REAL cc1 = c[x], cc2 = c[kl], cc3 = c[km], aa2 = a[kl], aa3 = a[km], aa4 = a[kr];
+      F[k] = (REAL)1.0 / ((REAL)1.0 - aa4 * cc3 - aa3 * cc2 - aa2 * cc1 * ((REAL)1.0 - cc3 * aa4));
+      F[nfin + k] = cc1, F[2 * nfin + k] = cc2, F[3 * nfin + k] = cc3;
+      F[4 * nfin + k] = aa2, F[5 * nfin + k] = aa3, F[6 * nfin + k] = aa4;
     }
   }
 }
@@ -1259,10 +1272,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NW, int L>
+// ORDER selects the columns of one launch (the line-SOR variants of cz_solver.f90 differ in the column order):
+//   0  one checkerboard colour, in place          pcr_rb (:540), pcr_rb_esa (:1324)           g.color = colour
+//   1  one diagonal (i-ist)+(j-jst) = g.color of the lexicographic order, in place: a column of pcr (:718-719) / pcr_esa sees
+//      the new values of its i-1 and j-1 neighbours, which lie on the diagonal before => diagonals in sequence, columns of one in parallel
+//   2  all columns from the old field, result into WOUT (pcr_j_esa :1553-1632; the caller copies back, :1655-1663)
+template <int NW, int L, int FINAL4, int ORDER>
 __global__ void __launch_bounds__(64 * NW)
-pcr_rb2_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, const REAL* __restrict__ tab,
-          int tab_len, int nfin, double* partials, double* dst, int accumulate, unsigned* counter) {
+pcr_rb2_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg,
+          const REAL* __restrict__ tab, int tab_len, int nfin, double* partials, double* dst, int accumulate, unsigned* counter) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
@@ -1277,7 +1295,10 @@ pcr_rb2_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, P
 
   const REAL r = (REAL)1.0 / (REAL)6.0;
   const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
-  const long long ncol = (long long)g.nhalf * g.nj;
+  const int dlo = (ORDER == 1) ? max(0, g.color - (g.nj - 1)) : 0;  // first i offset on the diagonal
+  const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj
+                         : (ORDER == 1) ? (long long)(min(g.ni - 1, g.color) - dlo + 1)
+                                        : (long long)g.ni * g.nj;
   const long long ngroups = (ncol + L - 1) / L;
   double acc = 0.0;
   for (long long q = (long long)blockIdx.x * NW + wave; q < ngroups; q += (long long)gridDim.x * NW) {
@@ -1285,18 +1306,28 @@ pcr_rb2_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, P
     bool act[L];
 #pragma unroll
     for (int l = 0; l < L; l++) {
-      const long long col = q * L + l;  // column ordinal among the colour's columns
-      const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
-      act[l] = jrow < g.nj;
+      const long long col = q * L + l;  // column ordinal among the launch's columns
       int ii = 0, jj = 0;
-      if (act[l]) {
-        const int j1 = g.jst1 + jrow;
-        int i1 = g.ist1 + 2 * ih;
-        if (((i1 + j1) & 1) != g.color) i1 += 1;  // first i of this colour in the row
-        act[l] = (i1 - g.ist1) < g.ni;
-        ii = g.ii0 + (i1 - g.ist1);
-        jj = g.jj0 + jrow;
+      if (ORDER == 0) {
+        const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+        act[l] = jrow < g.nj;
+        if (act[l]) {
+          const int j1 = g.jst1 + jrow;
+          int i1 = g.ist1 + 2 * ih;
+          if (((i1 + j1) & 1) != g.color) i1 += 1;  // first i of this colour in the row
+          act[l] = (i1 - g.ist1) < g.ni;
+          ii = g.ii0 + (i1 - g.ist1);
+          jj = g.jj0 + jrow;
+        }
+      } else if (ORDER == 1) {
+        act[l] = col < ncol;
+        const int io = dlo + (int)col;
+        ii = g.ii0 + io, jj = g.jj0 + (g.color - io);
+      } else {
+        act[l] = col < ncol;
+        ii = g.ii0 + (int)(col % g.ni), jj = g.jj0 + (int)(col / g.ni);
       }
+      if (!act[l]) ii = g.ii0, jj = g.jj0;
       c0[l] = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;  // element (kst, i, j)
     }
     // ---- source term (:558-568)
@@ -1318,7 +1349,8 @@ pcr_rb2_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, P
     wave_lds_sync();
     // ---- PCR stages (:572-595), right-hand side only
     int cur = 0;
-    for (int p = 1; p <= g.pn - 1; p++) {
+    const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
+    for (int p = 1; p <= nstage; p++) {
       const int s = 1 << (p - 1);
       const REAL* Tp = T + (size_t)(p - 1) * 3 * n;
       const REAL* dc = D + (size_t)cur * L * LD;
@@ -1334,10 +1366,34 @@ pcr_rb2_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, P
       wave_lds_sync();
       cur ^= 1;
     }
-    // ---- 2x2 systems of the last stage (:599-616)
-    {
+    // ---- 4x4 systems of the last stage by Cramer's rule (:787-842; pcr, pcr_esa, pcr_rb_esa)
+    if (FINAL4) {
+      const int s = 1 << (g.pn - 2);
+      const REAL* F = T + (size_t)nstage * 3 * n;
+      const REAL* dc = D + (size_t)cur * L * LD;
+      REAL* dn = D + (size_t)(cur ^ 1) * L * LD;
+      for (int k = lane; k < nfin; k += 64) {
+        const int x = k + 1;
+        const int kl = (k + s <= n - 1) ? x + s : n + 1, km = (k + 2 * s <= n - 1) ? x + 2 * s : n + 1, kr = (k + 3 * s <= n - 1) ? x + 3 * s : n + 1;
+        const REAL inv_detA = F[k], cc1 = F[nfin + k], cc2 = F[2 * nfin + k], cc3 = F[3 * nfin + k];
+        const REAL aa2 = F[4 * nfin + k], aa3 = F[5 * nfin + k], aa4 = F[6 * nfin + k];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const REAL dd1 = dc[l * LD + x], dd2 = dc[l * LD + kl], dd3 = dc[l * LD + km], dd4 = dc[l * LD + kr];
+          const REAL detA1 = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+          const REAL detA2 = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+          const REAL detA3 = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+          const REAL detA4 = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+          dn[l * LD + x] = detA1 * inv_detA;
+          if (kl <= n) dn[l * LD + kl] = detA2 * inv_detA;
+          if (km <= n) dn[l * LD + km] = detA3 * inv_detA;
+          if (kr <= n) dn[l * LD + kr] = detA4 * inv_detA;
+        }
+      }
+      wave_lds_sync();
+    } else {  // ---- 2x2 systems of the last stage (:599-616)
       const int s = 1 << (g.pn - 1);
-      const REAL* F = T + (size_t)(g.pn - 1) * 3 * n;
+      const REAL* F = T + (size_t)nstage * 3 * n;
       const REAL* dc = D + (size_t)cur * L * LD;
       REAL* dn = D + (size_t)(cur ^ 1) * L * LD;
       for (int k = lane; k < nfin; k += 64) {
@@ -1365,7 +1421,8 @@ pcr_rb2_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, P
           const size_t e = c0[l] + k;
           const REAL pp = X[e];
           const REAL dp = (d1[l * LD + k + 1] - pp) * omg * MSK[e];
-          X[e] = pp + dp;
+          if (ORDER == 2) WOUT[e] = pp + dp;
+          else X[e] = pp + dp;
           const REAL d2 = dp * dp;
           acc += (double)d2;
         }
@@ -1720,7 +1777,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   double* partials = nullptr;   // device
   REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
-  int pcr_tab_n = 0, pcr_tab_pn = 0;
+  int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
   size_t pcr_tab_cap = 0;
   double* shell_partials = nullptr;  // per-workgroup sums of the last pair_shell_k launch, folded in by the interior launch
   int shell_pending = 0;
@@ -2242,39 +2299,40 @@ bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, 
   return true;
 }
 
-template <int NW, int L>
-bool try_pcr_rb2_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate, int tab_len,
-                      int nfin) {
+template <int NW, int L, int FINAL4, int ORDER>
+bool try_pcr_rb2_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
+                      int tab_len, int nfin, long long ncol) {
   const size_t lds = ((size_t)tab_len + (size_t)NW * 2 * L * (g.n + 2) + 8) * sizeof(REAL) + 32 * sizeof(double);
   if (lds > 160 * 1024) return false;
-  const long long ncol = (long long)g.nhalf * g.nj;
   const long long ngroups = (ncol + L - 1) / L;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(32 / NW)));
-  const unsigned nblk = (unsigned)std::min<long long>((ngroups + NW - 1) / NW, (long long)ctx.num_cu * per_cu);
+  const unsigned nblk = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + NW - 1) / NW, (long long)ctx.num_cu * per_cu));
   ensure_partials(nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb2_k<NW, L>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb2_k<NW, L, FINAL4, ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
     attr_set = true;
   }
   ScopedTimer tm(LBL_PCR);
-  hipLaunchKernelGGL((pcr_rb2_k<NW, L>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.pcr_tab, tab_len, nfin,
-                     ctx.partials, res_dev, accumulate, ctx.counter);
+  hipLaunchKernelGGL((pcr_rb2_k<NW, L, FINAL4, ORDER>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, wout, msk, rhs, g, omg, ctx.pcr_tab,
+                     tab_len, nfin, ctx.partials, res_dev, accumulate, ctx.counter);
   HIP_CHECK(hipGetLastError());
   return true;
 }
 
-// fast form: coefficient table (computed once per line length) + persistent right-hand-side-only kernel
-bool try_pcr_rb2(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate) {
+// fast form: coefficient table (computed once per line length and variant) + persistent right-hand-side-only kernel
+template <int FINAL4, int ORDER>
+bool try_pcr_rb2(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate) {
   const int n = g.n, pn = g.pn;
-  if (pn < 2 || pn > 20) return false;
-  const int s = 1 << (pn - 1);
-  const int nfin = std::min(s, n);
-  const int tab_len = (pn - 1) * 3 * n + 3 * nfin;
+  if (pn < (FINAL4 ? 3 : 2) || pn > 20) return false;
+  const int nstage = FINAL4 ? pn - 2 : pn - 1;
+  const int nfin = std::min(1 << nstage, n);
+  const int tab_len = nstage * 3 * n + (FINAL4 ? 7 : 3) * nfin;
   const size_t fixed = ((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double);
   const size_t per_line = (size_t)2 * (n + 2) * sizeof(REAL);
   if (fixed + 4 * per_line > 160 * 1024) return false;  // table + four lines must fit
-  if (ctx.pcr_tab_n != n || ctx.pcr_tab_pn != pn) {
+  if (ctx.pcr_tab_n != n || ctx.pcr_tab_pn != pn || ctx.pcr_tab_final4 != FINAL4) {
     if ((size_t)tab_len > ctx.pcr_tab_cap) {
       if (ctx.pcr_tab) {
         HIP_CHECK(hipStreamSynchronize(ctx.stream));
@@ -2283,19 +2341,67 @@ bool try_pcr_rb2(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, RE
       HIP_CHECK(hipMalloc(&ctx.pcr_tab, (size_t)tab_len * sizeof(REAL)));
       ctx.pcr_tab_cap = tab_len;
     }
-    hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), (size_t)4 * (n + 2) * sizeof(REAL), ctx.stream, ctx.pcr_tab, n, pn, nfin);
+    hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), (size_t)4 * (n + 2) * sizeof(REAL), ctx.stream, ctx.pcr_tab, n, pn, nfin, FINAL4);
     HIP_CHECK(hipGetLastError());
-    ctx.pcr_tab_n = n, ctx.pcr_tab_pn = pn;
+    ctx.pcr_tab_n = n, ctx.pcr_tab_pn = pn, ctx.pcr_tab_final4 = FINAL4;
+  }
+  long long ncol;
+  if (ORDER == 0) ncol = (long long)g.nhalf * g.nj;
+  else if (ORDER == 1) ncol = std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1;
+  else ncol = (long long)g.ni * g.nj;
+  if (ORDER == 1) {  // a diagonal holds few lines: small workgroups spread them over the chip
+    if (try_pcr_rb2_inst<4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+    return false;
   }
   const int v = ctx.tune.pcr_variant;
   // measured at 512^3 FP32 (profiles/r01/pcr_variants.txt): waves per CU matter most, 16 x 1 line beats 8 x 2 lines
   if (v == 0 || v == 161)
-    if (try_pcr_rb2_inst<16, 1>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin)) return true;
+    if (try_pcr_rb2_inst<16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
   if (v == 0 || v == 82)
-    if (try_pcr_rb2_inst<8, 2>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin)) return true;
+    if (try_pcr_rb2_inst<8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
   if (v == 0 || v == 81)
-    if (try_pcr_rb2_inst<8, 1>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin)) return true;
-  return try_pcr_rb2_inst<4, 1>(x, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin);
+    if (try_pcr_rb2_inst<8, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+  return try_pcr_rb2_inst<4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol);
+}
+
+PcrGeom make_pcr_geom(const Box& b, const int* idx, int pn, int sel) {
+  PcrGeom g;
+  g.nkp = b.nkp, g.nip = b.nip;
+  g.kk0 = b.kk0, g.n = b.kk1 - b.kk0 + 1;
+  g.ii0 = b.ii0, g.ni = b.ii1 - b.ii0 + 1, g.jj0 = b.jj0, g.nj = b.jj1 - b.jj0 + 1;
+  g.ist1 = idx[0], g.jst1 = idx[2];
+  g.pn = pn, g.color = sel;
+  g.nhalf = (g.ni + 1) / 2 + 1;
+  return g;
+}
+
+// The line-SOR variants that end in 4x4 systems or visit the columns in another order (pcr, pcr_esa, pcr_rb_esa, pcr_j_esa).
+// order 0: colour `sel` in place; 1: lexicographic in place = one launch per diagonal; 2: all columns, x -> wout.
+// They exist in the table form only: a line whose table does not fit LDS is refused.
+void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int order, int sel,
+                        int final4, REAL omg, double* res_dev, int accumulate) {
+  if (b.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  bool ok = true;
+  if (order == 1) {
+    const int ni = b.ii1 - b.ii0 + 1, nj = b.jj1 - b.jj0 + 1;
+    for (int dgn = 0; dgn <= ni + nj - 2 && ok; dgn++) {
+      const PcrGeom g = make_pcr_geom(b, idx, pn, dgn);
+      ok = final4 ? try_pcr_rb2<1, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0)
+                  : try_pcr_rb2<0, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0);
+    }
+  } else {
+    const PcrGeom g = make_pcr_geom(b, idx, pn, sel);
+    if (order == 0) ok = final4 ? try_pcr_rb2<1, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
+    else ok = final4 ? try_pcr_rb2<1, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
+  }
+  if (!ok) {
+    fprintf(stderr, "czhip: line SOR (4x4 / ordered variants): the coefficient table of a k-line of %d unknowns does not fit the 160 KiB of LDS\n",
+            b.kk1 - b.kk0 + 1);
+    exit(1);
+  }
 }
 
 void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int color, REAL omg,
@@ -2311,7 +2417,7 @@ void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, cons
   g.ist1 = idx[0], g.jst1 = idx[2];
   g.pn = pn, g.color = color;
   g.nhalf = (g.ni + 1) / 2 + 1;
-  if (ctx.tune.pcr_fast && try_pcr_rb2(x, msk, rhs, g, omg, res_dev, accumulate)) return;
+  if (ctx.tune.pcr_fast && try_pcr_rb2<0, 0>(x, nullptr, msk, rhs, g, omg, res_dev, accumulate)) return;
   // one wave per k-line, NW lines per workgroup; each line keeps 2 x (a, c, d) of n+2 entries in LDS.  Prefer four
   // lines per group while two groups still fit a CU's 160 KiB, then fall back to fewer lines per group for long lines.
   if (try_pcr_rb<4>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
@@ -2881,6 +2987,58 @@ void pcr_rb_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, CZ_REAL*
   *res += read_scalar(0);
 }
 
+namespace {
+double pcr_flop(const int* idx, int stages, double fin) {
+  const double nk = idx[5] - idx[4] + 1;
+  return (double)((idx[3] - idx[2] + 1) * (idx[1] - idx[0] + 1)) * (nk * 6.0 + nk * stages * 14.0 + fin + nk * 6.0 + 6.0);
+}
+}  // namespace
+
+void pcr_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1,
+          CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop) {
+  ensure_init();
+  (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1;
+  *flop += pcr_flop(idx, *pn - 2, (double)(1 << (*pn - 2)) * 74.0);  // cz_solver.f90:689-696
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_pcr_variant(x, nullptr, msk, rhs, bx, idx, *pn, 1, 0, 1, *omg, ctx.scal_dev + 0, 0);
+  *res += read_scalar(0);
+}
+
+void pcr_esa_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d,
+              CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop) {
+  ensure_init();
+  (void)s, (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1;
+  *flop += pcr_flop(idx, *pn - 2, (double)(1 << (*pn - 2)) * 78.0);  // :1078-1085
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_pcr_variant(x, nullptr, msk, rhs, bx, idx, *pn, 1, 0, 1, *omg, ctx.scal_dev + 0, 0);
+  *res += read_scalar(0);
+}
+
+void pcr_rb_esa_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a,
+                 CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop) {
+  ensure_init();
+  (void)ofst, (void)s, (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1;
+  *flop += pcr_flop(idx, *pn - 2, (double)(1 << (*pn - 2)) * 78.0) * 0.5;  // :1291-1299
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_pcr_variant(x, nullptr, msk, rhs, bx, idx, *pn, 0, *color, 1, *omg, ctx.scal_dev + 0, 0);
+  *res += read_scalar(0);
+}
+
+void pcr_j_esa_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d,
+                CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* src, CZ_REAL* wrk, CZ_REAL* omg, double* res, double* flop) {
+  ensure_init();
+  (void)s, (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1, (void)src;
+  *flop += pcr_flop(idx, *pn - 1, (double)(1 << (*pn - 1)) * 9.0);  // :1499-1506
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_pcr_variant(x, wrk, msk, rhs, bx, idx, *pn, 2, 0, 0, *omg, ctx.scal_dev + 0, 0);
+  czhip_internal::copy_inner_async(x, wrk, sz, idx, *g);  // :1655-1663
+  *res += read_scalar(0);
+}
+
 void imask_k_(CZ_REAL* x, int* sz, int* idx, int* g) {
   ensure_init();
   Box bx = make_box(sz, idx, *g);
@@ -2967,6 +3125,12 @@ int pcr_num_stage(int n) { return num_stage(n); }
 void pcr_rb_async(REAL* x, const REAL* msk, const REAL* rhs, const int* sz, const int* idx, int g, int pn, int color, REAL omg,
                   double* res_dev, int accumulate) {
   launch_pcr_rb(x, msk, rhs, make_box(sz, idx, g), idx, pn, color, omg, res_dev, accumulate);
+}
+// order 0: colour `sel` in place; 1: lexicographic in place (one launch per diagonal); 2: all columns x -> wout
+void pcr_variant_async(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const int* sz, const int* idx, int g, int pn, int order,
+                       int sel, int final4, REAL omg, double* res_dev, int accumulate) {
+  ensure_init();
+  launch_pcr_variant(x, wout, msk, rhs, make_box(sz, idx, g), idx, pn, order, sel, final4, omg, res_dev, accumulate);
 }
 void imask_async(REAL* x, const int* sz, const int* idx, int g) { launch_imask(x, make_box(sz, idx, g)); }
 // MAF flavour, device-resident coordinates (xc|yc|zc and pvt are device pointers)

@@ -104,6 +104,23 @@ void search_pivot_(CZ_REAL* pvt, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL*
 /* cz_Ffunc.h:60-77 <- cz_solver.f90:497-662 */
 void pcr_rb_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a,
              CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop);
+/* The other line-SOR variants: pn-2 PCR stages + 4x4 systems by Cramer's rule (pcr, pcr_esa, pcr_rb_esa) or pn-1 stages + 2x2
+ * systems (pcr_j_esa); columns in lexicographic order in place (pcr, pcr_esa: computed diagonal by diagonal, bit-identical to
+ * the sequential loop), one colour in place (pcr_rb_esa), or all from the old field through wrk (pcr_j_esa).  The work arrays
+ * (a..d1, src) are the reference's scratch and are ignored; entries beyond a line are zeros ("ESA" semantics, also where the
+ * reference indexes past its arrays, i.e. when n < 3/4 * 2^pn). */
+/* cz_Ffunc.h:99-114 <- cz_solver.f90:666-878 */
+void pcr_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1,
+          CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop);
+/* cz_Ffunc.h:130-146 <- cz_solver.f90:1050-1257 */
+void pcr_esa_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d,
+              CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop);
+/* cz_Ffunc.h:79-97 <- cz_solver.f90:1261-1469 */
+void pcr_rb_esa_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a,
+                 CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop);
+/* cz_Ffunc.h:148-166 <- cz_solver.f90:1473-1676 */
+void pcr_j_esa_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d,
+                CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* src, CZ_REAL* wrk, CZ_REAL* omg, double* res, double* flop);
 /* cz_Ffunc.h:440-443 <- cz_blas.f90:24-104 */
 void imask_k_(CZ_REAL* x, int* sz, int* idx, int* g);
 

@@ -30,6 +30,7 @@
  * the wide accumulation while the REAL one pins the oracle to the reference.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <stddef.h>
 
 #ifdef CZ_REAL_IS_DOUBLE
@@ -473,6 +474,147 @@ void oracle_psor2sma_core_maf(REAL* p, const int* sz, const int* idx, const int*
                               const REAL* z, const int* ofst, const int* color, const REAL* omg, const REAL* b, double* res,
                               REAL* tmp, double* flop) {
   oracle_psor2sma_core_maf_w(p, sz, idx, gp, x, y, z, ofst, color, omg, b, res, tmp, flop, NULL);
+}
+
+/* ---- the other line-SOR variants of cz_solver.f90.  They share one column solver and differ in
+ *   - the number of PCR stages and the direct solve that ends them: pn-1 stages + 2x2 systems, or pn-2 stages + 4x4 systems
+ *     by Cramer's rule;
+ *   - how entries beyond the line are reached: clamped to the entries kst-1 / ked+1 (pcr) or read from arrays extended
+ *     by s zero entries on both sides ("ESA").  Both read +0.0 there, so one restatement with wide zero pads serves both;
+ *   - the order of the columns: lexicographic in place (pcr, pcr_esa: a column sees the new values of its i-1 and j-1
+ *     neighbours), one checkerboard colour in place (pcr_rb_esa), or all columns from the old field (pcr_j_esa).
+ * The ESA variants index a, c, d beyond their declared extent unless n >= 3/4 * 2^pn (e.g. d(k+3*sq) at :1388); this
+ * restatement reads zeros there, which is what the reference reads when the memory behind its arrays is zero. */
+static void pcr_column(const REAL* xs, REAL* xd, const REAL* msk, const REAL* rhs, size_t c0, size_t rowlen, size_t plane, int n, int pn,
+                       int final4, REAL omg, REAL* W /* 6 arrays of n + 2P */, int P, REAL* res1, double* resw) {
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const int LD = n + 2 * P;
+  REAL *a = W + P, *c = a + LD, *d = c + LD, *a1 = d + LD, *c1 = a1 + LD, *d1 = c1 + LD; /* element k = 0..n-1 <-> kst+k */
+  for (int k = -P; k < n + P; k++) a[k] = c[k] = d[k] = a1[k] = c1[k] = d1[k] = (REAL)0.0;
+  for (int k = 1; k < n; k++) a[k] = -r;     /* :725-739, :1309-1329, :1101-1118 */
+  for (int k = 0; k < n - 1; k++) c[k] = -r;
+  for (int k = 0; k < n; k++) {              /* :741-757 */
+    const size_t e = c0 + (size_t)k;
+    d[k] = ((xs[e - plane] + xs[e + plane] + xs[e - rowlen] + xs[e + rowlen] - rhs[e]) * r) * msk[e];
+  }
+  d[0] = (d[0] + xs[c0 - 1] * r) * msk[c0];
+  d[n - 1] = (d[n - 1] + xs[c0 + (size_t)n] * r) * msk[c0 + (size_t)n - 1];
+  const int nstage = final4 ? pn - 2 : pn - 1;
+  for (int p = 1; p <= nstage; p++) {        /* :759-783 */
+    const int s = 1 << (p - 1);
+    for (int k = 0; k < n; k++) {
+      const REAL ap = a[k], cp = c[k];
+      const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * c[k - s] - cp * a[k + s]);
+      a1[k] = -e * ap * a[k - s];
+      c1[k] = -e * cp * c[k + s];
+      d1[k] = e * (d[k] - ap * d[k - s] - cp * d[k + s]);
+    }
+    for (int k = 0; k < n; k++) a[k] = a1[k], c[k] = c1[k], d[k] = d1[k];
+  }
+  if (final4) {                              /* :787-842 */
+    const int s = 1 << (pn - 2);
+    for (int k = 0; k < s; k++) {
+      const int kl = k + s, km = k + 2 * s, kr = k + 3 * s;
+      const REAL cc1 = c[k], cc2 = c[kl], cc3 = c[km], aa2 = a[kl], aa3 = a[km], aa4 = a[kr];
+      const REAL dd1 = d[k], dd2 = d[kl], dd3 = d[km], dd4 = d[kr];
+      const REAL inv_detA = (REAL)1.0 / ((REAL)1.0 - aa4 * cc3 - aa3 * cc2 - aa2 * cc1 * ((REAL)1.0 - cc3 * aa4));
+      const REAL detA1 = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+      const REAL detA2 = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+      const REAL detA3 = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+      const REAL detA4 = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+      d1[k] = detA1 * inv_detA;
+      d1[kl] = detA2 * inv_detA;
+      d1[km] = detA3 * inv_detA;
+      d1[kr] = detA4 * inv_detA;
+    }
+  } else {                                   /* :1602-1617 */
+    const int s = 1 << (pn - 1);
+    for (int k = 0; k < s; k++) {
+      const REAL cc1 = c[k], aa2 = a[k + s], f1 = d[k], f2 = d[k + s];
+      const REAL jj = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+      d1[k] = (f1 - cc1 * f2) * jj;
+      d1[k + s] = (f2 - aa2 * f1) * jj;
+    }
+  }
+  for (int k = 0; k < n; k++) {              /* :854-863 */
+    const size_t e = c0 + (size_t)k;
+    const REAL pp = xs[e];
+    const REAL dp = (d1[k] - pp) * omg * msk[e];
+    xd[e] = pp + dp;
+    const REAL d2 = dp * dp;
+    *res1 = *res1 + d2;
+    *resw += (double)d2;
+  }
+}
+
+/* order: 0 = lexicographic in place, 1 = one colour in place, 2 = all columns from the old field (result through wrk) */
+static void pcr_sweep(const int* sz, const int* idx, const int* gp, int pn, int order, int color, int final4, REAL* x, const REAL* msk,
+                      const REAL* rhs, REAL* wrk, REAL omg, double* res, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const int n = ked - kst + 1, P = 1 << (pn > 1 ? pn : 1);
+  REAL* W = (REAL*)malloc((size_t)6 * (n + 2 * P) * sizeof(REAL));
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++) {
+      if (order == 1 && (i + j) % 2 != color) continue;
+      pcr_column(x, order == 2 ? wrk : x, msk, rhs, IDX(kst, i, j), nk, nk * ni, n, pn, final4, omg, W, P, &res1, &resw);
+    }
+  if (order == 2)
+    for (int j = jst; j <= jed; j++)
+      for (int i = ist; i <= ied; i++)
+        for (int k = kst; k <= ked; k++) x[IDX(k, i, j)] = wrk[IDX(k, i, j)]; /* :1655-1663 */
+  free(W);
+  *res = *res + (double)res1;
+  if (res_wide) *res_wide += resw;
+}
+
+/* the same sweeps with the additional double-precision accumulation of sum dp^2 (what the GPU's residual is compared with) */
+void oracle_pcr_sweep_w(const int* sz, const int* idx, const int* gp, const int* pn, const int* order, const int* color, const int* final4,
+                        REAL* x, const REAL* msk, const REAL* rhs, REAL* wrk, const REAL* omg, double* res, double* res_wide) {
+  pcr_sweep(sz, idx, gp, *pn, *order, *color, *final4, x, msk, rhs, wrk, *omg, res, res_wide);
+}
+
+#define PCR_FLOP(stages, fin) \
+  ((double)((jed - jst + 1) * (ied - ist + 1)) * ((ked - kst + 1) * 6.0 + (ked - kst + 1) * (double)(stages)*14.0 + (fin) + (ked - kst + 1) * 6.0 + 6.0))
+
+/* pcr : cz_solver.f90:666-878 */
+void oracle_pcr(const int* sz, const int* idx, const int* gp, const int* pn, REAL* x, const REAL* msk, const REAL* rhs, REAL* a, REAL* c,
+                REAL* d, REAL* a1, REAL* c1, REAL* d1, const REAL* omg, double* res, double* flop) {
+  UNPACK_IDX;
+  (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1;
+  *flop += PCR_FLOP(*pn - 2, (double)(1 << (*pn - 2)) * 74.0); /* :689-696 */
+  pcr_sweep(sz, idx, gp, *pn, 0, 0, 1, x, msk, rhs, NULL, *omg, res, NULL);
+}
+
+/* pcr_esa : cz_solver.f90:1050-1257 */
+void oracle_pcr_esa(const int* sz, const int* idx, const int* gp, const int* pn, const int* s, REAL* x, const REAL* msk, const REAL* rhs,
+                    REAL* a, REAL* c, REAL* d, REAL* a1, REAL* c1, REAL* d1, const REAL* omg, double* res, double* flop) {
+  UNPACK_IDX;
+  (void)s, (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1;
+  *flop += PCR_FLOP(*pn - 2, (double)(1 << (*pn - 2)) * 78.0); /* :1078-1085 */
+  pcr_sweep(sz, idx, gp, *pn, 0, 0, 1, x, msk, rhs, NULL, *omg, res, NULL);
+}
+
+/* pcr_rb_esa : cz_solver.f90:1261-1469 */
+void oracle_pcr_rb_esa(const int* sz, const int* idx, const int* gp, const int* pn, const int* ofst, const int* color, const int* s, REAL* x,
+                       const REAL* msk, const REAL* rhs, REAL* a, REAL* c, REAL* d, REAL* a1, REAL* c1, REAL* d1, const REAL* omg,
+                       double* res, double* flop) {
+  UNPACK_IDX;
+  (void)ofst, (void)s, (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1;
+  *flop += PCR_FLOP(*pn - 2, (double)(1 << (*pn - 2)) * 78.0) * 0.5; /* :1291-1299 */
+  pcr_sweep(sz, idx, gp, *pn, 1, *color, 1, x, msk, rhs, NULL, *omg, res, NULL);
+}
+
+/* pcr_j_esa : cz_solver.f90:1473-1676 (src is the reference's scratch for the source term) */
+void oracle_pcr_j_esa(const int* sz, const int* idx, const int* gp, const int* pn, const int* s, REAL* x, const REAL* msk, const REAL* rhs,
+                      REAL* a, REAL* c, REAL* d, REAL* a1, REAL* c1, REAL* d1, REAL* src, REAL* wrk, const REAL* omg, double* res,
+                      double* flop) {
+  UNPACK_IDX;
+  (void)s, (void)a, (void)c, (void)d, (void)a1, (void)c1, (void)d1, (void)src;
+  *flop += PCR_FLOP(*pn - 1, (double)(1 << (*pn - 1)) * 9.0); /* :1499-1506 */
+  pcr_sweep(sz, idx, gp, *pn, 2, 0, 0, x, msk, rhs, wrk, *omg, res, NULL);
 }
 
 /* ---- psor : cz_solver.f90:207-269.  Lexicographic in-place SOR (j outer, i, k inner): every update sees the new values of

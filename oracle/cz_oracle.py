@@ -263,6 +263,70 @@ class Kernels:
         self.last_flop = fl.value
         return r.value
 
+    def _pcr_work(self, sz, pn, nwide=3):
+        """work arrays of the line-SOR kernels: three of NK+4 entries (cz_Evaluate.cpp:257-262) and three ESA arrays, which
+        the reference declares with n + 2*2^(pn-2) entries (cz_Evaluate.cpp:304-311) but indexes further when n < 3/4 * 2^pn:
+        they are allocated with room (zeros) for those accesses."""
+        nk = int(sz[2]) + 4
+        small = [np.zeros(nk + (1 << pn) + 8, dtype=self.real) for _ in range(3)]
+        wide = [np.zeros(nk + 4 * (1 << pn) + 8, dtype=self.real) for _ in range(nwide)]
+        return small, wide
+
+    def pcr(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
+        """cz_solver.f90:666-878: lexicographic line SOR, pn-2 PCR stages + 4x4 systems"""
+        sz, idx, g, pnc = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn)
+        w1, w = self._pcr_work(sz, pn)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self._f("pcr")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), self._rp(x), self._rp(msk), self._rp(rhs),
+                       *[self._rp(v) for v in w], *[self._rp(v) for v in w1], self._rs(omg), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def pcr_esa(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
+        """cz_solver.f90:1050-1257"""
+        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int(1 << (pn - 2))
+        w1, w = self._pcr_work(sz, pn)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self._f("pcr_esa")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), C.byref(ss), self._rp(x), self._rp(msk), self._rp(rhs),
+                           *[self._rp(v) for v in w], *[self._rp(v) for v in w1], self._rs(omg), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def pcr_rb_esa(self, sz, idx, pn, ofst, color, x, msk, rhs, omg, res=0.0):
+        """cz_solver.f90:1261-1469"""
+        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int(1 << (pn - 2))
+        o, c = C.c_int(ofst), C.c_int(color)
+        w1, w = self._pcr_work(sz, pn)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self._f("pcr_rb_esa")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), C.byref(o), C.byref(c), C.byref(ss), self._rp(x),
+                              self._rp(msk), self._rp(rhs), *[self._rp(v) for v in w], *[self._rp(v) for v in w1], self._rs(omg),
+                              C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def pcr_j_esa(self, sz, idx, pn, x, msk, rhs, src, wrk, omg, res=0.0):
+        """cz_solver.f90:1473-1676"""
+        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int(1 << (pn - 2))
+        w1, w = self._pcr_work(sz, pn)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self._f("pcr_j_esa")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), C.byref(ss), self._rp(x), self._rp(msk), self._rp(rhs),
+                             *[self._rp(v) for v in w], *[self._rp(v) for v in w1], self._rp(src), self._rp(wrk), self._rs(omg),
+                             C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
+    def pcr_sweep_wide(self, name, sz, idx, pn, color, x, msk, rhs, wrk, omg, wide, res=0.0):
+        """one sweep of a line-SOR variant with sum dp^2 also accumulated in double (oracle only)"""
+        assert self.kind == "oracle"
+        order, final4 = {"pcr": (0, 1), "pcr_esa": (0, 1), "pcr_rb_esa": (1, 1), "pcr_j_esa": (2, 0)}[name]
+        sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
+        ints = [C.c_int(v) for v in (pn, order, color, final4)]
+        r = C.c_double(res)
+        self.lib.oracle_pcr_sweep_w(self._ip(sz), self._ip(idx), C.byref(g), *[C.byref(v) for v in ints], self._rp(x), self._rp(msk),
+                                    self._rp(rhs), self._rp(wrk) if wrk is not None else None, self._rs(omg), C.byref(r),
+                                    wide.ctypes.data_as(_c_dbl_p))
+        return r.value
+
     def fileout_t(self, sz, s, dh, org, fname):
         """cz_utility.f90:17-47 (reference build with -D_aurora_=1 only): writes the .sph file `fname` (<= 20 characters)."""
         assert self.kind == "ref_sph" and len(fname) <= 20
@@ -467,6 +531,42 @@ class CZ:
         return itr, res
 
     # cz_Poisson.cpp:273-322
+    # cz_Poisson.cpp:621-742 (pcr_rb_esa), :745-826 (pcr), :910-1005 (pcr_esa), :1008-1095 (pcr_j_esa)
+    def LSOR_PCR_VARIANT(self, X, B, itr_max, name, converge_check=True):
+        k, res, itr = self.k, 0.0, 1
+        pn = get_num_stage(self.idx[5] - self.idx[4] + 1)
+        if not hasattr(self, "MSK"):
+            self.MSK = k.alloc(self.size)
+            k.imask_k(self.MSK, self.size, self.idx)  # cz_Evaluate.cpp:389
+        while itr <= itr_max:
+            res = 0.0
+            if self.wide:
+                w = np.zeros(1)
+                for color in ((0, 1) if name == "pcr_rb_esa" else (0,)):
+                    k.pcr_sweep_wide(name, self.size, self.idx, pn, color, X, self.MSK, B, self.WRK, self.ac1, w)
+                res = float(w[0])
+            elif name == "pcr":
+                res = k.pcr(self.size, self.idx, pn, X, self.MSK, B, self.ac1)
+            elif name == "pcr_esa":
+                res = k.pcr_esa(self.size, self.idx, pn, X, self.MSK, B, self.ac1)
+            elif name == "pcr_rb_esa":
+                for color in (0, 1):
+                    res = k.pcr_rb_esa(self.size, self.idx, pn, 0, color, X, self.MSK, B, self.ac1, res=res)
+            elif name == "pcr_j_esa":
+                if not hasattr(self, "SRC"):
+                    self.SRC = k.alloc(self.size)
+                res = k.pcr_j_esa(self.size, self.idx, pn, X, self.MSK, B, self.SRC, self.WRK, self.ac1)
+            else:
+                raise ValueError(name)
+            if converge_check:
+                res = math.sqrt(res * self.res_normal)
+                self.history.append((itr, res))
+                k.bc_k(self.size, X, self.pitch, self.origin, self.nID)
+                if res < self.eps:
+                    break
+            itr += 1
+        return itr, res
+
     def Preconditioner(self, xx, bb, pc):
         if pc in ("jacobi", "jacobi_maf"):
             self.JACOBI(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
@@ -476,6 +576,9 @@ class CZ:
             self.PSOR(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
         elif pc == "pcr_rb":
             self.LSOR_PCR_RB(xx, bb, LC_MAX, converge_check=False)
+        elif pc in ("pcr", "pcr_rb_esa"):  # cz_Poisson.cpp:300-316, cz_Evaluate.cpp:585-592
+            self.LSOR_PCR_VARIANT(xx, bb, LC_MAX, pc, converge_check=False)
+        # "pcr_j_esa" is accepted by cz_Evaluate.cpp:588-590 but CZ::Preconditioner has no case for it: it copies
         else:
             self.k.blas_copy(xx, bb, self.size)
 
@@ -568,6 +671,8 @@ def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", wit
         itr, res = cz.PSOR(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
     elif solver == "pcr_rb":
         itr, res = cz.LSOR_PCR_RB(cz.P, cz.RHS, itr_max)
+    elif solver in ("pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa"):
+        itr, res = cz.LSOR_PCR_VARIANT(cz.P, cz.RHS, itr_max, solver)
     elif solver in ("pbicgstab", "pbicgstab_maf"):
         itr, res = cz.PBiCGSTAB(cz.P, cz.RHS, itr_max, precond or "none", maf=solver.endswith("_maf"))
     else:

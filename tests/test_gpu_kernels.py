@@ -516,3 +516,42 @@ def test_psor_random_boxes_vs_oracle(prec, box):
         r = h.psor_maf(dp, sz, idx, xc, yc, zc, 1.2, db)
         assert _beq(dp.get(), p1), idx
         assert _rel(r, float(w[0])) < 1e-12
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", [(9, 8, 32), (20, 13, 64), (7, 11, 128), (12, 9, 40), (10, 6, 256), (5, 4, 512)],
+                         ids=lambda b: "x".join(map(str, b)))
+def test_pcr_variants_random_boxes_vs_oracle(prec, box):
+    """pcr / pcr_esa (lexicographic, diagonal by diagonal), pcr_rb_esa (4x4 final stage), pcr_j_esa (all columns from the old
+    field) == the oracle (itself pinned against the serial reference build), bit for bit.  (12,9,40): n = 38 < 3/4 * 64, where the
+    reference's ESA arrays are too short and zeros are read instead."""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    for name in ("pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa"):
+        x1, dx = x0.copy(), h.alloc(sz, x0)
+        for it in range(2):
+            if name == "pcr":
+                r1, r2 = ko.pcr(sz, idx, pn, x1, msk, rhs, 1.3), h.pcr(sz, idx, pn, dx, dm, dr, 1.3)
+            elif name == "pcr_esa":
+                r1, r2 = ko.pcr_esa(sz, idx, pn, x1, msk, rhs, 1.3), h.pcr_esa(sz, idx, pn, dx, dm, dr, 1.3)
+            elif name == "pcr_rb_esa":
+                r1 = r2 = 0.0
+                for color in (0, 1):
+                    r1 = ko.pcr_rb_esa(sz, idx, pn, 0, color, x1, msk, rhs, 1.3, res=r1)
+                    r2 = h.pcr_rb_esa(sz, idx, pn, 0, color, dx, dm, dr, 1.3, res=r2)
+            else:
+                src, wrk = np.zeros(shape, dtype=R), np.zeros(shape, dtype=R)
+                r1 = ko.pcr_j_esa(sz, idx, pn, x1, msk, rhs, src, wrk, 1.3)
+                r2 = h.pcr_j_esa(sz, idx, pn, dx, dm, dr, h.alloc(sz), h.alloc(sz), 1.3)
+            assert _beq(dx.get(), x1), (name, it)
+            assert _rel(r2, r1) < (2e-3 if prec == "f32" else 1e-11), (name, r1, r2)  # the oracle sums dp^2 in REAL here
+            assert h.last_flop == ko.last_flop, name
