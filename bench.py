@@ -29,7 +29,7 @@ ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--n", type=int, default=512, help="cells per GPU and axis")
-ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor"])
+ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor", "pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa"])
 ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "sor2sma"])
 ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
 ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +57,7 @@ if world not in DIVS:
 div = DIVS[world]
 n = args.n
 gsz = [n * div[0], n * div[1], n * div[2]]
-coef = 1.2 if args.solver in ("pcr_rb", "psor") else 1.5 if (args.solver == "sor2sma" or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
+coef = 0.9 if args.solver == "pcr_j_esa" else 1.2 if args.solver in ("pcr_rb", "psor", "pcr", "pcr_esa", "pcr_rb_esa") else 1.5 if (args.solver == "sor2sma" or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
 
 if torch.cuda.is_available():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -114,7 +114,8 @@ else:
     barrier()
     dt = time.perf_counter() - t0
 _jl = args.solver == "jacobi" or (args.solver == "pbicgstab" and args.precond == "jacobi")
-nk, kern_ms = cz.timing_read("jacobi" if _jl else args.solver if args.solver in ("pcr_rb", "psor") else "rbsor")
+_line = args.solver.startswith("pcr")
+nk, kern_ms = cz.timing_read("jacobi" if _jl else "pcr_rb" if _line else "psor" if args.solver == "psor" else "rbsor")
 nk2, kern2_ms = cz.timing_read("jacobi2" if _jl else "rbsor2")  # fused: 2 sweeps / both colours per launch
 cz.timing(False)
 
@@ -135,11 +136,12 @@ if rank == 0:
     alg_bytes_per_launch = my_points * word * (3 if jac_like else 2)
     kernel_name = "stencil_k<jacobi>" if jac_like else "stencil_k<rbsor colour>"
     tkey = f"{'jacobi' if jac_like else 'sor2sma'}_{n}_{args.prec}"
-    if args.solver == "pcr_rb":
-        # one colour launch: own lines read x, rhs, msk and write x (4 words), the other colour's lines are read once as
-        # i/j neighbours (1 word): 5 words x half the points
-        alg_bytes_per_launch = my_points * word * 5 // 2
-        kernel_name, tkey = "pcr_rb_k (one colour of k-line solves per launch)", f"pcr_rb_{n}_{args.prec}"
+    if _line:
+        # one iteration: every line reads x, rhs, msk and writes x (4 words), and is read once more as i/j neighbour (1 word);
+        # pcr_rb / pcr_rb_esa: two colour launches per iteration, pcr / pcr_esa: one launch per (i+j) diagonal, pcr_j_esa: one
+        per_iter = {"pcr_rb": 2, "pcr_rb_esa": 2, "pcr_j_esa": 1}.get(args.solver, nk // max(args.steps, 1))
+        alg_bytes_per_launch = my_points * word * 5 // max(per_iter, 1)
+        kernel_name, tkey = f"pcr_rb2_k ({per_iter} launches of k-line solves per iteration)", f"{args.solver}_{n}_{args.prec}"
     if args.solver == "psor":
         # one sweep (all tile-hyperplane launches together): p read and written in place, b read: 3 words per point
         alg_bytes_per_launch = my_points * word * 3
@@ -190,7 +192,7 @@ if rank == 0:
         out["config"]["step"] = "one BiCGSTAB iteration: 2 x 8 preconditioner sweeps, 2 SpMV, 5 dots, 4 axpy-type updates (cz_Poisson.cpp:373-500)"
         # 76 words per point and iteration with the Jacobi preconditioner
         out["roofline"]["iteration_algorithmic_GBps"] = my_points * word * (76 if args.precond == "jacobi" else 92) * args.steps / dt / 1e9
-    if world == 1 and not args.no_cpu_baseline and not bicg and args.solver not in ("pcr_rb", "psor"):
+    if world == 1 and not args.no_cpu_baseline and not bicg and args.solver in ("jacobi", "sor2sma"):
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--n", str(n), "--solver", args.solver,
                                 "--prec", args.prec, "--seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)
