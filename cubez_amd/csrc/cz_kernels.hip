@@ -1134,15 +1134,28 @@ psor_tile_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorGeom g
   const int t = threadIdx.x;
   const int K0 = g.kk0 + tk * T, I0 = g.ii0 + ti * T, J0 = g.jj0 + tj * T;  // first cell of the tile
   const size_t si = (size_t)g.nkp, sj = (size_t)g.nkp * g.nip;
-  for (int e = t; e < L2 * L1; e += T * T) {
-    const int k = e % L1, r = e / L1, i = r % L1, j = r / L1;
-    const int gk = K0 - 1 + k, gi = I0 - 1 + i, gj = J0 - 1 + j;
-    lp[e] = (gk < g.nkp && gi < g.nip && gj < g.njp) ? P[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
-  }
-  for (int e = t; e < T * T * T; e += T * T) {
-    const int k = e % T, r = e / T, i = r % T, j = r / T;
-    const int gk = K0 + k, gi = I0 + i, gj = J0 + j;
-    lb[e] = (gk <= g.kk1 && gi <= g.ii1 && gj <= g.jj1) ? B[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
+  {  // every global read of the tile is issued before the first use (one memory latency per tile)
+    constexpr int NP = (L2 * L1 + T * T - 1) / (T * T), NB = T;
+    REAL rp[NP], rb[NB];
+#pragma unroll
+    for (int m = 0; m < NP; m++) {
+      const int e = t + m * T * T;
+      const int k = e % L1, r = e / L1, i = r % L1, j = r / L1;
+      const int gk = K0 - 1 + k, gi = I0 - 1 + i, gj = J0 - 1 + j;
+      rp[m] = (e < L2 * L1 && gk < g.nkp && gi < g.nip && gj < g.njp) ? P[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
+    }
+#pragma unroll
+    for (int m = 0; m < NB; m++) {
+      const int e = t + m * T * T;
+      const int k = e % T, r = e / T, i = r % T, j = r / T;
+      const int gk = K0 + k, gi = I0 + i, gj = J0 + j;
+      rb[m] = (gk <= g.kk1 && gi <= g.ii1 && gj <= g.jj1) ? B[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
+    }
+#pragma unroll
+    for (int m = 0; m < NP; m++)
+      if (t + m * T * T < L2 * L1) lp[t + m * T * T] = rp[m];
+#pragma unroll
+    for (int m = 0; m < NB; m++) lb[t + m * T * T] = rb[m];
   }
   const int i = t % T, j = t / T;
   const int gi = I0 + i, gj = J0 + j;
