@@ -1467,6 +1467,275 @@ pcr_rb2_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Line SOR, register form.  A wave owns a k-line (L lines at a time); lane `lane` holds the M consecutive entries
+// k = lane*M .. lane*M + M-1 of the right-hand side d in registers.  A reduction stage needs d(k-s) and d(k+s): for s < M
+// they are in the lane's own registers except at the edges of its block (one value from lane-1 / lane+1), for s >= M they are
+// entry m of lane -/+ s/M -- a cross-lane shuffle, no LDS memory and no barrier at all.  LDS holds only the
+// line-independent coefficient table (pcr_coef_k's values, re-ordered [m][lane] so that reads are conflict-free), loaded
+// once per persistent workgroup.  Same operations on the same operand values as pcr_rb2_k => same bits.
+// ------------------------------------------------------------------------------------------------------------
+// table: stage p = 1..nstage: [e | ap | cp] x NE, then the final stage [7 x NE if FINAL4 else 3 x NE], NE = 64*M, entry of
+// element k = lane*M + m at m*64 + lane; entries of k >= n are zero
+__global__ void __launch_bounds__(256)
+pcr_coef_perm_k(const REAL* __restrict__ nat, REAL* __restrict__ tab, int n, int pn, int nfin, int final4, int M) {
+  const int NE = 64 * M;
+  const int nstage = final4 ? pn - 2 : pn - 1;
+  const int s = 1 << nstage;  // stride of the final stage
+  for (int k = threadIdx.x; k < NE; k += 256) {
+    const int x = (k % M) * 64 + k / M;
+    for (int p = 0; p < nstage; p++)
+      for (int v = 0; v < 3; v++) tab[(size_t)(p * 3 + v) * NE + x] = (k < n) ? nat[(size_t)p * 3 * n + (size_t)v * n + k] : (REAL)0;
+    const REAL* F = nat + (size_t)nstage * 3 * n;
+    REAL* G = tab + (size_t)nstage * 3 * NE;
+    const int kb = k % s;  // base element of the 2x2 / 4x4 system this element belongs to
+    const int nf = final4 ? 7 : 3;
+    for (int v = 0; v < nf; v++) G[(size_t)v * NE + x] = (k < n && kb < nfin) ? F[(size_t)v * nfin + kb] : (REAL)0;
+  }
+}
+
+// M consecutive elements from / to an address that is only element-aligned (a k-line starts at padded index g): the hardware
+// takes multi-dword global accesses at dword alignment
+#ifdef CZ_REAL_IS_DOUBLE
+typedef double RunVec __attribute__((ext_vector_type(2), aligned(8)));
+constexpr int kRunW = 2;
+#else
+typedef float RunVec __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int kRunW = 4;
+#endif
+template <int M>
+__device__ __forceinline__ void load_run(const REAL* __restrict__ p, REAL (&o)[M]) {
+  if (M % kRunW == 0) {
+#pragma unroll
+    for (int c = 0; c < M; c += kRunW) {
+      const RunVec v = *reinterpret_cast<const RunVec*>(p + c);
+#pragma unroll
+      for (int w = 0; w < kRunW; w++) o[c + w] = v[w];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < M; c++) o[c] = p[c];
+  }
+}
+template <int M>
+__device__ __forceinline__ void store_run(REAL* __restrict__ p, const REAL (&o)[M], int nvalid) {
+  if (M % kRunW == 0 && nvalid >= M) {
+#pragma unroll
+    for (int c = 0; c < M; c += kRunW) {
+      RunVec v;
+#pragma unroll
+      for (int w = 0; w < kRunW; w++) v[w] = o[c + w];
+      *reinterpret_cast<RunVec*>(p + c) = v;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < M; c++)
+      if (c < nvalid) p[c] = o[c];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T lane_up(T v, int q, int lane) {  // value of lane - q, zero below lane 0
+  const T r = __shfl_up(v, (unsigned)q, 64);
+  return (q < 64 && lane >= q) ? r : (T)0;
+}
+template <typename T>
+__device__ __forceinline__ T lane_down(T v, int q, int lane) {  // value of lane + q, zero above lane 63
+  const T r = __shfl_down(v, (unsigned)q, 64);
+  return (q < 64 && lane + q < 64) ? r : (T)0;
+}
+
+template <int M, int NW, int L, int FINAL4, int ORDER>
+__global__ void __launch_bounds__(64 * NW)
+pcr_line_reg_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg,
+               const REAL* __restrict__ tab, int tab_len, double* partials, double* dst, int accumulate, unsigned* counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NE = 64 * M;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = g.n;
+  REAL* T = reinterpret_cast<REAL*>(smem);
+  double* wsum = reinterpret_cast<double*>(T + tab_len + 4);
+  wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
+  for (int i = threadIdx.x; i < tab_len; i += 64 * NW) T[i] = tab[i];
+  __syncthreads();
+
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const int dlo = (ORDER == 1) ? max(0, g.color - (g.nj - 1)) : 0;
+  const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj
+                         : (ORDER == 1) ? (long long)(min(g.ni - 1, g.color) - dlo + 1)
+                                        : (long long)g.ni * g.nj;
+  const long long ngroups = (ncol + L - 1) / L;
+  const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
+  const int k0 = lane * M;
+  double acc = 0.0;
+  for (long long q = (long long)blockIdx.x * NW + wave; q < ngroups; q += (long long)gridDim.x * NW) {
+    size_t c0[L];
+    bool act[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const long long col = q * L + l;
+      int ii = 0, jj = 0;
+      if (ORDER == 0) {
+        const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+        act[l] = jrow < g.nj;
+        if (act[l]) {
+          const int j1 = g.jst1 + jrow;
+          int i1 = g.ist1 + 2 * ih;
+          if (((i1 + j1) & 1) != g.color) i1 += 1;
+          act[l] = (i1 - g.ist1) < g.ni;
+          ii = g.ii0 + (i1 - g.ist1);
+          jj = g.jj0 + jrow;
+        }
+      } else if (ORDER == 1) {
+        act[l] = col < ncol;
+        const int io = dlo + (int)col;
+        ii = g.ii0 + io, jj = g.jj0 + (g.color - io);
+      } else {
+        act[l] = col < ncol;
+        ii = g.ii0 + (int)(col % g.ni), jj = g.jj0 + (int)(col / g.ni);
+      }
+      if (!act[l]) ii = g.ii0, jj = g.jj0;
+      c0[l] = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;
+    }
+    // ---- source term (:558-568)
+    // (a run may reach past the end of its line: those values are read from the rows behind it -- the array continues for at
+    // least one more plane -- and discarded)
+    REAL d[L][M];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      if (act[l] && k0 < n) {
+        const size_t e0 = c0[l] + k0;
+        REAL xjm[M], xjp[M], xim[M], xip[M], rh[M], mk[M];
+        load_run<M>(X + e0 - plane, xjm);
+        load_run<M>(X + e0 + plane, xjp);
+        load_run<M>(X + e0 - rowlen, xim);
+        load_run<M>(X + e0 + rowlen, xip);
+        load_run<M>(RHS + e0, rh);
+        load_run<M>(MSK + e0, mk);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const int k = k0 + m;
+          REAL dv = ((xjm[m] + xjp[m] + xim[m] + xip[m] - rh[m]) * r) * mk[m];
+          if (k == 0) dv = (dv + X[e0 - 1] * r) * mk[m];
+          if (k == n - 1) dv = (dv + X[e0 + m + 1] * r) * mk[m];
+          d[l][m] = (k < n) ? dv : (REAL)0;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < M; m++) d[l][m] = (REAL)0;
+      }
+    }
+    // ---- PCR stages (:572-595), right-hand side only; every index below is a compile-time constant
+#pragma unroll
+    for (int sidx = 0; sidx < 20; sidx++) {
+      if ((1 << sidx) >= NE) break;  // compile time
+      if (sidx < nstage) {
+        const int s = 1 << sidx;
+        const REAL* Tp = T + (size_t)sidx * 3 * NE;
+        REAL nd[L][M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const REAL e = Tp[m * 64 + lane], ap = Tp[NE + m * 64 + lane], cp = Tp[2 * NE + m * 64 + lane];
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            REAL dl, dr;
+            if (s < M) {
+              dl = (m - s >= 0) ? d[l][(m - s >= 0) ? m - s : 0] : lane_up(d[l][(m - s + M) % M], 1, lane);
+              dr = (m + s < M) ? d[l][(m + s < M) ? m + s : 0] : lane_down(d[l][(m + s) % M], 1, lane);
+            } else {
+              dl = lane_up(d[l][m], s / M, lane);
+              dr = lane_down(d[l][m], s / M, lane);
+            }
+            nd[l][m] = e * (d[l][m] - ap * dl - cp * dr);
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < L; l++)
+#pragma unroll
+          for (int m = 0; m < M; m++) d[l][m] = (k0 + m < n) ? nd[l][m] : (REAL)0;
+      }
+    }
+    // ---- final stage: every entry solves for itself
+    {
+      const int s = 1 << nstage;
+      const int qf = s / M;  // s >= M always (s >= n/4 > 8M .. see launch_pcr_reg)
+      const REAL* F = T + (size_t)nstage * 3 * NE;
+      REAL sol[L][M];
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        const int k = k0 + m;
+        const int rr = k >> nstage;  // position of this entry in its 2x2 / 4x4 system (s = 2^nstage)
+        const int x = m * 64 + lane;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const REAL me = d[l][m];
+          if (!FINAL4) {  // (:599-616)
+            const REAL jj2 = F[x], cc1 = F[NE + x], aa2 = F[2 * NE + x];
+            const REAL up = lane_up(me, qf, lane), dn = lane_down(me, qf, lane);
+            const REAL f1 = rr == 0 ? me : up, f2 = rr == 0 ? dn : me;
+            sol[l][m] = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;
+          } else {  // Cramer's rule (:787-842)
+            const REAL inv_detA = F[x], cc1 = F[NE + x], cc2 = F[2 * NE + x], cc3 = F[3 * NE + x];
+            const REAL aa2 = F[4 * NE + x], aa3 = F[5 * NE + x], aa4 = F[6 * NE + x];
+            const REAL u1 = lane_up(me, qf, lane), u2 = lane_up(me, 2 * qf, lane), u3 = lane_up(me, 3 * qf, lane);
+            const REAL w1 = lane_down(me, qf, lane), w2 = lane_down(me, 2 * qf, lane), w3 = lane_down(me, 3 * qf, lane);
+            const REAL dd1 = rr == 0 ? me : rr == 1 ? u1 : rr == 2 ? u2 : u3;
+            const REAL dd2 = rr == 0 ? w1 : rr == 1 ? me : rr == 2 ? u1 : u2;
+            const REAL dd3 = rr == 0 ? w2 : rr == 1 ? w1 : rr == 2 ? me : u1;
+            const REAL dd4 = rr == 0 ? w3 : rr == 1 ? w2 : rr == 2 ? w1 : me;
+            REAL det;
+            if (rr == 0) det = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+            else if (rr == 1) det = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+            else if (rr == 2) det = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+            else det = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+            sol[l][m] = det * inv_detA;
+          }
+        }
+      }
+      // ---- relaxation (:626-633)
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        if (!act[l] || k0 >= n) continue;
+        const size_t e0 = c0[l] + k0;
+        REAL pp[M], mk[M], out[M];
+        load_run<M>(X + e0, pp);
+        load_run<M>(MSK + e0, mk);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const REAL dp = (sol[l][m] - pp[m]) * omg * mk[m];
+          out[m] = pp[m] + dp;
+          const REAL d2 = dp * dp;
+          if (k0 + m < n) acc += (double)d2;
+        }
+        store_run<M>((ORDER == 2 ? WOUT : X) + e0, out, n - k0);
+      }
+    }
+  }
+  // ---- residual: partial per workgroup, fixed-order sum by the last one (write-through hand-off as in stencil_k)
+  __syncthreads();
+  const double sblk = block_sum<64 * NW>(acc, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64 * NW) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<64 * NW>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
 // imask_k (cz_blas.f90:24-104): 1 on the inner box, 0 elsewhere (whole padded array)
 __global__ void __launch_bounds__(256)
 imask_k(REAL* X, int nkp, int nip, int njp, int kk0, int kk1, int ii0, int ii1, int jj0, int jj1) {
@@ -1775,7 +2044,8 @@ copy_shell_k(REAL* __restrict__ dst, const REAL* __restrict__ src, int nkp, int 
 struct Tuning {
   int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
   int fuse_fin = 1;
-  int pcr_fast = 1, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k); variant = NW*10+L
+  int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
+                                      // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
   #ifdef CZ_REAL_IS_DOUBLE
   int t2_threads = 1024, t2_mv = 2, t2_tj = 64;  // best of tools/tune_jacobi2.py at 512^3 FP64 (profiles/r01)
 #else
@@ -1789,6 +2059,9 @@ struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   double* partials = nullptr;   // device
+  REAL* pcr_tab_perm = nullptr; // the same table in the [m][lane] order of pcr_line_reg_k, for pcr_perm_M entries per lane
+  int pcr_perm_M = 0;
+  size_t pcr_perm_cap = 0;
   REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
   int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
   size_t pcr_tab_cap = 0;
@@ -2334,30 +2607,110 @@ bool try_pcr_rb2_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, con
   return true;
 }
 
+// the line-independent coefficients of a line of n unknowns (pcr_coef_k), computed once per (n, pn, variant)
+void ensure_pcr_table(int n, int pn, int final4, int nfin, int tab_len) {
+  if (ctx.pcr_tab_n == n && ctx.pcr_tab_pn == pn && ctx.pcr_tab_final4 == final4) return;
+  if ((size_t)tab_len > ctx.pcr_tab_cap) {
+    if (ctx.pcr_tab) {
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      HIP_CHECK(hipFree(ctx.pcr_tab));
+    }
+    HIP_CHECK(hipMalloc(&ctx.pcr_tab, (size_t)tab_len * sizeof(REAL)));
+    ctx.pcr_tab_cap = tab_len;
+  }
+  hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), (size_t)4 * (n + 2) * sizeof(REAL), ctx.stream, ctx.pcr_tab, n, pn, nfin, final4);
+  HIP_CHECK(hipGetLastError());
+  ctx.pcr_tab_n = n, ctx.pcr_tab_pn = pn, ctx.pcr_tab_final4 = final4;
+  ctx.pcr_perm_M = 0;  // the permuted copy is stale
+}
+
+template <int M, int NW, int L, int FINAL4, int ORDER>
+bool try_pcr_reg_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
+                      int tab_len, long long ncol) {
+  const size_t lds = ((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double);
+  if (lds > 160 * 1024) return false;
+  const long long ngroups = (ncol + L - 1) / L;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(32 / NW)));
+  const unsigned nblk = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + NW - 1) / NW, (long long)ctx.num_cu * per_cu));
+  ensure_partials(nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_line_reg_k<M, NW, L, FINAL4, ORDER>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  ScopedTimer tm(LBL_PCR);
+  hipLaunchKernelGGL((pcr_line_reg_k<M, NW, L, FINAL4, ORDER>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, wout, msk, rhs, g, omg,
+                     ctx.pcr_tab_perm, tab_len, ctx.partials, res_dev, accumulate, ctx.counter);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// register form (pcr_line_reg_k): lines of up to 1024 unknowns whose permuted table fits LDS
+template <int FINAL4, int ORDER>
+bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
+                 long long ncol) {
+  const int n = g.n, pn = g.pn;
+  if (pn < (FINAL4 ? 3 : 2) || n > 1024) return false;
+  const int nstage = FINAL4 ? pn - 2 : pn - 1;
+  int M = 2;
+  while (64 * M < n) M *= 2;
+  if ((1 << nstage) < M) return false;  // the final stage must pair entries of different lanes
+  const int NE = 64 * M;
+  const int tab_len = (nstage * 3 + (FINAL4 ? 7 : 3)) * NE;
+  if (((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double) > 160 * 1024) return false;
+  const int nfin = std::min(1 << nstage, n);
+  ensure_pcr_table(n, pn, FINAL4, nfin, nstage * 3 * n + (FINAL4 ? 7 : 3) * nfin);
+  if (ctx.pcr_perm_M != M) {
+    if ((size_t)tab_len > ctx.pcr_perm_cap) {
+      if (ctx.pcr_tab_perm) {
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        HIP_CHECK(hipFree(ctx.pcr_tab_perm));
+      }
+      HIP_CHECK(hipMalloc(&ctx.pcr_tab_perm, (size_t)tab_len * sizeof(REAL)));
+      ctx.pcr_perm_cap = tab_len;
+    }
+    hipLaunchKernelGGL(pcr_coef_perm_k, dim3(1), dim3(256), 0, ctx.stream, ctx.pcr_tab, ctx.pcr_tab_perm, n, pn, nfin, FINAL4, M);
+    HIP_CHECK(hipGetLastError());
+    ctx.pcr_perm_M = M;
+  }
+  const int v = ctx.tune.pcr_variant;
+#define CZ_PCR_REG(M_)                                                                                                                \
+  if (M == M_) {                                                                                                                      \
+    if (ORDER == 1) return try_pcr_reg_inst<M_, 4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
+    if (v == 161) return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
+    if (v == 81) return try_pcr_reg_inst<M_, 8, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);     \
+    if (v == 82) return try_pcr_reg_inst<M_, 8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);     \
+    if (v == 162) return try_pcr_reg_inst<M_, 16, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
+    /* measured at 512^3 (profiles/r01/pcr_variants.txt): FP32 8 waves x 2 lines, FP64 16 waves x 1 line */                         \
+    if (sizeof(REAL) == 4 && M_ <= 8)                                                                                                 \
+      return try_pcr_reg_inst<M_, 8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                \
+    return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                 \
+  }
+  CZ_PCR_REG(2) CZ_PCR_REG(4) CZ_PCR_REG(8) CZ_PCR_REG(16)
+#undef CZ_PCR_REG
+  return false;
+}
+
 // fast form: coefficient table (computed once per line length and variant) + persistent right-hand-side-only kernel
 template <int FINAL4, int ORDER>
 bool try_pcr_rb2(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate) {
   const int n = g.n, pn = g.pn;
   if (pn < (FINAL4 ? 3 : 2) || pn > 20) return false;
+  {
+    long long nc;
+    if (ORDER == 0) nc = (long long)g.nhalf * g.nj;
+    else if (ORDER == 1) nc = std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1;
+    else nc = (long long)g.ni * g.nj;
+    if (ctx.tune.pcr_fast >= 2 && try_pcr_reg<FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, nc)) return true;
+  }
   const int nstage = FINAL4 ? pn - 2 : pn - 1;
   const int nfin = std::min(1 << nstage, n);
   const int tab_len = nstage * 3 * n + (FINAL4 ? 7 : 3) * nfin;
   const size_t fixed = ((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double);
   const size_t per_line = (size_t)2 * (n + 2) * sizeof(REAL);
   if (fixed + 4 * per_line > 160 * 1024) return false;  // table + four lines must fit
-  if (ctx.pcr_tab_n != n || ctx.pcr_tab_pn != pn || ctx.pcr_tab_final4 != FINAL4) {
-    if ((size_t)tab_len > ctx.pcr_tab_cap) {
-      if (ctx.pcr_tab) {
-        HIP_CHECK(hipStreamSynchronize(ctx.stream));
-        HIP_CHECK(hipFree(ctx.pcr_tab));
-      }
-      HIP_CHECK(hipMalloc(&ctx.pcr_tab, (size_t)tab_len * sizeof(REAL)));
-      ctx.pcr_tab_cap = tab_len;
-    }
-    hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), (size_t)4 * (n + 2) * sizeof(REAL), ctx.stream, ctx.pcr_tab, n, pn, nfin, FINAL4);
-    HIP_CHECK(hipGetLastError());
-    ctx.pcr_tab_n = n, ctx.pcr_tab_pn = pn, ctx.pcr_tab_final4 = FINAL4;
-  }
+  ensure_pcr_table(n, pn, FINAL4, nfin, tab_len);
   long long ncol;
   if (ORDER == 0) ncol = (long long)g.nhalf * g.nj;
   else if (ORDER == 1) ncol = std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1;
@@ -2539,6 +2892,7 @@ void czhip_finalize(void) {
   (void)hipFree(ctx.partials);
   (void)hipFree(ctx.shell_partials);
   if (ctx.pcr_tab) (void)hipFree(ctx.pcr_tab);
+  if (ctx.pcr_tab_perm) (void)hipFree(ctx.pcr_tab_perm);
   (void)hipFree(ctx.scal_dev);
   (void)hipHostFree(ctx.scal_host);
   (void)hipStreamDestroy(ctx.stream);
