@@ -3127,6 +3127,16 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
 
 int czhip_use_t2(void) { return ctx.tune.use_t2; }
 
+// line-SOR kernel choice: form 0 = pcr_rb_k (the reference's arithmetic literally, pcr_rb only), 1 = table + d in LDS, 2 = table +
+// d in registers (default); variant = waves per workgroup * 10 + lines per wave, 0 = measured default.  Negative: keep.
+int czhip_set_pcr_mode(int form, int variant) {
+  ensure_init();
+  if (form > 2) return 1;
+  if (form >= 0) ctx.tune.pcr_fast = form;
+  if (variant >= 0) ctx.tune.pcr_variant = variant;
+  return 0;
+}
+
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev) {
   ensure_init();

@@ -210,6 +210,10 @@ int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_R
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable); /* 0 / -1 keep; returns 0 if ok */
+/* line-SOR kernels (pcr*_): form 0 = one wave per line with the reference's arithmetic literally (pcr_rb_ only), 1 = coefficient
+ * table + right-hand side in LDS, 2 = table + right-hand side in registers (default); variant = waves*10 + lines per wave, 0 = default;
+ * negative = keep.  All forms give the same bits. */
+int czhip_set_pcr_mode(int form, int variant);
 int czhip_use_t2(void);
 
 /* Convergence bookkeeping on the device (cz_Poisson.cpp:67-77): res = sqrt(res_dev[0]*res_normal);

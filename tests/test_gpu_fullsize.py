@@ -119,3 +119,54 @@ def test_decomposed_512_equals_single_domain():
         ref = P1[g + hj - 1:g + hj - 1 + nj, g + hi - 1:g + hi - 1 + ni, g + hk - 1:g + hk - 1 + nk]
         h1.update(np.ascontiguousarray(own).tobytes()), h2.update(np.ascontiguousarray(ref).tobytes())
     assert h1.hexdigest() == h2.hexdigest()
+
+
+def test_psor_512_is_locally_consistent_with_the_sequential_order():
+    """One lexicographic SOR sweep at 512^3.  In the order (j, i, k) every update reads the NEW values of its k-1, i-1, j-1
+    neighbours and the OLD ones of k+1, i+1, j+1, so the result can be checked point by point (vectorised, exact) without
+    running the sequential loop: new(p) == old(p) + ((ss - b)/dd - old(p))*omg with ss built from exactly those values."""
+    from cubez_amd import CzHip
+    h = CzHip("f32")
+    R = np.float32
+    sz, idx = [N, N, N], [2, N - 1, 2, N - 1, 2, N - 1]
+    rng = np.random.default_rng(2024)
+    old = rng.uniform(-1, 1, (N + 4, N + 4, N + 4)).astype(R)
+    b = rng.uniform(-1, 1, (N + 4, N + 4, N + 4)).astype(R)
+    cf = np.array([1.1, 0.9, 1.05, 0.95, 1.2, 0.8, 6.3], dtype=R)
+    omg = R(1.2)
+    dp_, db_ = h.alloc(sz, old), h.alloc(sz, b)
+    res = h.psor(dp_, sz, idx, cf, omg, db_)
+    new = dp_.get()
+    c = (slice(3, N + 1),) * 3                      # inner box 2..N-1 (1-based) -> padded 3..N
+    def sh(a, dj, di, dk):
+        return a[3 + dj:N + 1 + dj, 3 + di:N + 1 + di, 3 + dk:N + 1 + dk]
+    ss = cf[0] * sh(old, 0, 1, 0) + cf[1] * sh(new, 0, -1, 0)
+    ss = ss + cf[2] * sh(old, 1, 0, 0)
+    ss = ss + cf[3] * sh(new, -1, 0, 0)
+    ss = ss + cf[4] * sh(old, 0, 0, 1)
+    ss = ss + cf[5] * sh(new, 0, 0, -1)
+    dp = ((ss - b[c]) / cf[6] - old[c]) * omg
+    assert (old[c] + dp).tobytes() == new[c].tobytes()
+    assert abs(res - float(np.sum(dp.astype(np.float64) ** 2))) <= 1e-10 * res
+    mask = np.ones_like(old, dtype=bool)
+    mask[c] = False
+    assert np.array_equal(new[mask], old[mask])       # nothing outside the inner box is written
+
+
+def test_line_sor_512_three_kernel_forms_agree():
+    """pcr_rb at 512^3: the literal per-line kernel, the table kernel with the right-hand side in LDS and the register kernel are
+    three implementations of the same arithmetic -- same field, bit for bit, after two iterations."""
+    from cubez_amd import CZ
+    outs = []
+    for form in (0, 1, 2):
+        cz = CZ("f32", quiet=True)
+        cz.lib.czhip_set_pcr_mode(form, 0)
+        try:
+            assert cz.setup([N, N, N, "pcr_rb", 2, 1.2]) == 1
+            cz.solve()
+            outs.append((hashlib.sha256(cz.field().tobytes()).hexdigest(), cz.history()))
+        finally:
+            cz.lib.czhip_set_pcr_mode(2, 0)
+            cz.close()
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    assert np.allclose(outs[0][1], outs[2][1], rtol=1e-12, atol=0) and np.allclose(outs[1][1], outs[2][1], rtol=1e-12, atol=0)
