@@ -1,0 +1,145 @@
+// cz_h_ctx.h -- part of cz_kernels.hip (ONE translation unit per precision; this file is included inside its anonymous
+// namespace and is not a stand-alone header): host side: tuning, per-thread context, timers, index boxes.
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+struct Tuning {
+  int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
+  int fuse_fin = 1;
+  int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
+                                      // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
+  #ifdef CZ_REAL_IS_DOUBLE
+  int t2_threads = 1024, t2_mv = 2, t2_tj = 64;  // best of tools/tune_jacobi2.py at 512^3 FP64 (profiles/r01)
+#else
+  int t2_threads = 512, t2_mv = 2, t2_tj = 16;   // best at 512^3 FP32
+#endif  // two-sweep kernel: threads, vectors/thread, planes/chunk
+  int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
+};
+
+struct Ctx {
+  bool ready = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  double* partials = nullptr;   // device
+  REAL* pcr_tab_perm = nullptr; // the same table in the [m][lane] order of pcr_line_reg_k, for pcr_perm_M entries per lane
+  int pcr_perm_M = 0;
+  size_t pcr_perm_cap = 0;
+  REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
+  int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
+  size_t pcr_tab_cap = 0;
+  double* shell_partials = nullptr;  // per-workgroup sums of the last pair_shell_k launch, folded in by the interior launch
+  int shell_pending = 0;
+  size_t partials_cap = 0;
+  unsigned* counter = nullptr;  // arrival ticket of the in-kernel finalisation
+  REAL* xyz = nullptr;           // device copies of the host coordinate arrays X, Y, Z handed to the *_maf_ drop-in symbols
+  size_t xyz_cap = 0;
+  double* scal_dev = nullptr;   // a few device doubles for the synchronous entry points
+  double* scal_host = nullptr;  // pinned
+  Tuning tune;
+  std::map<std::vector<double>, REAL*> bc_tabs;  // key: ix, jx, dh, org0, org1
+  int num_cu = 256;
+  // optional per-launch HIP-event timing of the labelled kernels (bench.py roofline leg)
+  bool timing = false;
+  struct Ev { hipEvent_t a, b; int label; };
+  std::vector<Ev> ev_used, ev_free;
+  double t_acc[16] = {0};       // per label: time [ms] and launches of events already folded (long runs)
+  long long t_cnt[16] = {0};
+};
+thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
+
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_SHELL, LBL_PSOR, LBL_COUNT };
+static_assert(LBL_COUNT <= 16, "Ctx::t_acc / t_cnt hold 16 labels");
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb", "pair_shell", "psor"};
+
+struct ScopedTimer {
+  bool on;
+  Ctx::Ev ev;
+  explicit ScopedTimer(int label) : on(ctx.timing) {
+    if (!on) return;
+    if (!ctx.ev_free.empty()) {
+      ev = ctx.ev_free.back();
+      ctx.ev_free.pop_back();
+    } else {
+      HIP_CHECK(hipEventCreate(&ev.a));
+      HIP_CHECK(hipEventCreate(&ev.b));
+    }
+    ev.label = label;
+    HIP_CHECK(hipEventRecord(ev.a, ctx.stream));
+  }
+  ~ScopedTimer() {
+    if (!on) return;
+    HIP_CHECK(hipEventRecord(ev.b, ctx.stream));
+    ctx.ev_used.push_back(ev);
+    if (ctx.ev_used.size() >= 4096) fold_events(2048);
+  }
+  // long runs: turn the oldest recorded pairs into per-label sums and recycle their events (they completed long ago)
+  static void fold_events(size_t n) {
+    for (size_t i = 0; i < n; i++) {
+      Ctx::Ev& e = ctx.ev_used[i];
+      HIP_CHECK(hipEventSynchronize(e.b));
+      float ms = 0.f;
+      HIP_CHECK(hipEventElapsedTime(&ms, e.a, e.b));
+      ctx.t_acc[e.label] += ms;
+      ctx.t_cnt[e.label]++;
+      ctx.ev_free.push_back(e);
+    }
+    ctx.ev_used.erase(ctx.ev_used.begin(), ctx.ev_used.begin() + n);
+  }
+};
+
+void ensure_init() {
+  if (!ctx.ready) czhip_init(-1);
+}
+
+void ensure_partials(size_t n) {
+  if (n <= ctx.partials_cap) return;
+  if (ctx.partials) {
+    HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    HIP_CHECK(hipFree(ctx.partials));
+  }
+  size_t cap = n < 65536 ? 65536 : n;
+  HIP_CHECK(hipMalloc(&ctx.partials, cap * sizeof(double)));
+  ctx.partials_cap = cap;
+}
+
+struct Box {
+  int ni, nj, nk, g, nkp, nip, njp;
+  int kk0, kk1, ii0, ii1, jj0, jj1;
+  bool empty;
+};
+
+Box make_box(const int* sz, const int* idx, int g) {
+  Box b;
+  b.ni = sz[0], b.nj = sz[1], b.nk = sz[2], b.g = g;
+  b.nkp = b.nk + 2 * g, b.nip = b.ni + 2 * g, b.njp = b.nj + 2 * g;
+  // 1-based inclusive (ist,ied,jst,jed,kst,ked) -> padded 0-based
+  b.ii0 = idx[0] + g - 1, b.ii1 = idx[1] + g - 1;
+  b.jj0 = idx[2] + g - 1, b.jj1 = idx[3] + g - 1;
+  b.kk0 = idx[4] + g - 1, b.kk1 = idx[5] + g - 1;
+  b.empty = b.ii1 < b.ii0 || b.jj1 < b.jj0 || b.kk1 < b.kk0;
+  // the 7-point stencil reads one layer around the box: it must exist inside the padded array
+  if (!b.empty && (g < 1 || b.ii0 < 1 || b.jj0 < 1 || b.kk0 < 1 || b.ii1 > b.nip - 2 || b.jj1 > b.njp - 2 || b.kk1 > b.nkp - 2)) {
+    fprintf(stderr, "czhip: index range (%d..%d, %d..%d, %d..%d) does not fit sz=(%d,%d,%d) g=%d\n", idx[0], idx[1], idx[2],
+            idx[3], idx[4], idx[5], sz[0], sz[1], sz[2], g);
+    exit(1);
+  }
+  return b;
+}
+
+inline bool vec_ok(const Box& b, std::initializer_list<const void*> ptrs) {
+  if (b.nkp % VW != 0) return false;
+  for (const void* p : ptrs)
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15u)) return false;
+  return true;
+}
+
+template <int V>
+EGeom make_egeom(const Box& b) {
+  EGeom e;
+  e.R = b.nkp / V;
+  e.PSV = (long long)e.R * b.nip;
+  e.kk0 = b.kk0, e.kk1 = b.kk1, e.jj0 = b.jj0;
+  e.F0 = (long long)b.ii0 * e.R;
+  e.Fend = (long long)(b.ii1 + 1) * e.R;
+  return e;
+}

@@ -1,0 +1,274 @@
+// cz_h_linesor.h -- part of cz_kernels.hip (ONE translation unit per precision; this file is included inside its anonymous
+// namespace and is not a stand-alone header): host side: launches of the line-SOR and psor kernels.
+int num_stage(int n) {  // cz.h:293-300
+  int b = 1;
+  for (int i = 1; i < 20; i++) {
+    b *= 2;
+    if (n < b) return i;
+  }
+  return -1;
+}
+
+template <int NW>
+bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, double* res_dev, int accumulate, size_t lds_cap) {
+  const long long ncol = (long long)g.nhalf * g.nj;
+  const unsigned nblk = (unsigned)((ncol + NW - 1) / NW);
+  const size_t lds = (size_t)NW * 6 * (g.n + 2) * sizeof(REAL) + 64 + 16 * sizeof(double);
+  if (lds > lds_cap) return false;
+  ensure_partials(nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  ScopedTimer tm(LBL_PCR);
+  hipLaunchKernelGGL((pcr_rb_k<NW>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.partials, res_dev, accumulate,
+                     ctx.counter);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+template <int NW, int L, int FINAL4, int ORDER>
+bool try_pcr_rb2_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
+                      int tab_len, int nfin, long long ncol) {
+  const size_t lds = ((size_t)tab_len + (size_t)NW * 2 * L * (g.n + 2) + 8) * sizeof(REAL) + 32 * sizeof(double);
+  if (lds > 160 * 1024) return false;
+  const long long ngroups = (ncol + L - 1) / L;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(32 / NW)));
+  const unsigned nblk = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + NW - 1) / NW, (long long)ctx.num_cu * per_cu));
+  ensure_partials(nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb2_k<NW, L, FINAL4, ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024));
+    attr_set = true;
+  }
+  ScopedTimer tm(LBL_PCR);
+  hipLaunchKernelGGL((pcr_rb2_k<NW, L, FINAL4, ORDER>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, wout, msk, rhs, g, omg, ctx.pcr_tab,
+                     tab_len, nfin, ctx.partials, res_dev, accumulate, ctx.counter);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// the line-independent coefficients of a line of n unknowns (pcr_coef_k), computed once per (n, pn, variant)
+void ensure_pcr_table(int n, int pn, int final4, int nfin, int tab_len) {
+  if (ctx.pcr_tab_n == n && ctx.pcr_tab_pn == pn && ctx.pcr_tab_final4 == final4) return;
+  if ((size_t)tab_len > ctx.pcr_tab_cap) {
+    if (ctx.pcr_tab) {
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      HIP_CHECK(hipFree(ctx.pcr_tab));
+    }
+    HIP_CHECK(hipMalloc(&ctx.pcr_tab, (size_t)tab_len * sizeof(REAL)));
+    ctx.pcr_tab_cap = tab_len;
+  }
+  hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), (size_t)4 * (n + 2) * sizeof(REAL), ctx.stream, ctx.pcr_tab, n, pn, nfin, final4);
+  HIP_CHECK(hipGetLastError());
+  ctx.pcr_tab_n = n, ctx.pcr_tab_pn = pn, ctx.pcr_tab_final4 = final4;
+  ctx.pcr_perm_M = 0;  // the permuted copy is stale
+}
+
+template <int M, int NW, int L, int FINAL4, int ORDER>
+bool try_pcr_reg_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
+                      int tab_len, long long ncol) {
+  const size_t lds = ((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double);
+  if (lds > 160 * 1024) return false;
+  const long long ngroups = (ncol + L - 1) / L;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(32 / NW)));
+  const unsigned nblk = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + NW - 1) / NW, (long long)ctx.num_cu * per_cu));
+  ensure_partials(nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_line_reg_k<M, NW, L, FINAL4, ORDER>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  ScopedTimer tm(LBL_PCR);
+  hipLaunchKernelGGL((pcr_line_reg_k<M, NW, L, FINAL4, ORDER>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, wout, msk, rhs, g, omg,
+                     ctx.pcr_tab_perm, tab_len, ctx.partials, res_dev, accumulate, ctx.counter);
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// register form (pcr_line_reg_k): lines of up to 1024 unknowns whose permuted table fits LDS
+template <int FINAL4, int ORDER>
+bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
+                 long long ncol) {
+  const int n = g.n, pn = g.pn;
+  if (pn < (FINAL4 ? 3 : 2) || n > 1024) return false;
+  const int nstage = FINAL4 ? pn - 2 : pn - 1;
+  int M = 2;
+  while (64 * M < n) M *= 2;
+  if ((1 << nstage) < M) return false;  // the final stage must pair entries of different lanes
+  const int NE = 64 * M;
+  const int tab_len = (nstage * 3 + (FINAL4 ? 7 : 3)) * NE;
+  if (((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double) > 160 * 1024) return false;
+  const int nfin = std::min(1 << nstage, n);
+  ensure_pcr_table(n, pn, FINAL4, nfin, nstage * 3 * n + (FINAL4 ? 7 : 3) * nfin);
+  if (ctx.pcr_perm_M != M) {
+    if ((size_t)tab_len > ctx.pcr_perm_cap) {
+      if (ctx.pcr_tab_perm) {
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        HIP_CHECK(hipFree(ctx.pcr_tab_perm));
+      }
+      HIP_CHECK(hipMalloc(&ctx.pcr_tab_perm, (size_t)tab_len * sizeof(REAL)));
+      ctx.pcr_perm_cap = tab_len;
+    }
+    hipLaunchKernelGGL(pcr_coef_perm_k, dim3(1), dim3(256), 0, ctx.stream, ctx.pcr_tab, ctx.pcr_tab_perm, n, pn, nfin, FINAL4, M);
+    HIP_CHECK(hipGetLastError());
+    ctx.pcr_perm_M = M;
+  }
+  const int v = ctx.tune.pcr_variant;
+#define CZ_PCR_REG(M_)                                                                                                                \
+  if (M == M_) {                                                                                                                      \
+    if (ORDER == 1) return try_pcr_reg_inst<M_, 4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
+    if (v == 161) return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
+    if (v == 81) return try_pcr_reg_inst<M_, 8, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);     \
+    if (v == 82) return try_pcr_reg_inst<M_, 8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);     \
+    if (v == 162) return try_pcr_reg_inst<M_, 16, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
+    /* measured at 512^3 (profiles/r01/pcr_variants.txt): FP32 8 waves x 2 lines, FP64 16 waves x 1 line */                         \
+    if (sizeof(REAL) == 4 && M_ <= 8)                                                                                                 \
+      return try_pcr_reg_inst<M_, 8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                \
+    return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                 \
+  }
+  CZ_PCR_REG(2) CZ_PCR_REG(4) CZ_PCR_REG(8) CZ_PCR_REG(16)
+#undef CZ_PCR_REG
+  return false;
+}
+
+// fast form: coefficient table (computed once per line length and variant) + persistent right-hand-side-only kernel
+template <int FINAL4, int ORDER>
+bool try_pcr_rb2(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate) {
+  const int n = g.n, pn = g.pn;
+  if (pn < (FINAL4 ? 3 : 2) || pn > 20) return false;
+  {
+    long long nc;
+    if (ORDER == 0) nc = (long long)g.nhalf * g.nj;
+    else if (ORDER == 1) nc = std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1;
+    else nc = (long long)g.ni * g.nj;
+    if (ctx.tune.pcr_fast >= 2 && try_pcr_reg<FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, nc)) return true;
+  }
+  const int nstage = FINAL4 ? pn - 2 : pn - 1;
+  const int nfin = std::min(1 << nstage, n);
+  const int tab_len = nstage * 3 * n + (FINAL4 ? 7 : 3) * nfin;
+  const size_t fixed = ((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double);
+  const size_t per_line = (size_t)2 * (n + 2) * sizeof(REAL);
+  if (fixed + 4 * per_line > 160 * 1024) return false;  // table + four lines must fit
+  ensure_pcr_table(n, pn, FINAL4, nfin, tab_len);
+  long long ncol;
+  if (ORDER == 0) ncol = (long long)g.nhalf * g.nj;
+  else if (ORDER == 1) ncol = std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1;
+  else ncol = (long long)g.ni * g.nj;
+  if (ORDER == 1) {  // a diagonal holds few lines: small workgroups spread them over the chip
+    if (try_pcr_rb2_inst<4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+    return false;
+  }
+  const int v = ctx.tune.pcr_variant;
+  // measured at 512^3 FP32 (profiles/r01/pcr_variants.txt): waves per CU matter most, 16 x 1 line beats 8 x 2 lines
+  if (v == 0 || v == 161)
+    if (try_pcr_rb2_inst<16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+  if (v == 0 || v == 82)
+    if (try_pcr_rb2_inst<8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+  if (v == 0 || v == 81)
+    if (try_pcr_rb2_inst<8, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+  return try_pcr_rb2_inst<4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol);
+}
+
+PcrGeom make_pcr_geom(const Box& b, const int* idx, int pn, int sel) {
+  PcrGeom g;
+  g.nkp = b.nkp, g.nip = b.nip;
+  g.kk0 = b.kk0, g.n = b.kk1 - b.kk0 + 1;
+  g.ii0 = b.ii0, g.ni = b.ii1 - b.ii0 + 1, g.jj0 = b.jj0, g.nj = b.jj1 - b.jj0 + 1;
+  g.ist1 = idx[0], g.jst1 = idx[2];
+  g.pn = pn, g.color = sel;
+  g.nhalf = (g.ni + 1) / 2 + 1;
+  return g;
+}
+
+// The line-SOR variants that end in 4x4 systems or visit the columns in another order (pcr, pcr_esa, pcr_rb_esa, pcr_j_esa).
+// order 0: colour `sel` in place; 1: lexicographic in place = one launch per diagonal; 2: all columns, x -> wout.
+// They exist in the table form only: a line whose table does not fit LDS is refused.
+void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int order, int sel,
+                        int final4, REAL omg, double* res_dev, int accumulate) {
+  if (b.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  bool ok = true;
+  if (order == 1) {
+    const int ni = b.ii1 - b.ii0 + 1, nj = b.jj1 - b.jj0 + 1;
+    for (int dgn = 0; dgn <= ni + nj - 2 && ok; dgn++) {
+      const PcrGeom g = make_pcr_geom(b, idx, pn, dgn);
+      ok = final4 ? try_pcr_rb2<1, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0)
+                  : try_pcr_rb2<0, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0);
+    }
+  } else {
+    const PcrGeom g = make_pcr_geom(b, idx, pn, sel);
+    if (order == 0) ok = final4 ? try_pcr_rb2<1, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
+    else ok = final4 ? try_pcr_rb2<1, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
+  }
+  if (!ok) {
+    fprintf(stderr, "czhip: line SOR (4x4 / ordered variants): the coefficient table of a k-line of %d unknowns does not fit the 160 KiB of LDS\n",
+            b.kk1 - b.kk0 + 1);
+    exit(1);
+  }
+}
+
+void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int color, REAL omg,
+                   double* res_dev, int accumulate) {
+  if (b.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  PcrGeom g;
+  g.nkp = b.nkp, g.nip = b.nip;
+  g.kk0 = b.kk0, g.n = b.kk1 - b.kk0 + 1;
+  g.ii0 = b.ii0, g.ni = b.ii1 - b.ii0 + 1, g.jj0 = b.jj0, g.nj = b.jj1 - b.jj0 + 1;
+  g.ist1 = idx[0], g.jst1 = idx[2];
+  g.pn = pn, g.color = color;
+  g.nhalf = (g.ni + 1) / 2 + 1;
+  if (ctx.tune.pcr_fast && try_pcr_rb2<0, 0>(x, nullptr, msk, rhs, g, omg, res_dev, accumulate)) return;
+  // one wave per k-line, NW lines per workgroup; each line keeps 2 x (a, c, d) of n+2 entries in LDS.  Prefer four
+  // lines per group while two groups still fit a CU's 160 KiB, then fall back to fewer lines per group for long lines.
+  if (try_pcr_rb<4>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
+  if (try_pcr_rb<2>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
+  if (try_pcr_rb<1>(x, msk, rhs, g, omg, res_dev, accumulate, 160 * 1024)) return;
+  fprintf(stderr, "czhip: pcr_rb: a k-line of %d unknowns does not fit the 160 KiB of LDS\n", g.n);
+  exit(1);
+}
+
+// one lexicographic SOR sweep (psor / psor_maf): a launch per tile hyperplane, then the fixed-order sum of the tile partials
+void launch_psor(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* res_dev, int accumulate, const int* skip,
+                 const MafArgs* ma) {
+  if (bx.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  constexpr int T = 16;
+  PsorGeom g;
+  g.nkp = bx.nkp, g.nip = bx.nip, g.njp = bx.njp;
+  g.kk0 = bx.kk0, g.kk1 = bx.kk1, g.ii0 = bx.ii0, g.ii1 = bx.ii1, g.jj0 = bx.jj0, g.jj1 = bx.jj1;
+  g.ntk = (bx.kk1 - bx.kk0 + T) / T, g.nti = (bx.ii1 - bx.ii0 + T) / T, g.ntj = (bx.jj1 - bx.jj0 + T) / T;
+  const size_t ntiles = (size_t)g.ntk * g.nti * g.ntj;
+  ensure_partials(ntiles);
+  const size_t lds = ((size_t)(T + 2) * (T + 2) * (T + 2) + (size_t)T * T * T) * sizeof(REAL);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&psor_tile_k<T, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&psor_tile_k<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  {
+    ScopedTimer tm(LBL_PSOR);
+    for (int H = 0; H <= g.ntk + g.nti + g.ntj - 3; H++) {
+      if (ma) hipLaunchKernelGGL((psor_tile_k<T, 1>), dim3(g.nti, g.ntj), dim3(T * T), lds, ctx.stream, p, b, c, g, H, ctx.partials, skip, *ma);
+      else hipLaunchKernelGGL((psor_tile_k<T, 0>), dim3(g.nti, g.ntj), dim3(T * T), lds, ctx.stream, p, b, c, g, H, ctx.partials, skip, MafArgs());
+    }
+  }
+  HIP_CHECK(hipGetLastError());
+  reduce_partials((int)ntiles, res_dev, accumulate, skip);
+}
+
+void launch_imask(REAL* x, const Box& b) {
+  hipLaunchKernelGGL(imask_k, dim3(2048), dim3(256), 0, ctx.stream, x, b.nkp, b.nip, b.njp, b.kk0, b.kk1, b.ii0, b.ii1, b.jj0, b.jj1);
+  HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,129 @@
+// cz_k_common.h -- part of cz_kernels.hip (ONE translation unit per precision; this file is included inside its anonymous
+// namespace and is not a stand-alone header): vector types, loads/stores, block reduction, MAF weights.
+template <int V>
+struct alignas(sizeof(REAL) * V) Vec {
+  REAL v[V];
+};
+
+struct Coef {
+  REAL c1, c2, c3, c4, c5, c6, dd, omg;
+};
+
+// Geometry of one launch, all in PADDED 0-based indices (kk = k+g-1, ...).
+struct Geom {
+  int nip;          // padded rows per plane = NI+2g
+  int R;            // vectors per k-row = (NK+2g)/V
+  long long PSV;    // vectors per plane = R*(NI+2g)
+  int kk0, kk1;     // inner k range (inclusive)
+  int jj0, jj1;     // inner j range (inclusive)
+  long long F0;     // first vector of the update range inside a plane = ii0*R
+  long long Fend;   // one past the last vector of the update range    = (ii1+1)*R
+  int nseg;         // segments per plane
+  int TJ;           // planes per chunk
+  int S;            // vectors per segment
+};
+
+enum { MODE_JACOBI = 0, MODE_RB = 1, MODE_AX = 2, MODE_RK = 3 };
+
+// In-kernel finalisation of the residual: the workgroup that arrives last sums the per-workgroup partials in a fixed
+// order (deterministic) and, if asked, performs the convergence bookkeeping of cz_Poisson.cpp:67-77 -- no extra
+// launches per sweep.  Hand-off follows cdna_hip_programming.md Guideline 16 in its write-through form: sc1 store of
+// the partial -> s_waitcnt vmcnt(0) -> agent-scope ticket add; the last arriver reads every partial with sc1 loads.
+struct Fin {
+  double* dst = nullptr;  // device double receiving sum dp^2 (nullptr: leave the partials for a separate reduce launch)
+  int accumulate = 0;     // dst += instead of dst =
+  int do_check = 0;       // also: res = sqrt(dst*res_normal); hist[itr] = res; eps test -> flag/conv_itr
+  int itr = 0;
+  double res_normal = 0.0, eps = 0.0;
+  double* hist = nullptr;
+  int* flag = nullptr;
+  int* conv_itr = nullptr;
+  unsigned* counter = nullptr;  // arrival ticket, zero before every launch (the last workgroup resets it)
+  // MODE_AX only: fold the dot products that follow the SpMV in BiCGSTAB into it (cz_Poisson.cpp:421-427, 457-464):
+  // dst[0] = sum out*y, dst2[0] = sum out*out over the inner box (per-point products rounded to REAL like blas_dot1/2)
+  int ax_dots = 0;
+  const REAL* doty = nullptr;
+  double* dst2 = nullptr;
+};
+
+// 16-byte global accesses go through a native vector type so that hipcc emits one global_load/store_dwordx4
+// (a struct copy was split into dwordx3 + dword stores).
+template <int V>
+struct NatVec {
+  typedef REAL type __attribute__((ext_vector_type(V)));
+};
+template <>
+struct NatVec<1> {
+  typedef REAL type;
+};
+template <int V>
+__device__ __forceinline__ Vec<V> ldv(const REAL* base, long long vec_index) {
+  typedef typename NatVec<V>::type nv;
+  const nv x = *reinterpret_cast<const nv*>(base + vec_index * V);
+  Vec<V> r;
+  __builtin_memcpy(&r, &x, sizeof(r));
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void stv(REAL* base, long long vec_index, const Vec<V>& x) {
+  typedef typename NatVec<V>::type nv;
+  nv y;
+  __builtin_memcpy(&y, &x, sizeof(y));
+  *reinterpret_cast<nv*>(base + vec_index * V) = y;
+}
+template <int V>
+__device__ __forceinline__ Vec<V> zerov() {
+  Vec<V> z;
+#pragma unroll
+  for (int c = 0; c < V; c++) z.v[c] = (REAL)0;
+  return z;
+}
+
+// deterministic block reduction of one double per thread: wave64 shuffle tree, then LDS across waves.
+template <int TB>
+__device__ __forceinline__ double block_sum(double x, double* wsum /* TB/64 doubles of LDS */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) wsum[wave] = x;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < TB / 64; w++) s += wsum[w];
+  }
+  return s;  // valid on thread 0
+}
+
+// MAF flavour (cz_maf.f90, cz_blas.f90:738-1039): the six neighbour weights and the diagonal are
+// recomputed at every point from 1-D coordinate arrays (device copies of xc, yc, zc; X(i) of the Fortran is xc[i+1], which
+// for g = 2 is xc[padded index]).  pvt: row scaling of calc_ax_maf / calc_rk_maf.
+struct MafArgs {
+  const REAL* xc;
+  const REAL* yc;
+  const REAL* zc;
+  const REAL* pvt;
+};
+
+struct MafW {
+  REAL w1, w2, w3, w4, w5, w6, dd;  // weights of p(i+1), p(i-1), p(j+1), p(j-1), p(k+1), p(k-1); dd = 2(C1+C2+C3)
+};
+
+// cz_maf.f90:193-221, operation for operation
+__device__ __forceinline__ MafW maf_weights(REAL XG, REAL XGG, REAL YE, REAL YEE, REAL ZT, REAL ZTT) {
+  const REAL YJA = XG * YE * ZT;
+  const REAL YJAI = (REAL)1.0 / YJA;
+  const REAL GX = YE * ZT * YJAI;
+  const REAL EY = XG * ZT * YJAI;
+  const REAL TZ = XG * YE * YJAI;
+  const REAL C1 = GX * GX, C2 = EY * EY, C3 = TZ * TZ;
+  const REAL C7 = -XGG * C1 * GX;
+  const REAL C8 = -YEE * C2 * EY;
+  const REAL C9 = -ZTT * C3 * TZ;
+  MafW w;
+  w.w1 = C1 + (REAL)0.5 * C7, w.w2 = C1 - (REAL)0.5 * C7;
+  w.w3 = C2 + (REAL)0.5 * C8, w.w4 = C2 - (REAL)0.5 * C8;
+  w.w5 = C3 + (REAL)0.5 * C9, w.w6 = C3 - (REAL)0.5 * C9;
+  w.dd = (REAL)2.0 * (C1 + C2 + C3);
+  return w;
+}

@@ -1,0 +1,794 @@
+// cz_k_linesor.h -- part of cz_kernels.hip (ONE translation unit per precision; this file is included inside its anonymous
+// namespace and is not a stand-alone header): line SOR by parallel cyclic reduction (pcr_*), lexicographic point SOR (psor), imask_k.
+// ------------------------------------------------------------------------------------------------------------
+// Line SOR by parallel cyclic reduction, pcr_rb (cz_solver.f90:497-662).
+// One wave64 per (i,j) column of the active checkerboard colour, four columns per workgroup.  The column's tridiagonal
+// system along k lives in LDS (a, c, d and their successors a1, c1, d1, ping-ponged instead of copied back); lanes
+// stride over k, so every global access is coalesced along the unit-stride axis.  pn-1 reduction stages of stride
+// 2^(p-1), then the 2x2 systems of stride 2^(pn-1), then the relaxation -- operation for operation the reference's
+// arithmetic (serial build: entries outside kst..ked are zero, kept in two pad slots).  sum dp^2 is accumulated in double.
+// ------------------------------------------------------------------------------------------------------------
+struct PcrGeom {
+  int nkp, nip;                 // padded extents
+  int kk0, n;                   // padded index of kst, number of unknowns per column
+  int ii0, ni, jj0, nj;         // inner (i,j) range in padded indices / counts
+  int ist1, jst1;               // 1-based ist, jst (colour rule mod(i+j,2) == color uses 1-based indices)
+  int pn, color;
+  int nhalf;                    // columns of one colour per j row (upper bound)
+};
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, double* partials,
+         double* dst, int accumulate, unsigned* counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
+  REAL* base = reinterpret_cast<REAL*>(smem) + (size_t)wave * 6 * LD;
+  REAL* A[2] = {base, base + 3 * LD};          // [buf][a | c | d]
+  double* wsum = reinterpret_cast<double*>(reinterpret_cast<REAL*>(smem) + (size_t)NW * 6 * LD + 4);
+  wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
+
+  const long long col = (long long)blockIdx.x * NW + wave;  // column ordinal among the colour's columns
+  const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+  bool active = jrow < g.nj;
+  int ii = 0, jj = 0;
+  if (active) {
+    const int j1 = g.jst1 + jrow;
+    int i1 = g.ist1 + 2 * ih;
+    if (((i1 + j1) & 1) != g.color) i1 += 1;   // first i of this colour in the row
+    active = (i1 - g.ist1) < g.ni;
+    ii = g.ii0 + (i1 - g.ist1);
+    jj = g.jj0 + jrow;
+  }
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const size_t c0 = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;  // element (kst, i, j)
+  double acc = 0.0;
+
+  // ---- set-up: coefficients and source term (:545-568)
+  if (active) {
+    REAL* a = A[0];
+    REAL* c = a + LD;
+    REAL* d = c + LD;
+    if (lane == 0) {
+      for (int b = 0; b < 2; b++)
+        for (int v = 0; v < 3; v++) A[b][v * LD] = (REAL)0, A[b][v * LD + n + 1] = (REAL)0;
+    }
+    for (int k = lane; k < n; k += 64) {
+      const size_t e = c0 + k;
+      a[k + 1] = (k == 0) ? (REAL)0 : -r;
+      c[k + 1] = (k == n - 1) ? (REAL)0 : -r;
+      REAL dv = ((X[e - plane] + X[e + plane] + X[e - rowlen] + X[e + rowlen] - RHS[e]) * r) * MSK[e];
+      if (k == 0) dv = (dv + X[e - 1] * r) * MSK[e];
+      if (k == n - 1) dv = (dv + X[e + 1] * r) * MSK[e];
+      d[k + 1] = dv;
+    }
+  }
+  __syncthreads();
+  // ---- PCR stages (:572-595)
+  int cur = 0;
+  for (int p = 1; p <= g.pn - 1; p++) {
+    const int s = 1 << (p - 1);
+    if (active) {
+      const REAL* a = A[cur];
+      const REAL* c = a + LD;
+      const REAL* d = c + LD;
+      REAL* a1 = A[cur ^ 1];
+      REAL* c1 = a1 + LD;
+      REAL* d1 = c1 + LD;
+      for (int k = lane; k < n; k += 64) {
+        const int x = k + 1;
+        const int kl = (k - s >= 0) ? x - s : 0;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL ap = a[x], cp = c[x];
+        const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * c[kl] - cp * a[kr]);
+        a1[x] = -e * ap * a[kl];
+        c1[x] = -e * cp * c[kr];
+        d1[x] = e * (d[x] - ap * d[kl] - cp * d[kr]);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // ---- 2x2 systems of the last stage (:599-616), result into the d slot of the other buffer
+  {
+    const int s = 1 << (g.pn - 1);
+    if (active) {
+      const REAL* a = A[cur];
+      const REAL* c = a + LD;
+      const REAL* d = c + LD;
+      REAL* d1 = A[cur ^ 1] + 2 * LD;
+      for (int k = lane; k < s && k < n; k += 64) {
+        const int x = k + 1;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL cc1 = c[x], aa2 = a[kr], f1 = d[x], f2 = d[kr];
+        const REAL jj2 = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+        const REAL dd1 = (f1 - cc1 * f2) * jj2;
+        const REAL dd2 = (f2 - aa2 * f1) * jj2;
+        d1[x] = dd1;
+        if (kr <= n) d1[kr] = dd2;  // (the reference also stores the k = ked+1 dummy, which nothing reads)
+      }
+    }
+    __syncthreads();
+  }
+  // ---- relaxation (:626-633)
+  if (active) {
+    const REAL* d1 = A[cur ^ 1] + 2 * LD;
+    for (int k = lane; k < n; k += 64) {
+      const size_t e = c0 + k;
+      const REAL pp = X[e];
+      const REAL dp = (d1[k + 1] - pp) * omg * MSK[e];
+      X[e] = pp + dp;
+      const REAL d2 = dp * dp;
+      acc += (double)d2;
+    }
+  }
+  // ---- residual: partial per workgroup, fixed-order sum by the last one (write-through hand-off as in stencil_k)
+  __syncthreads();
+  const double sblk = block_sum<64 * NW>(acc, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 8);
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64 * NW) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<64 * NW>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// psor / psor_maf (cz_solver.f90:207-269, cz_maf.f90:23-112): lexicographic in-place SOR.  In the
+// order (j outer, i, k inner) an update sees the NEW values of its k-1, i-1, j-1 neighbours and the OLD ones of k+1, i+1,
+// j+1, so all points of a hyperplane k+i+j = const are independent: the sweep is a wavefront, and what one thread of the
+// reference computes can be reproduced bit for bit in parallel.  Two levels: the box is cut into T^3 tiles, the tiles of
+// one tile-hyperplane tk+ti+tj = H are independent (one launch per H, 3N/T - 2 launches per sweep); inside a tile, staged
+// in LDS with one halo layer (new values from the tiles before, old values from the tiles after), thread (i,j) owns a
+// column and updates k = h - i - j at step h (3T - 2 barrier-separated steps).
+// ------------------------------------------------------------------------------------------------------------
+struct PsorGeom {
+  int nkp, nip, njp;
+  int kk0, kk1, ii0, ii1, jj0, jj1;  // inner box, padded 0-based
+  int ntk, nti, ntj;                 // tiles per axis
+};
+
+template <int T, int MAF>
+__global__ void __launch_bounds__(T * T)
+psor_tile_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorGeom g, int H, double* __restrict__ tile_partials,
+            const int* __restrict__ skip, MafArgs ma) {
+  if (skip != nullptr && *skip != 0) return;
+  const int ti = blockIdx.x, tj = blockIdx.y, tk = H - ti - tj;
+  if (tk < 0 || tk >= g.ntk) return;  // uniform per workgroup
+  constexpr int L1 = T + 2, L2 = (T + 2) * (T + 2);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[T * T / 64 + 2];
+  REAL* lp = reinterpret_cast<REAL*>(smem);  // p tile with one halo layer: [j][i][k]
+  REAL* lb = lp + L2 * L1;                   // b tile
+  const int t = threadIdx.x;
+  const int K0 = g.kk0 + tk * T, I0 = g.ii0 + ti * T, J0 = g.jj0 + tj * T;  // first cell of the tile
+  const size_t si = (size_t)g.nkp, sj = (size_t)g.nkp * g.nip;
+  {  // every global read of the tile is issued before the first use (one memory latency per tile)
+    constexpr int NP = (L2 * L1 + T * T - 1) / (T * T), NB = T;
+    REAL rp[NP], rb[NB];
+#pragma unroll
+    for (int m = 0; m < NP; m++) {
+      const int e = t + m * T * T;
+      const int k = e % L1, r = e / L1, i = r % L1, j = r / L1;
+      const int gk = K0 - 1 + k, gi = I0 - 1 + i, gj = J0 - 1 + j;
+      rp[m] = (e < L2 * L1 && gk < g.nkp && gi < g.nip && gj < g.njp) ? P[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
+    }
+#pragma unroll
+    for (int m = 0; m < NB; m++) {
+      const int e = t + m * T * T;
+      const int k = e % T, r = e / T, i = r % T, j = r / T;
+      const int gk = K0 + k, gi = I0 + i, gj = J0 + j;
+      rb[m] = (gk <= g.kk1 && gi <= g.ii1 && gj <= g.jj1) ? B[(size_t)gk + (size_t)gi * si + (size_t)gj * sj] : (REAL)0;
+    }
+#pragma unroll
+    for (int m = 0; m < NP; m++)
+      if (t + m * T * T < L2 * L1) lp[t + m * T * T] = rp[m];
+#pragma unroll
+    for (int m = 0; m < NB; m++) lb[t + m * T * T] = rb[m];
+  }
+  const int i = t % T, j = t / T;
+  const int gi = I0 + i, gj = J0 + j;
+  const bool col_in = gi <= g.ii1 && gj <= g.jj1;
+  REAL XG = 0, XGG = 0, YE = 0, YEE = 0;
+  if (MAF && col_in) {  // padded index == index into xc / yc / zc for g = 2 (see MafArgs)
+    const REAL xm = ma.xc[gi - 1], x0 = ma.xc[gi], xp = ma.xc[gi + 1];
+    const REAL ym = ma.yc[gj - 1], y0 = ma.yc[gj], yp = ma.yc[gj + 1];
+    XG = (REAL)0.5 * (xp - xm), XGG = xp - (REAL)2.0 * x0 + xm;
+    YE = (REAL)0.5 * (yp - ym), YEE = yp - (REAL)2.0 * y0 + ym;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int h = 0; h <= 3 * T - 3; h++) {
+    const int k = h - i - j;
+    if (k >= 0 && k < T && col_in && K0 + k <= g.kk1) {
+      const int x = (k + 1) + L1 * (i + 1) + L2 * (j + 1);
+      const REAL pp = lp[x];
+      const REAL bb = lb[k + T * (i + T * j)];
+      if (MAF) {
+        const int gk = K0 + k;
+        const REAL zm = ma.zc[gk - 1], z0 = ma.zc[gk], zp = ma.zc[gk + 1];
+        const MafW w = maf_weights(XG, XGG, YE, YEE, (REAL)0.5 * (zp - zm), zp - (REAL)2.0 * z0 + zm);
+        const REAL rp = w.w1 * lp[x + L1] + w.w2 * lp[x - L1] + w.w3 * lp[x + L2] + w.w4 * lp[x - L2] + w.w5 * lp[x + 1] +
+                        w.w6 * lp[x - 1] + bb;  // cz_maf.f90:93-99
+        const REAL dp = (rp / w.dd - pp) * c.omg;
+        lp[x] = pp + dp;
+        const REAL d2 = dp * dp;
+        acc += (double)d2;
+      } else {
+        Vec<1> pc, im, ip, pm, pn, bv;
+        pc.v[0] = pp, im.v[0] = lp[x - L1], ip.v[0] = lp[x + L1], pm.v[0] = lp[x - L2], pn.v[0] = lp[x + L2], bv.v[0] = bb;
+        lp[x] = relax_vec<1>(pc, im, ip, pm, pn, lp[x - 1], lp[x + 1], bv, c, 1u, 1u, acc).v[0];
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = t; e < T * T * T; e += T * T) {
+    const int k = e % T, r = e / T, i2 = r % T, j2 = r / T;
+    const int gk = K0 + k, gi2 = I0 + i2, gj2 = J0 + j2;
+    if (gk <= g.kk1 && gi2 <= g.ii1 && gj2 <= g.jj1) P[(size_t)gk + (size_t)gi2 * si + (size_t)gj2 * sj] = lp[(k + 1) + L1 * (i2 + 1) + L2 * (j2 + 1)];
+  }
+  const double sblk = block_sum<T * T>(acc, wsum);
+  if (t == 0) tile_partials[(size_t)tk + (size_t)g.ntk * (ti + (size_t)g.nti * tj)] = sblk;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pcr_rb, fast form.  The matrix of every k-line is the same (a = c = -1/6, zero at the ends; cz_solver.f90:545-556), so
+// the a/c recurrences of the reduction and the reciprocals e = 1/(1 - ap*c(kl) - cp*a(kr)) (:572-595), and cc1/aa2/jj of
+// the final 2x2 systems (:599-616), are identical for all lines: pcr_coef_k evaluates them ONCE, with the reference's
+// operations in the reference's order, into a table; the per-line work that remains is the right-hand side
+//     d1(k) = e * (d(k) - ap*d(kl) - cp*d(kr))
+// -- the very expression of :590 with the very same operand values, hence the same bits -- without the division and the
+// two coefficient updates (14 -> 5 flop per entry and stage).  pcr_rb2_k keeps the table in LDS, is persistent (the table
+// is loaded once per workgroup), gives each wave L lines at a time (one table read serves L lines) and synchronises
+// waves individually (a line never leaves its wave).
+// ------------------------------------------------------------------------------------------------------------
+// table layout: stage p = 1..nstage: [e | ap | cp] x n entries each, then the final stage x nfin entries:
+//   final4 = 0 (pcr_rb, pcr_j_esa): nstage = pn-1, 2x2 systems (:599-616): [jj | cc1 | aa2]
+//   final4 = 1 (pcr, pcr_esa, pcr_rb_esa): nstage = pn-2, 4x4 systems by Cramer's rule (:787-842): [inv_detA | cc1 | cc2 | cc3 | aa2 | aa3 | aa4]
+__global__ void __launch_bounds__(256)
+pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin, int final4) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, LD = n + 2;
+  REAL* A[2] = {reinterpret_cast<REAL*>(smem), reinterpret_cast<REAL*>(smem) + 2 * LD};  // [buf][a | c]
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  for (int k = t; k < n; k += 256) {
+    A[0][k + 1] = (k == 0) ? (REAL)0 : -r;
+    A[0][LD + k + 1] = (k == n - 1) ? (REAL)0 : -r;
+  }
+  if (t == 0)
+    for (int b = 0; b < 2; b++)
+      for (int v = 0; v < 2; v++) A[b][v * LD] = (REAL)0, A[b][v * LD + n + 1] = (REAL)0;
+  __syncthreads();
+  int cur = 0;
+  const int nstage = final4 ? pn - 2 : pn - 1;
+  for (int p = 1; p <= nstage; p++) {
+    const int s = 1 << (p - 1);
+    const REAL* a = A[cur];
+    const REAL* c = a + LD;
+    REAL* a1 = A[cur ^ 1];
+    REAL* c1 = a1 + LD;
+    REAL* T = tab + (size_t)(p - 1) * 3 * n;
+    for (int k = t; k < n; k += 256) {
+      const int x = k + 1;
+      const int kl = (k - s >= 0) ? x - s : 0;
+      const int kr = (k + s <= n - 1) ? x + s : n + 1;
+      const REAL ap = a[x], cp = c[x];
+      const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * c[kl] - cp * a[kr]);
+      a1[x] = -e * ap * a[kl];
+      c1[x] = -e * cp * c[kr];
+      T[k] = e, T[n + k] = ap, T[2 * n + k] = cp;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const REAL* a = A[cur];
+  const REAL* c = a + LD;
+  REAL* F = tab + (size_t)nstage * 3 * n;
+  if (!final4) {
+    const int s = 1 << (pn - 1);
+    for (int k = t; k < nfin; k += 256) {
+      const int x = k + 1;
+      const int kr = (k + s <= n - 1) ? x + s : n + 1;
+      const REAL cc1 = c[x], aa2 = a[kr];
+      F[k] = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+      F[nfin + k] = cc1;
+      F[2 * nfin + k] = aa2;
+    }
+  } else {
+    const int s = 1 << (pn - 2);
+    for (int k = t; k < nfin; k += 256) {
+      const int x = k + 1;
+      const int kl = (k + s <= n - 1) ? x + s : n + 1, km = (k + 2 * s <= n - 1) ? x + 2 * s : n + 1, kr = (k + 3 * s <= n - 1) ? x + 3 * s : n + 1;
+      const REAL cc1 = c[x], cc2 = c[kl], cc3 = c[km], aa2 = a[kl], aa3 = a[km], aa4 = a[kr];
+      F[k] = (REAL)1.0 / ((REAL)1.0 - aa4 * cc3 - aa3 * cc2 - aa2 * cc1 * ((REAL)1.0 - cc3 * aa4));
+      F[nfin + k] = cc1, F[2 * nfin + k] = cc2, F[3 * nfin + k] = cc3;
+      F[4 * nfin + k] = aa2, F[5 * nfin + k] = aa3, F[6 * nfin + k] = aa4;
+    }
+  }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+  // the lanes of ONE wave hand data to each other through LDS: order the accesses, no workgroup barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ORDER selects the columns of one launch (the line-SOR variants of cz_solver.f90 differ in the column order):
+//   0  one checkerboard colour, in place          pcr_rb (:540), pcr_rb_esa (:1324)           g.color = colour
+//   1  one diagonal (i-ist)+(j-jst) = g.color of the lexicographic order, in place: a column of pcr (:718-719) / pcr_esa sees
+//      the new values of its i-1 and j-1 neighbours, which lie on the diagonal before => diagonals in sequence, columns of one in parallel
+//   2  all columns from the old field, result into WOUT (pcr_j_esa :1553-1632; the caller copies back, :1655-1663)
+template <int NW, int L, int FINAL4, int ORDER>
+__global__ void __launch_bounds__(64 * NW)
+pcr_rb2_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg,
+          const REAL* __restrict__ tab, int tab_len, int nfin, double* partials, double* dst, int accumulate, unsigned* counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
+  REAL* T = reinterpret_cast<REAL*>(smem);
+  REAL* D = T + tab_len + (size_t)wave * 2 * L * LD;  // [buf][line][LD]
+  double* wsum = reinterpret_cast<double*>(T + tab_len + (size_t)NW * 2 * L * LD + 4);
+  wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
+
+  for (int i = threadIdx.x; i < tab_len; i += 64 * NW) T[i] = tab[i];
+  if (lane < 2 * L) D[lane * LD] = (REAL)0, D[lane * LD + n + 1] = (REAL)0;
+  __syncthreads();
+
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const int dlo = (ORDER == 1) ? max(0, g.color - (g.nj - 1)) : 0;  // first i offset on the diagonal
+  const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj
+                         : (ORDER == 1) ? (long long)(min(g.ni - 1, g.color) - dlo + 1)
+                                        : (long long)g.ni * g.nj;
+  const long long ngroups = (ncol + L - 1) / L;
+  double acc = 0.0;
+  for (long long q = (long long)blockIdx.x * NW + wave; q < ngroups; q += (long long)gridDim.x * NW) {
+    size_t c0[L];
+    bool act[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const long long col = q * L + l;  // column ordinal among the launch's columns
+      int ii = 0, jj = 0;
+      if (ORDER == 0) {
+        const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+        act[l] = jrow < g.nj;
+        if (act[l]) {
+          const int j1 = g.jst1 + jrow;
+          int i1 = g.ist1 + 2 * ih;
+          if (((i1 + j1) & 1) != g.color) i1 += 1;  // first i of this colour in the row
+          act[l] = (i1 - g.ist1) < g.ni;
+          ii = g.ii0 + (i1 - g.ist1);
+          jj = g.jj0 + jrow;
+        }
+      } else if (ORDER == 1) {
+        act[l] = col < ncol;
+        const int io = dlo + (int)col;
+        ii = g.ii0 + io, jj = g.jj0 + (g.color - io);
+      } else {
+        act[l] = col < ncol;
+        ii = g.ii0 + (int)(col % g.ni), jj = g.jj0 + (int)(col / g.ni);
+      }
+      if (!act[l]) ii = g.ii0, jj = g.jj0;
+      c0[l] = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;  // element (kst, i, j)
+    }
+    // ---- source term (:558-568)
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      REAL* d = D + l * LD;
+      for (int k = lane; k < n; k += 64) {
+        REAL dv = (REAL)0;
+        if (act[l]) {
+          const size_t e = c0[l] + k;
+          const REAL mk = MSK[e];
+          dv = ((X[e - plane] + X[e + plane] + X[e - rowlen] + X[e + rowlen] - RHS[e]) * r) * mk;
+          if (k == 0) dv = (dv + X[e - 1] * r) * mk;
+          if (k == n - 1) dv = (dv + X[e + 1] * r) * mk;
+        }
+        d[k + 1] = dv;
+      }
+    }
+    wave_lds_sync();
+    // ---- PCR stages (:572-595), right-hand side only
+    int cur = 0;
+    const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
+    for (int p = 1; p <= nstage; p++) {
+      const int s = 1 << (p - 1);
+      const REAL* Tp = T + (size_t)(p - 1) * 3 * n;
+      const REAL* dc = D + (size_t)cur * L * LD;
+      REAL* dn = D + (size_t)(cur ^ 1) * L * LD;
+      for (int k = lane; k < n; k += 64) {
+        const int x = k + 1;
+        const int kl = (k - s >= 0) ? x - s : 0;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL e = Tp[k], ap = Tp[n + k], cp = Tp[2 * n + k];
+#pragma unroll
+        for (int l = 0; l < L; l++) dn[l * LD + x] = e * (dc[l * LD + x] - ap * dc[l * LD + kl] - cp * dc[l * LD + kr]);
+      }
+      wave_lds_sync();
+      cur ^= 1;
+    }
+    // ---- 4x4 systems of the last stage by Cramer's rule (:787-842; pcr, pcr_esa, pcr_rb_esa)
+    if (FINAL4) {
+      const int s = 1 << (g.pn - 2);
+      const REAL* F = T + (size_t)nstage * 3 * n;
+      const REAL* dc = D + (size_t)cur * L * LD;
+      REAL* dn = D + (size_t)(cur ^ 1) * L * LD;
+      for (int k = lane; k < nfin; k += 64) {
+        const int x = k + 1;
+        const int kl = (k + s <= n - 1) ? x + s : n + 1, km = (k + 2 * s <= n - 1) ? x + 2 * s : n + 1, kr = (k + 3 * s <= n - 1) ? x + 3 * s : n + 1;
+        const REAL inv_detA = F[k], cc1 = F[nfin + k], cc2 = F[2 * nfin + k], cc3 = F[3 * nfin + k];
+        const REAL aa2 = F[4 * nfin + k], aa3 = F[5 * nfin + k], aa4 = F[6 * nfin + k];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const REAL dd1 = dc[l * LD + x], dd2 = dc[l * LD + kl], dd3 = dc[l * LD + km], dd4 = dc[l * LD + kr];
+          const REAL detA1 = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+          const REAL detA2 = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+          const REAL detA3 = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+          const REAL detA4 = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+          dn[l * LD + x] = detA1 * inv_detA;
+          if (kl <= n) dn[l * LD + kl] = detA2 * inv_detA;
+          if (km <= n) dn[l * LD + km] = detA3 * inv_detA;
+          if (kr <= n) dn[l * LD + kr] = detA4 * inv_detA;
+        }
+      }
+      wave_lds_sync();
+    } else {  // ---- 2x2 systems of the last stage (:599-616)
+      const int s = 1 << (g.pn - 1);
+      const REAL* F = T + (size_t)nstage * 3 * n;
+      const REAL* dc = D + (size_t)cur * L * LD;
+      REAL* dn = D + (size_t)(cur ^ 1) * L * LD;
+      for (int k = lane; k < nfin; k += 64) {
+        const int x = k + 1;
+        const int kr = (k + s <= n - 1) ? x + s : n + 1;
+        const REAL jj2 = F[k], cc1 = F[nfin + k], aa2 = F[2 * nfin + k];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const REAL f1 = dc[l * LD + x], f2 = dc[l * LD + kr];
+          const REAL dd1 = (f1 - cc1 * f2) * jj2;
+          const REAL dd2 = (f2 - aa2 * f1) * jj2;
+          dn[l * LD + x] = dd1;
+          if (kr <= n) dn[l * LD + kr] = dd2;
+        }
+      }
+      wave_lds_sync();
+    }
+    // ---- relaxation (:626-633)
+    {
+      const REAL* d1 = D + (size_t)(cur ^ 1) * L * LD;
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        if (!act[l]) continue;
+        for (int k = lane; k < n; k += 64) {
+          const size_t e = c0[l] + k;
+          const REAL pp = X[e];
+          const REAL dp = (d1[l * LD + k + 1] - pp) * omg * MSK[e];
+          if (ORDER == 2) WOUT[e] = pp + dp;
+          else X[e] = pp + dp;
+          const REAL d2 = dp * dp;
+          acc += (double)d2;
+        }
+      }
+    }
+    wave_lds_sync();  // the next group's source term overwrites buffer 0
+  }
+  // ---- residual: partial per workgroup, fixed-order sum by the last one (write-through hand-off as in stencil_k)
+  __syncthreads();
+  const double sblk = block_sum<64 * NW>(acc, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64 * NW) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<64 * NW>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Line SOR, register form.  A wave owns a k-line (L lines at a time); lane `lane` holds the M consecutive entries
+// k = lane*M .. lane*M + M-1 of the right-hand side d in registers.  A reduction stage needs d(k-s) and d(k+s): for s < M
+// they are in the lane's own registers except at the edges of its block (one value from lane-1 / lane+1), for s >= M they are
+// entry m of lane -/+ s/M -- a cross-lane shuffle, no LDS memory and no barrier at all.  LDS holds only the
+// line-independent coefficient table (pcr_coef_k's values, re-ordered [m][lane] so that reads are conflict-free), loaded
+// once per persistent workgroup.  Same operations on the same operand values as pcr_rb2_k => same bits.
+// ------------------------------------------------------------------------------------------------------------
+// table: stage p = 1..nstage: [e | ap | cp] x NE, then the final stage [7 x NE if FINAL4 else 3 x NE], NE = 64*M, entry of
+// element k = lane*M + m at m*64 + lane; entries of k >= n are zero
+__global__ void __launch_bounds__(256)
+pcr_coef_perm_k(const REAL* __restrict__ nat, REAL* __restrict__ tab, int n, int pn, int nfin, int final4, int M) {
+  const int NE = 64 * M;
+  const int nstage = final4 ? pn - 2 : pn - 1;
+  const int s = 1 << nstage;  // stride of the final stage
+  for (int k = threadIdx.x; k < NE; k += 256) {
+    const int x = (k % M) * 64 + k / M;
+    for (int p = 0; p < nstage; p++)
+      for (int v = 0; v < 3; v++) tab[(size_t)(p * 3 + v) * NE + x] = (k < n) ? nat[(size_t)p * 3 * n + (size_t)v * n + k] : (REAL)0;
+    const REAL* F = nat + (size_t)nstage * 3 * n;
+    REAL* G = tab + (size_t)nstage * 3 * NE;
+    const int kb = k % s;  // base element of the 2x2 / 4x4 system this element belongs to
+    const int nf = final4 ? 7 : 3;
+    for (int v = 0; v < nf; v++) G[(size_t)v * NE + x] = (k < n && kb < nfin) ? F[(size_t)v * nfin + kb] : (REAL)0;
+  }
+}
+
+// M consecutive elements from / to an address that is only element-aligned (a k-line starts at padded index g): the hardware
+// takes multi-dword global accesses at dword alignment
+#ifdef CZ_REAL_IS_DOUBLE
+typedef double RunVec __attribute__((ext_vector_type(2), aligned(8)));
+constexpr int kRunW = 2;
+#else
+typedef float RunVec __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int kRunW = 4;
+#endif
+template <int M>
+__device__ __forceinline__ void load_run(const REAL* __restrict__ p, REAL (&o)[M]) {
+  if (M % kRunW == 0) {
+#pragma unroll
+    for (int c = 0; c < M; c += kRunW) {
+      const RunVec v = *reinterpret_cast<const RunVec*>(p + c);
+#pragma unroll
+      for (int w = 0; w < kRunW; w++) o[c + w] = v[w];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < M; c++) o[c] = p[c];
+  }
+}
+template <int M>
+__device__ __forceinline__ void store_run(REAL* __restrict__ p, const REAL (&o)[M], int nvalid) {
+  if (M % kRunW == 0 && nvalid >= M) {
+#pragma unroll
+    for (int c = 0; c < M; c += kRunW) {
+      RunVec v;
+#pragma unroll
+      for (int w = 0; w < kRunW; w++) v[w] = o[c + w];
+      *reinterpret_cast<RunVec*>(p + c) = v;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < M; c++)
+      if (c < nvalid) p[c] = o[c];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T lane_up(T v, int q, int lane) {  // value of lane - q, zero below lane 0
+  const T r = __shfl_up(v, (unsigned)q, 64);
+  return (q < 64 && lane >= q) ? r : (T)0;
+}
+template <typename T>
+__device__ __forceinline__ T lane_down(T v, int q, int lane) {  // value of lane + q, zero above lane 63
+  const T r = __shfl_down(v, (unsigned)q, 64);
+  return (q < 64 && lane + q < 64) ? r : (T)0;
+}
+
+template <int M, int NW, int L, int FINAL4, int ORDER>
+__global__ void __launch_bounds__(64 * NW)
+pcr_line_reg_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg,
+               const REAL* __restrict__ tab, int tab_len, double* partials, double* dst, int accumulate, unsigned* counter) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NE = 64 * M;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = g.n;
+  REAL* T = reinterpret_cast<REAL*>(smem);
+  double* wsum = reinterpret_cast<double*>(T + tab_len + 4);
+  wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
+  for (int i = threadIdx.x; i < tab_len; i += 64 * NW) T[i] = tab[i];
+  __syncthreads();
+
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const int dlo = (ORDER == 1) ? max(0, g.color - (g.nj - 1)) : 0;
+  const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj
+                         : (ORDER == 1) ? (long long)(min(g.ni - 1, g.color) - dlo + 1)
+                                        : (long long)g.ni * g.nj;
+  const long long ngroups = (ncol + L - 1) / L;
+  const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
+  const int k0 = lane * M;
+  double acc = 0.0;
+  for (long long q = (long long)blockIdx.x * NW + wave; q < ngroups; q += (long long)gridDim.x * NW) {
+    size_t c0[L];
+    bool act[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const long long col = q * L + l;
+      int ii = 0, jj = 0;
+      if (ORDER == 0) {
+        const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+        act[l] = jrow < g.nj;
+        if (act[l]) {
+          const int j1 = g.jst1 + jrow;
+          int i1 = g.ist1 + 2 * ih;
+          if (((i1 + j1) & 1) != g.color) i1 += 1;
+          act[l] = (i1 - g.ist1) < g.ni;
+          ii = g.ii0 + (i1 - g.ist1);
+          jj = g.jj0 + jrow;
+        }
+      } else if (ORDER == 1) {
+        act[l] = col < ncol;
+        const int io = dlo + (int)col;
+        ii = g.ii0 + io, jj = g.jj0 + (g.color - io);
+      } else {
+        act[l] = col < ncol;
+        ii = g.ii0 + (int)(col % g.ni), jj = g.jj0 + (int)(col / g.ni);
+      }
+      if (!act[l]) ii = g.ii0, jj = g.jj0;
+      c0[l] = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;
+    }
+    // ---- source term (:558-568)
+    // (a run may reach past the end of its line: those values are read from the rows behind it -- the array continues for at
+    // least one more plane -- and discarded)
+    REAL d[L][M];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      if (act[l] && k0 < n) {
+        const size_t e0 = c0[l] + k0;
+        REAL xjm[M], xjp[M], xim[M], xip[M], rh[M], mk[M];
+        load_run<M>(X + e0 - plane, xjm);
+        load_run<M>(X + e0 + plane, xjp);
+        load_run<M>(X + e0 - rowlen, xim);
+        load_run<M>(X + e0 + rowlen, xip);
+        load_run<M>(RHS + e0, rh);
+        load_run<M>(MSK + e0, mk);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const int k = k0 + m;
+          REAL dv = ((xjm[m] + xjp[m] + xim[m] + xip[m] - rh[m]) * r) * mk[m];
+          if (k == 0) dv = (dv + X[e0 - 1] * r) * mk[m];
+          if (k == n - 1) dv = (dv + X[e0 + m + 1] * r) * mk[m];
+          d[l][m] = (k < n) ? dv : (REAL)0;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < M; m++) d[l][m] = (REAL)0;
+      }
+    }
+    // ---- PCR stages (:572-595), right-hand side only; every index below is a compile-time constant
+#pragma unroll
+    for (int sidx = 0; sidx < 20; sidx++) {
+      if ((1 << sidx) >= NE) break;  // compile time
+      if (sidx < nstage) {
+        const int s = 1 << sidx;
+        const REAL* Tp = T + (size_t)sidx * 3 * NE;
+        REAL nd[L][M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const REAL e = Tp[m * 64 + lane], ap = Tp[NE + m * 64 + lane], cp = Tp[2 * NE + m * 64 + lane];
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            REAL dl, dr;
+            if (s < M) {
+              dl = (m - s >= 0) ? d[l][(m - s >= 0) ? m - s : 0] : lane_up(d[l][(m - s + M) % M], 1, lane);
+              dr = (m + s < M) ? d[l][(m + s < M) ? m + s : 0] : lane_down(d[l][(m + s) % M], 1, lane);
+            } else {
+              dl = lane_up(d[l][m], s / M, lane);
+              dr = lane_down(d[l][m], s / M, lane);
+            }
+            nd[l][m] = e * (d[l][m] - ap * dl - cp * dr);
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < L; l++)
+#pragma unroll
+          for (int m = 0; m < M; m++) d[l][m] = (k0 + m < n) ? nd[l][m] : (REAL)0;
+      }
+    }
+    // ---- final stage: every entry solves for itself
+    {
+      const int s = 1 << nstage;
+      const int qf = s / M;  // s >= M always (s >= n/4 > 8M .. see launch_pcr_reg)
+      const REAL* F = T + (size_t)nstage * 3 * NE;
+      REAL sol[L][M];
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        const int k = k0 + m;
+        const int rr = k >> nstage;  // position of this entry in its 2x2 / 4x4 system (s = 2^nstage)
+        const int x = m * 64 + lane;
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          const REAL me = d[l][m];
+          if (!FINAL4) {  // (:599-616)
+            const REAL jj2 = F[x], cc1 = F[NE + x], aa2 = F[2 * NE + x];
+            const REAL up = lane_up(me, qf, lane), dn = lane_down(me, qf, lane);
+            const REAL f1 = rr == 0 ? me : up, f2 = rr == 0 ? dn : me;
+            sol[l][m] = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;
+          } else {  // Cramer's rule (:787-842)
+            const REAL inv_detA = F[x], cc1 = F[NE + x], cc2 = F[2 * NE + x], cc3 = F[3 * NE + x];
+            const REAL aa2 = F[4 * NE + x], aa3 = F[5 * NE + x], aa4 = F[6 * NE + x];
+            const REAL u1 = lane_up(me, qf, lane), u2 = lane_up(me, 2 * qf, lane), u3 = lane_up(me, 3 * qf, lane);
+            const REAL w1 = lane_down(me, qf, lane), w2 = lane_down(me, 2 * qf, lane), w3 = lane_down(me, 3 * qf, lane);
+            const REAL dd1 = rr == 0 ? me : rr == 1 ? u1 : rr == 2 ? u2 : u3;
+            const REAL dd2 = rr == 0 ? w1 : rr == 1 ? me : rr == 2 ? u1 : u2;
+            const REAL dd3 = rr == 0 ? w2 : rr == 1 ? w1 : rr == 2 ? me : u1;
+            const REAL dd4 = rr == 0 ? w3 : rr == 1 ? w2 : rr == 2 ? w1 : me;
+            REAL det;
+            if (rr == 0) det = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+            else if (rr == 1) det = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+            else if (rr == 2) det = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+            else det = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+            sol[l][m] = det * inv_detA;
+          }
+        }
+      }
+      // ---- relaxation (:626-633)
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        if (!act[l] || k0 >= n) continue;
+        const size_t e0 = c0[l] + k0;
+        REAL pp[M], mk[M], out[M];
+        load_run<M>(X + e0, pp);
+        load_run<M>(MSK + e0, mk);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const REAL dp = (sol[l][m] - pp[m]) * omg * mk[m];
+          out[m] = pp[m] + dp;
+          const REAL d2 = dp * dp;
+          if (k0 + m < n) acc += (double)d2;
+        }
+        store_run<M>((ORDER == 2 ? WOUT : X) + e0, out, n - k0);
+      }
+    }
+  }
+  // ---- residual: partial per workgroup, fixed-order sum by the last one (write-through hand-off as in stencil_k)
+  __syncthreads();
+  const double sblk = block_sum<64 * NW>(acc, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64 * NW) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<64 * NW>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
+// imask_k (cz_blas.f90:24-104): 1 on the inner box, 0 elsewhere (whole padded array)
+__global__ void __launch_bounds__(256)
+imask_k(REAL* X, int nkp, int nip, int njp, int kk0, int kk1, int ii0, int ii1, int jj0, int jj1) {
+  const size_t n = (size_t)nkp * nip * njp;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    const int kk = (int)(e % nkp);
+    const size_t r = e / nkp;
+    const int ii = (int)(r % nip), jj = (int)(r / nip);
+    const bool in = kk >= kk0 && kk <= kk1 && ii >= ii0 && ii <= ii1 && jj >= jj0 && jj <= jj1;
+    X[e] = in ? (REAL)1.0 : (REAL)0.0;
+  }
+}

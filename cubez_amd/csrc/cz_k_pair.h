@@ -1,0 +1,452 @@
+// cz_k_pair.h -- part of cz_kernels.hip (ONE translation unit per precision; this file is included inside its anonymous
+// namespace and is not a stand-alone header): jacobi2_k (two sweeps / both RB colours per pass) and pair_shell_k (the shell slabs of a decomposed brick).
+// ------------------------------------------------------------------------------------------------------------
+// TWO relaxed-Jacobi sweeps per pass over memory (temporal blocking, single-domain runs).
+//
+// Each sweep of cz_solver.f90:334-351 is HBM bound at 12 B per update and stencil_k already moves within 5 % of the
+// ideal bytes (profiles/r01), so the only way past the streaming ceiling is to apply sweep n+1 and sweep n+2 while
+// the data are on chip.  Same 2.5-D march as stencil_k, two stages deep:
+//     stage 1 at plane q   : v(q)   = relax(u(q-1), u(q), u(q+1))     on E1 = own segment +- one k-row (R vectors)
+//     stage 2 at plane q-1 : w(q-1) = relax(v(q-2), v(q-1), v(q))     on the own segment
+// u = input field (time n), v = time n+1 (never leaves the CU: registers + LDS), w = output (time n+2).
+// Register queues hold u(q-1..q+1) and v(q-2..q) of the thread's vectors; LDS holds the centre planes u(q) (own
+// segment +- 2 rows) and v(q-1) (own +- 1 row) for the i+-1 / k+-1 neighbours, double-buffered, one barrier per plane.
+// The halo rows of v and the first/last plane of a chunk are recomputed by the neighbouring workgroups (redundant
+// arithmetic, (S+2R)/S in i and (TJ+2)/TJ in j) instead of being exchanged.  Points outside the inner box pass
+// through unchanged (v = u), exactly what a separate first sweep would have left in memory, and the per-point
+// arithmetic is the same un-fused float sequence, so the result is bit-identical to two launches of stencil_k.
+// Both residuals (sum dp^2 of sweep n+1 and of sweep n+2) are produced; each point is counted by the one workgroup
+// that owns it.
+// ------------------------------------------------------------------------------------------------------------
+struct Geom2 {
+  int R;
+  long long PSV;
+  int kk0, kk1, jj0, jj1;      // stage-2 (output) box = the inner box
+  long long F0, Fend;
+  // stage-1 box: the inner box, grown by one layer across rank-internal faces of a decomposed run (the first sweep
+  // must also be applied to the ghost layer the second sweep reads; two ghost layers are exchanged per pair)
+  int kk0a, kk1a, jj0a, jj1a;
+  long long F0a, Fenda;
+  int nseg, TJ, S;  // S = TB*MV - 2R
+  int par;          // RB: colour 0 = points with (kk + ii + jj + par) even
+  int zero_u;       // the input field is identically zero (a freshly cleared preconditioner vector): u is not read
+};
+
+struct Fin2 {
+  double* dst = nullptr;   // [0] <- sum of sweep n+1, [1] <- sum of sweep n+2
+  int do_check = 0, itr = 0;  // itr = iteration number of sweep n+1
+  int single = 0;             // RB: both stages belong to ONE iteration: dst[0] = sum1 + sum2, one bookkeeping step
+  const double* extra = nullptr;  // per-workgroup sums of the shell launch of a split pass (pair_shell_k): n_extra first-stage
+  int n_extra = 0;                // sums followed by n_extra second-stage sums, added to this launch's own
+  double res_normal = 0.0, eps = 0.0;
+  double* hist = nullptr;
+  int* flag = nullptr;
+  int* conv_itr = nullptr;
+  unsigned* counter = nullptr;
+};
+
+// bit cc set when (base + cc) is even
+template <int V>
+__device__ __forceinline__ unsigned colour_bits(int base) {
+  const unsigned even = (V == 4) ? 0x5u : (V == 2) ? 0x1u : 0x1u;   // components 0,2 / 0 / 0
+  const unsigned odd = (V == 4) ? 0xAu : (V == 2) ? 0x2u : 0x0u;    // components 1,3 / 1 / -
+  return (base & 1) ? odd : even;
+}
+
+template <int V>
+__device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
+                                            const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c,
+                                            unsigned mask, unsigned count_mask, double& acc) {
+  Vec<V> o;
+#pragma unroll
+  for (int cc = 0; cc < V; cc++) {
+    const REAL pp = pc.v[cc];
+    const REAL km1 = (cc == 0) ? kl : pc.v[cc > 0 ? cc - 1 : 0];
+    const REAL kp1 = (cc == V - 1) ? kr : pc.v[cc < V - 1 ? cc + 1 : V - 1];
+    const REAL ss = c.c1 * ip.v[cc] + c.c2 * im.v[cc] + c.c3 * pn.v[cc] + c.c4 * pm.v[cc] + c.c5 * kp1 + c.c6 * km1;
+    const REAL dp = ((ss - bb.v[cc]) / c.dd - pp) * c.omg;
+    const REAL d2 = dp * dp;
+    o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;
+    if (count_mask & (1u << cc)) acc += (double)d2;
+  }
+  return o;
+}
+
+// RB = 0: two Jacobi sweeps.  RB = 1: one red-black SOR iteration (cz_solver.f90:466-480 for colour 0 then colour 1):
+// stage 1 updates the points of colour 0, stage 2 those of colour 1 from the freshly updated colour-0 neighbours; the
+// other colour passes through each stage unchanged.  Out of place (U -> W) like the Jacobi pair.
+template <int V, int TB, int MV, int RB>
+__global__ void __launch_bounds__(TB, (TB == 512 && MV <= 2) ? 4 : 1)
+jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
+          const int* __restrict__ skip, Fin2 fin) {
+  if (skip != nullptr && *skip != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int R = g.R;
+  const int LU = g.S + 4 * R, LV = g.S + 2 * R;
+  Vec<V>* ldsU = reinterpret_cast<Vec<V>*>(smem);                 // 2 buffers of LU vectors
+  Vec<V>* ldsV = ldsU + (size_t)2 * LU;                            // 2 buffers of LV vectors
+  double* wsum = reinterpret_cast<double*>(ldsV + (size_t)2 * LV);  // 16 doubles + flag
+
+  int lb = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) lb = (lb & 7) * (nblk >> 3) + (lb >> 3);
+  const int seg = lb % g.nseg;
+  const int chunk = lb / g.nseg;
+  const long long fb = g.F0 + (long long)seg * g.S;
+  const int ja = g.jj0 + chunk * g.TJ;
+  int jb = ja + g.TJ - 1;
+  if (jb > g.jj1) jb = g.jj1;
+
+  double acc1 = 0.0, acc2 = 0.0;
+
+  if (ja <= jb && fb < g.Fend) {
+    const long long e1_0 = fb - R;       // first vector of E1
+    const long long e2_0 = fb - 2 * R;   // first vector of E2
+    long long f[MV];
+    unsigned ka[MV];     // stage-1 bits: components of the vector inside the stage-1 box (0 when the row is outside)
+    unsigned own[MV];    // stage-2 bits if this workgroup owns the vector (stores, residual counts), else 0
+    int pbase[MV];       // RB: (kk + ii + par) of component 0; component cc on plane jj has colour (pbase + cc + jj) & 1
+    bool ld[MV];
+#pragma unroll
+    for (int m = 0; m < MV; m++) {
+      const int e = t + m * TB;
+      f[m] = e1_0 + e;
+      ld[m] = (e < LV) && (f[m] < g.PSV) && !g.zero_u;
+      const long long row = f[m] / R;
+      const int kv = (int)(f[m] - row * R);
+      unsigned bits1 = 0, bits2 = 0;
+#pragma unroll
+      for (int cc = 0; cc < V; cc++) {
+        const int kk = kv * V + cc;
+        if (kk >= g.kk0a && kk <= g.kk1a) bits1 |= 1u << cc;
+        if (kk >= g.kk0 && kk <= g.kk1) bits2 |= 1u << cc;
+      }
+      pbase[m] = kv * V + (int)row + g.par;
+      ka[m] = (e < LV && f[m] >= g.F0a && f[m] < g.Fenda) ? bits1 : 0u;
+      own[m] = (e >= R && e < R + g.S && f[m] >= g.F0 && f[m] < g.Fend) ? bits2 : 0u;
+    }
+
+    Vec<V> ua[MV], ub[MV], uc[MV], b1[MV], b2[MV], va[MV], vb[MV], vc[MV];
+    // prologue: u(ja-2), u(ja-1); LDS_U[0] = u(ja-1) on E2
+    {
+      const REAL* Ua = U + (long long)(ja - 2) * g.PSV * V;
+      const REAL* Ub = U + (long long)(ja - 1) * g.PSV * V;
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        ua[m] = ld[m] ? ldv<V>(Ua, f[m]) : zerov<V>();
+        ub[m] = ld[m] ? ldv<V>(Ub, f[m]) : zerov<V>();
+        b2[m] = zerov<V>();
+        va[m] = zerov<V>();
+        vb[m] = zerov<V>();
+      }
+#pragma unroll
+      for (int m = 0; m < MV; m++)
+        if (t + m * TB < LV) ldsU[R + t + m * TB] = ub[m];
+      if (t < R) {
+        const long long fh = fb + g.S + R + t;
+        ldsU[t] = g.zero_u ? zerov<V>() : ldv<V>(Ub, e2_0 + t);
+        ldsU[R + LV + t] = (fh < g.PSV && !g.zero_u) ? ldv<V>(Ub, fh) : zerov<V>();
+      }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int q = ja - 1; q <= jb + 1; q++) {
+      const bool more = q <= jb;
+      const bool plane_inner = (q >= g.jj0a && q <= g.jj1a);
+      const bool count1 = (q >= ja && q <= jb);
+      const bool do2 = (q - 1 >= ja);
+      // ---- loads of this step: u(q+1) and b(q) on E1, outer halo rows of u(q+1)
+      const REAL* Uc = U + (long long)(q + 1) * g.PSV * V;
+      const REAL* Bq = B + (long long)q * g.PSV * V;
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        uc[m] = ld[m] ? ldv<V>(Uc, f[m]) : zerov<V>();
+        b1[m] = (ka[m] != 0 && plane_inner) ? ldv<V>(Bq, f[m]) : zerov<V>();
+      }
+      Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
+      if (more && t < R && !g.zero_u) {
+        hlo = ldv<V>(Uc, e2_0 + t);
+        const long long fh = fb + g.S + R + t;
+        if (fh < g.PSV) hhi = ldv<V>(Uc, fh);
+      }
+
+      // ---- stage 1: v(q) on E1
+      const Vec<V>* bufU = ldsU + (size_t)cur * LU;
+      const REAL* bufUf = reinterpret_cast<const REAL*>(bufU);
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        const int e = t + m * TB;
+        if (e >= LV) continue;
+        unsigned msk = plane_inner ? ka[m] : 0u;
+        if (RB) msk &= colour_bits<V>(pbase[m] + q);  // colour 0 on plane q
+        if (msk == 0) {
+          vc[m] = ub[m];  // outside the inner box: the first sweep leaves the value alone
+        } else {
+          const int x = e + R;
+          const Vec<V> im = bufU[x - R];
+          const Vec<V> ip = bufU[x + R];
+          const REAL kl = bufUf[x * V - 1];
+          const REAL kr = bufUf[x * V + V];
+          vc[m] = relax_vec<V>(ub[m], im, ip, ua[m], uc[m], kl, kr, b1[m], c, msk, count1 ? (own[m] & msk) : 0u, acc1);
+        }
+      }
+      // ---- publish v(q) for the next step's stage 2
+      {
+        Vec<V>* nV = ldsV + (size_t)(cur ^ 1) * LV;
+#pragma unroll
+        for (int m = 0; m < MV; m++)
+          if (t + m * TB < LV) nV[t + m * TB] = vc[m];
+      }
+      // ---- stage 2: w(q-1) on the own segment
+      if (do2) {
+        const Vec<V>* bufV = ldsV + (size_t)cur * LV;
+        const REAL* bufVf = reinterpret_cast<const REAL*>(bufV);
+        REAL* Wq = W + (long long)(q - 1) * g.PSV * V;
+#pragma unroll
+        for (int m = 0; m < MV; m++) {
+          if (own[m] == 0) continue;
+          const int e = t + m * TB;
+          const Vec<V> im = bufV[e - R];
+          const Vec<V> ip = bufV[e + R];
+          const REAL kl = bufVf[e * V - 1];
+          const REAL kr = bufVf[e * V + V];
+          unsigned m2 = own[m];
+          if (RB) m2 &= colour_bits<V>(pbase[m] + (q - 1) + 1);  // colour 1 on plane q-1
+          const Vec<V> o = relax_vec<V>(vb[m], im, ip, va[m], vc[m], kl, kr, b2[m], c, m2, m2, acc2);
+          if (own[m] == (1u << V) - 1) {
+            stv<V>(Wq, f[m], o);
+          } else {
+#pragma unroll
+            for (int cc = 0; cc < V; cc++)
+              if (own[m] & (1u << cc)) Wq[f[m] * V + cc] = o.v[cc];
+          }
+        }
+      }
+      // ---- stage the next u centre plane, rotate
+      if (more) {
+        Vec<V>* nU = ldsU + (size_t)(cur ^ 1) * LU;
+#pragma unroll
+        for (int m = 0; m < MV; m++)
+          if (t + m * TB < LV) nU[R + t + m * TB] = uc[m];
+        if (t < R) {
+          nU[t] = hlo;
+          nU[R + LV + t] = hhi;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        ua[m] = ub[m];
+        ub[m] = uc[m];
+        b2[m] = b1[m];
+        va[m] = vb[m];
+        vb[m] = vc[m];
+      }
+      cur ^= 1;
+    }
+  }
+
+  // ---- residuals: per-workgroup partials, finalised by the last workgroup (write-through hand-off, see stencil_k)
+  __syncthreads();
+  const double s1 = block_sum<TB>(acc1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<TB>(acc2, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  if (t == 0) {
+    __hip_atomic_store(&partials[lb], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[nblk + lb], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x1 = 0.0, x2 = 0.0;
+    for (int i = t; i < nblk; i += TB) {
+      x1 += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      x2 += __hip_atomic_load(&partials[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int i = t; i < fin.n_extra; i += TB) {  // written by an earlier launch on this stream
+      x1 += fin.extra[i];
+      x2 += fin.extra[fin.n_extra + i];
+    }
+    __syncthreads();
+    const double t1 = block_sum<TB>(x1, wsum);
+    __syncthreads();
+    const double t2 = block_sum<TB>(x2, wsum);
+    if (t == 0 && fin.single) {
+      const double tot = t1 + t2;  // colour 0 + colour 1 (cz_Poisson.cpp:205-209 accumulate into one res)
+      fin.dst[0] = tot;
+      if (fin.do_check) {
+        const double r = sqrt(tot * fin.res_normal);
+        fin.hist[fin.itr] = r;
+        if (r < fin.eps) {
+          *fin.flag = 1;
+          *fin.conv_itr = fin.itr;
+        }
+      }
+      *fin.counter = 0u;
+    } else if (t == 0) {
+      fin.dst[0] = t1;
+      fin.dst[1] = t2;
+      if (fin.do_check) {  // cz_Poisson.cpp:69-77 for iteration itr, then itr+1
+        double r = sqrt(t1 * fin.res_normal);
+        fin.hist[fin.itr] = r;
+        if (r < fin.eps) {
+          *fin.flag = 1;
+          *fin.conv_itr = fin.itr;
+        } else {
+          r = sqrt(t2 * fin.res_normal);
+          fin.hist[fin.itr + 1] = r;
+          if (r < fin.eps) {
+            *fin.flag = 1;
+            *fin.conv_itr = fin.itr + 1;
+          }
+        }
+      }
+      *fin.counter = 0u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The same two-stage update on thin boxes: the cells a decomposed brick owes its neighbours (two layers behind every
+// rank-internal face).  The driver runs this first, starts the halo exchange on a second stream and lets jacobi2_k
+// work on the interior meanwhile.  A slab two cells thick has no plane to march along, so it is cut into
+// small 3-D tiles instead: a workgroup stages the tile of u with two halo layers in LDS, applies stage 1 to the tile
+// plus one layer (LDS), then stage 2 to the tile.  Tile shapes follow the slab's orientation (long in k wherever k is
+// not the thin axis, so that global accesses stay coalesced).  Same scalar operation sequence as relax_vec<1> => the
+// fields are bit-identical to an unsplit jacobi2_k launch.
+// ------------------------------------------------------------------------------------------------------------
+struct ShellBox {
+  int i0, j0, k0, ni, nj, nk;  // padded 0-based start, extent
+  int kind;                    // tile shape: 0 = 64x4x2 (k,i,j; J slabs), 1 = 64x2x4 (I slabs), 2 = 2x16x16 (K slabs), 3 = 32x4x4
+  int ntk, nti, ntj;           // tiles per axis
+};
+struct ShellTab {
+  int n;
+  ShellBox b[6];
+  int ii0a, ii1a, jj0a, jj1a, kk0a, kk1a;  // stage-1 box of the brick (inner box grown across rank-internal faces)
+  int nkp, nip, njp;
+  int par;
+};
+
+// all tiles of one box that this workgroup takes; the tile shape is a compile-time constant (index arithmetic without divisions)
+template <int RB, int TK, int TI, int TJ>
+__device__ __forceinline__ void shell_tiles(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, const Coef& c,
+                                            const ShellTab& s, const ShellBox& d, REAL* lu, double& acc1, double& acc2) {
+  constexpr int UK = TK + 4, UI = TI + 4, UJ = TJ + 4;  // u tile: two halo layers
+  constexpr int VK = TK + 2, VI = TI + 2, VJ = TJ + 2;  // v tile: one halo layer
+  REAL* lv = lu + UK * UI * UJ;
+  const int t = threadIdx.x;
+  const int si = s.nkp, sj = s.nkp * s.nip;  // a halo'd tile spans < 2^31 elements: 32-bit offsets from the tile origin
+  const int ntiles = d.ntk * d.nti * d.ntj;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tkx = tile % d.ntk, tr = tile / d.ntk;
+    const int K0 = d.k0 + tkx * TK, I0 = d.i0 + (tr % d.nti) * TI, J0 = d.j0 + (tr / d.nti) * TJ;
+    const int ck = min(TK, d.k0 + d.nk - K0), ci = min(TI, d.i0 + d.ni - I0), cj = min(TJ, d.j0 + d.nj - J0);  // clipped core
+    const size_t org = (size_t)(K0 - 2) + (size_t)(I0 - 2) * s.nkp + (size_t)(J0 - 2) * s.nkp * s.nip;  // first cell of the u tile
+    const REAL* __restrict__ Ut = U + org;
+    const REAL* __restrict__ Bt = B + org;
+    REAL* __restrict__ Wt = W + org;
+    // ---- every global read of the tile is issued before the first use (one memory latency per tile, not one per element)
+    constexpr int NU = (UK * UI * UJ + 255) / 256, NV = (VK * VI * VJ + 255) / 256, NO = (TK * TI * TJ + 255) / 256;
+    REAL ru[NU], rb1[NV], rb2[NO];
+#pragma unroll
+    for (int n = 0; n < NU; n++) {
+      const int e = t + n * 256;
+      const int k = e % UK, r = e / UK, i = r % UI, j = r / UI;
+      const int gk = K0 - 2 + k, gi = I0 - 2 + i, gj = J0 - 2 + j;
+      ru[n] = (e < UK * UI * UJ && gk < s.nkp && gi < s.nip && gj < s.njp) ? Ut[k + i * si + j * sj] : (REAL)0;
+    }
+    unsigned in1 = 0;  // bit n: stage 1 applies to this thread's n-th point of the v tile
+#pragma unroll
+    for (int n = 0; n < NV; n++) {
+      const int e = t + n * 256;
+      const int k = e % VK, r = e / VK, i = r % VI, j = r / VI;
+      const int gk = K0 - 1 + k, gi = I0 - 1 + i, gj = J0 - 1 + j;
+      const bool inside = e < VK * VI * VJ && gi >= s.ii0a && gi <= s.ii1a && gj >= s.jj0a && gj <= s.jj1a && gk >= s.kk0a && gk <= s.kk1a &&
+                          !(RB && ((gk + gi + gj + s.par) & 1));
+      rb1[n] = inside ? Bt[(k + 1) + (i + 1) * si + (j + 1) * sj] : (REAL)0;
+      if (inside) in1 |= 1u << n;
+    }
+#pragma unroll
+    for (int n = 0; n < NO; n++) {
+      const int e = t + n * 256;
+      const int k = e % TK, r = e / TK, i = r % TI, j = r / TI;
+      const bool live = e < TK * TI * TJ && k < ck && i < ci && j < cj;
+      rb2[n] = live ? Bt[(k + 2) + (i + 2) * si + (j + 2) * sj] : (REAL)0;
+    }
+#pragma unroll
+    for (int n = 0; n < NU; n++)
+      if (t + n * 256 < UK * UI * UJ) lu[t + n * 256] = ru[n];
+    __syncthreads();
+    // ---- stage 1 on the core plus one layer
+#pragma unroll
+    for (int n = 0; n < NV; n++) {
+      const int e = t + n * 256;
+      if (e >= VK * VI * VJ) continue;
+      const int k = e % VK, r = e / VK, i = r % VI, j = r / VI;
+      const int cu = (k + 1) + UK * ((i + 1) + UI * (j + 1));
+      REAL v = lu[cu];
+      if (in1 & (1u << n)) {
+        const bool core = k >= 1 && k <= ck && i >= 1 && i <= ci && j >= 1 && j <= cj;
+        Vec<1> pc, im, ip, pm, pn, bb;
+        pc.v[0] = v, im.v[0] = lu[cu - UK], ip.v[0] = lu[cu + UK], pm.v[0] = lu[cu - UK * UI], pn.v[0] = lu[cu + UK * UI];
+        bb.v[0] = rb1[n];
+        v = relax_vec<1>(pc, im, ip, pm, pn, lu[cu - 1], lu[cu + 1], bb, c, 1u, core ? 1u : 0u, acc1).v[0];
+      }
+      lv[e] = v;
+    }
+    __syncthreads();
+    // ---- stage 2 on the core
+#pragma unroll
+    for (int n = 0; n < NO; n++) {
+      const int e = t + n * 256;
+      const int k = e % TK, r = e / TK, i = r % TI, j = r / TI;
+      if (e >= TK * TI * TJ || k >= ck || i >= ci || j >= cj) continue;
+      const int gk = K0 + k, gi = I0 + i, gj = J0 + j;
+      const int cv = (k + 1) + VK * ((i + 1) + VI * (j + 1));
+      REAL o = lv[cv];
+      if (!(RB && !((gk + gi + gj + s.par) & 1))) {  // RB: colour 0 passes through stage 2
+        Vec<1> pc, im, ip, pm, pn, bb;
+        pc.v[0] = o, im.v[0] = lv[cv - VK], ip.v[0] = lv[cv + VK], pm.v[0] = lv[cv - VK * VI], pn.v[0] = lv[cv + VK * VI];
+        bb.v[0] = rb2[n];
+        o = relax_vec<1>(pc, im, ip, pm, pn, lv[cv - 1], lv[cv + 1], bb, c, 1u, 1u, acc2).v[0];
+      }
+      Wt[(k + 2) + (i + 2) * si + (j + 2) * sj] = o;
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB>
+__global__ void __launch_bounds__(256)
+pair_shell_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, ShellTab s, double* partials,
+             const int* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double wsum[8];
+  const int t = threadIdx.x;
+  const ShellBox d = s.b[blockIdx.y];
+  REAL* lu = reinterpret_cast<REAL*>(smem);
+  double acc1 = 0.0, acc2 = 0.0;
+  switch (d.kind) {  // uniform per workgroup
+    case 0: shell_tiles<RB, 64, 4, 2>(U, B, W, c, s, d, lu, acc1, acc2); break;
+    case 1: shell_tiles<RB, 64, 2, 4>(U, B, W, c, s, d, lu, acc1, acc2); break;
+    case 2: shell_tiles<RB, 2, 16, 16>(U, B, W, c, s, d, lu, acc1, acc2); break;
+    default: shell_tiles<RB, 32, 4, 4>(U, B, W, c, s, d, lu, acc1, acc2); break;
+  }
+  // residuals: one pair of sums per workgroup; the interior launch that follows on the stream adds them to its own
+  const int nblk = gridDim.x * gridDim.y;
+  const int lb = blockIdx.y * gridDim.x + blockIdx.x;
+  const double s1 = block_sum<256>(acc1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<256>(acc2, wsum);
+  if (t == 0) {
+    partials[lb] = s1;
+    partials[nblk + lb] = s2;
+  }
+}
