@@ -31,7 +31,9 @@ def test_invalid_solver_exits_like_the_reference(tmp_path):
 
 
 @pytest.mark.parametrize("tag", ["jacobi_32x32x32_f32", "sor2sma_32x32x32_f64", "jacobi_48x40x36_f32", "pbicgstab_jacobi_64x64x64_f64",
-                                 "jacobi_maf_32x32x32_f32", "pbicgstab_maf_sor2sma_maf_32x32x32_f64"])
+                                 "jacobi_maf_32x32x32_f32", "pbicgstab_maf_sor2sma_maf_32x32x32_f64", "psor_32x32x32_f32",
+                                 "pcr_rb_32x32x32_f32", "pcr_rb_esa_32x32x32_f32", "pcr_j_esa_32x32x32_f64", "pcr_32x32x32_f32",
+                                 "pbicgstab_psor_32x32x32_f64", "pbicgstab_pcr_rb_esa_32x32x32_f64"])
 def test_cli_matches_reference_run(tmp_path, tag):
     c = CASES[tag]
     args = list(c["gsz"]) + [c["solver"], c["itr_max"], c["coef"]] + ([c["precond"]] if c["precond"] else [])
