@@ -139,7 +139,7 @@ bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Pc
 template <int FINAL4, int ORDER>
 bool try_pcr_rb2(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate) {
   const int n = g.n, pn = g.pn;
-  if (pn < (FINAL4 ? 3 : 2) || pn > 20) return false;
+  if (pn < (FINAL4 ? 2 : 1) || pn > 20) return false;  // (a line of ONE unknown has no 4x4 form: the reference's 2**(pn-2) is 0 there)
   {
     long long nc;
     if (ORDER == 0) nc = (long long)g.nhalf * g.nj;

@@ -274,13 +274,13 @@ class CzHip:
         return self._pcr_call(self.lib.pcr_, sz, idx, pn, [], x, msk, rhs, [], omg, res)
 
     def pcr_esa(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
-        return self._pcr_call(self.lib.pcr_esa_, sz, idx, pn, [1 << (pn - 2)], x, msk, rhs, [], omg, res)
+        return self._pcr_call(self.lib.pcr_esa_, sz, idx, pn, [(1 << pn) >> 2], x, msk, rhs, [], omg, res)
 
     def pcr_rb_esa(self, sz, idx, pn, ofst, color, x, msk, rhs, omg, res=0.0):
-        return self._pcr_call(self.lib.pcr_rb_esa_, sz, idx, pn, [ofst, color, 1 << (pn - 2)], x, msk, rhs, [], omg, res)
+        return self._pcr_call(self.lib.pcr_rb_esa_, sz, idx, pn, [ofst, color, (1 << pn) >> 2], x, msk, rhs, [], omg, res)
 
     def pcr_j_esa(self, sz, idx, pn, x, msk, rhs, src, wrk, omg, res=0.0):
-        return self._pcr_call(self.lib.pcr_j_esa_, sz, idx, pn, [1 << (pn - 2)], x, msk, rhs, [src, wrk], omg, res)
+        return self._pcr_call(self.lib.pcr_j_esa_, sz, idx, pn, [(1 << pn) >> 2], x, msk, rhs, [src, wrk], omg, res)
 
     def blas_clear(self, x, sz):
         (_, szp), g = self._i(sz), C.c_int(GUIDE)

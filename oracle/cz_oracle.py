@@ -284,7 +284,7 @@ class Kernels:
 
     def pcr_esa(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
         """cz_solver.f90:1050-1257"""
-        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int(1 << (pn - 2))
+        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int((1 << pn) >> 2)
         w1, w = self._pcr_work(sz, pn)
         r, fl = C.c_double(res), C.c_double(0.0)
         self._f("pcr_esa")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), C.byref(ss), self._rp(x), self._rp(msk), self._rp(rhs),
@@ -294,7 +294,7 @@ class Kernels:
 
     def pcr_rb_esa(self, sz, idx, pn, ofst, color, x, msk, rhs, omg, res=0.0):
         """cz_solver.f90:1261-1469"""
-        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int(1 << (pn - 2))
+        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int((1 << pn) >> 2)
         o, c = C.c_int(ofst), C.c_int(color)
         w1, w = self._pcr_work(sz, pn)
         r, fl = C.c_double(res), C.c_double(0.0)
@@ -306,7 +306,7 @@ class Kernels:
 
     def pcr_j_esa(self, sz, idx, pn, x, msk, rhs, src, wrk, omg, res=0.0):
         """cz_solver.f90:1473-1676"""
-        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int(1 << (pn - 2))
+        sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int((1 << pn) >> 2)
         w1, w = self._pcr_work(sz, pn)
         r, fl = C.c_double(res), C.c_double(0.0)
         self._f("pcr_j_esa")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), C.byref(ss), self._rp(x), self._rp(msk), self._rp(rhs),

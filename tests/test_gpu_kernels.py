@@ -555,3 +555,57 @@ def test_pcr_variants_random_boxes_vs_oracle(prec, box):
             assert _beq(dx.get(), x1), (name, it)
             assert _rel(r2, r1) < (2e-3 if prec == "f32" else 1e-11), (name, r1, r2)  # the oracle sums dp^2 in REAL here
             assert h.last_flop == ko.last_flop, name
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("nk", [3, 4, 5, 6, 7, 10])
+def test_line_sor_short_lines(prec, nk):
+    """k-lines of 1..8 unknowns (pn = 1..4): fewer reduction stages than the kernels are tuned for, none at all for n <= 3."""
+    ni, nj = 6, 5
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    n = nk - 2
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(n)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    names = ["pcr_rb", "pcr_j_esa"] + (["pcr_rb_esa", "pcr"] if pn >= 2 else [])
+    for name in names:
+        x1, dx = x0.copy(), h.alloc(sz, x0)
+        if name == "pcr_rb":
+            for color in (0, 1):
+                ko.pcr_rb(sz, idx, pn, 0, color, x1, msk, rhs, 1.1)
+                h.pcr_rb(sz, idx, pn, 0, color, dx, dm, dr, 1.1)
+        elif name == "pcr_rb_esa":
+            for color in (0, 1):
+                ko.pcr_rb_esa(sz, idx, pn, 0, color, x1, msk, rhs, 1.1)
+                h.pcr_rb_esa(sz, idx, pn, 0, color, dx, dm, dr, 1.1)
+        elif name == "pcr":
+            ko.pcr(sz, idx, pn, x1, msk, rhs, 1.1)
+            h.pcr(sz, idx, pn, dx, dm, dr, 1.1)
+        else:
+            ko.pcr_j_esa(sz, idx, pn, x1, msk, rhs, np.zeros(shape, dtype=R), np.zeros(shape, dtype=R), 1.1)
+            h.pcr_j_esa(sz, idx, pn, dx, dm, dr, h.alloc(sz), h.alloc(sz), 1.1)
+        assert _beq(dx.get(), x1), (name, n, pn)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_empty_index_ranges_are_no_ops(prec):
+    """ragged / empty inputs: an index range with ied < ist touches nothing and adds nothing to res (psor, pcr*, fused pair)."""
+    h = _hip(prec)
+    R = np.float32 if prec == "f32" else np.float64
+    sz = [8, 7, 12]
+    rng = np.random.default_rng(9)
+    x0 = rng.uniform(-1, 1, (sz[1] + 4, sz[0] + 4, sz[2] + 4)).astype(R)
+    dx, db, dm = h.alloc(sz, x0), h.alloc(sz, x0), h.alloc(sz, x0)
+    idx = [5, 4, 2, 6, 2, 11]
+    cf = [1, 1, 1, 1, 1, 1, 6]
+    assert h.psor(dx, sz, idx, cf, 1.1, db, res=0.5) == 0.5
+    assert h.pcr_rb(sz, idx, 4, 0, 0, dx, dm, db, 1.1, res=0.25) == 0.25
+    assert h.pcr(sz, idx, 4, dx, dm, db, 1.1, res=0.25) == 0.25
+    assert h.psor2sma_core(dx, sz, idx, cf, 0, 1, 1.1, db, res=0.125) == 0.125
+    assert dx.get().tobytes() == x0.tobytes()
