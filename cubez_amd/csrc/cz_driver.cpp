@@ -309,8 +309,12 @@ int CZ::Setup(int argc, char** argv) {
   }
   auto is_line = [](int t) { return t == LS_PCR || t == LS_PCR_ESA || t == LS_PCR_RB || t == LS_PCR_RB_ESA || t == LS_PCR_J_ESA; };
   if (is_line(ls_type) || is_line(pc_type)) {
-    if (numProc > 1) {
-      Hostonly_ printf("line SOR (pcr*) : single-domain runs only in this build\n");
+    // A k-line is solved by one wave: bricks must hold whole lines (no cut along k).  The colour and Jacobi orders exchange
+    // ghost columns after each colour / iteration and reproduce the single-domain run; the lexicographic orders (pcr, pcr_esa)
+    // are one wavefront through the grid and stay single-domain.
+    auto is_lex = [](int t) { return t == LS_PCR || t == LS_PCR_ESA; };
+    if (numProc > 1 && (G_div[2] > 1 || is_lex(ls_type) || is_lex(pc_type))) {
+      Hostonly_ printf("line SOR (pcr*) : decomposed runs need whole k-lines (gdv_z = 1) and the colour or Jacobi order\n");
       return 0;
     }
     MSK = czhip_alloc_s3d(size);            // :242
@@ -869,17 +873,21 @@ int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_
   int itr;
   for (itr = 1; itr <= itr_max; itr++) {
     if (order == 0) {
-      for (int color = 0; color < 2; color++)
-        pcr_variant_async(X, nullptr, MSK, B, size, innerFidx, gc, pn, 0, color, final4, ac1, d_res, color);  // :685-690
+      for (int color = 0; color < 2; color++) {  // :685-690; global colouring and an exchange per colour as in LSOR_PCR_RB
+        pcr_variant_async(X, nullptr, MSK, B, size, innerFidx, gc, pn, 0, (color + head[0] + head[1]) & 1, final4, ac1, d_res, color);
+        if (!Comm_S(X)) return 0;
+      }
     } else if (order == 1) {
       pcr_variant_async(X, nullptr, MSK, B, size, innerFidx, gc, pn, 1, 0, final4, ac1, d_res, 0);  // :783-786, :966-969
     } else {
       pcr_variant_async(X, WRK, MSK, B, size, innerFidx, gc, pn, 2, 0, final4, ac1, d_res, 0);  // :1061-1064
       copy_inner_async(X, WRK, size, innerFidx, gc);
+      if (!Comm_S(X)) return 0;  // :1068
     }
     flop += (npts() / n) * (n * 6.0 + n * (double)stages * 14.0 + fin + n * 6.0 + 6.0);
     if (converge_check) {
       // long launches: a host round trip per iteration is negligible, the reference's sequential test is kept as is
+      if (!Comm_SUM_dev(d_res, 1)) return 0;
       czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
@@ -916,11 +924,17 @@ int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, 
   }
   int itr;
   for (itr = 1; itr <= itr_max; itr++) {
-    for (int color = 0; color < 2; color++) pcr_rb_async(X, MSK, B, size, innerFidx, gc, pn, color, ac1, d_res, color);  // :573-578
+    for (int color = 0; color < 2; color++) {  // :573-578
+      // mod(i+j, 2) == color is meant in GLOBAL indices: the brick's local rule is shifted by its head (the reference's
+      // MPI path ignores this, cz_solver.f90:534 "unused variable"; here decomposed == single domain)
+      pcr_rb_async(X, MSK, B, size, innerFidx, gc, pn, (color + head[0] + head[1]) & 1, ac1, d_res, color);
+      if (!Comm_S(X)) return 0;  // after each colour, like the two-colour RB-SOR path
+    }
     flop += npts() * (12.0 + (pn - 1) * 14.0);
     if (converge_check) {
       // the line solves are long launches: a host round trip per iteration is negligible here, so the reference's
       // sequential test (:584-601) is kept as is
+      if (!Comm_SUM_dev(d_res, 1)) return 0;
       czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));

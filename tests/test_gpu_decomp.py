@@ -82,6 +82,10 @@ CASES = [
     ("f32", (48, 36, 44), "jacobi", 12, 0.8, (3, 1, 1)),     # middle brick: both faces of an axis border a rank
     ("f32", (40, 48, 44), "sor2sma", 9, 1.5, (1, 3, 1)),
     ("f64", (36, 40, 54), "jacobi", 10, 0.8, (1, 1, 3)),
+    ("f32", (40, 36, 32), "pcr_rb", 8, 1.2, (2, 1, 1)),       # line SOR: whole k-lines per brick, exchange after each colour
+    ("f64", (41, 37, 32), "pcr_rb", 8, 1.2, (2, 2, 1)),       # odd heads: global colouring
+    ("f32", (40, 39, 64), "pcr_rb_esa", 6, 1.2, (1, 3, 1)),
+    ("f64", (36, 40, 32), "pcr_j_esa", 6, 0.9, (2, 2, 1)),
 ]
 
 
@@ -99,7 +103,7 @@ def test_decomposed_equals_single_domain(case, overlap):
     for itr, res, hist, P, loc in results:
         assert itr == itr1
         assert np.allclose(hist, hist1, rtol=1e-12, atol=0)
-        if (loc["size"][2] + 4) % (4 if prec == "f32" else 2) == 0:
+        if solver in ("jacobi", "sor2sma") and (loc["size"][2] + 4) % (4 if prec == "f32" else 2) == 0:
             # aligned bricks take the two-sweeps-per-pass kernel with the two-layer exchange
             npass = itmax // 2 if solver == "jacobi" else itmax
             assert loc["fused_pairs"] == npass, loc
@@ -130,3 +134,28 @@ def test_decomposed_bicgstab(pc):
     assert all(r[0] == itr1 for r in results)
     assert np.allclose(results[0][2], hist1, rtol=1e-6, atol=0)
     assert np.abs(G[2:-2, 2:-2, 2:-2] - P1[2:-2, 2:-2, 2:-2]).max() < 1e-9
+
+
+def test_line_sor_refuses_a_cut_along_k():
+    """a k-line is solved by one wave: bricks must hold whole lines; pcr (lexicographic) stays single-domain"""
+    import ctypes as C
+    from cubez_amd import CZ, load
+    lib = load("f32")
+    lib.cz_comm_local_world.restype = C.c_void_p
+    lib.cz_comm_bootstrap_local.argtypes = [C.c_void_p, C.c_int]
+    lib.cz_comm_local_world_free.argtypes = [C.c_void_p]
+    for solver, div in (("pcr_rb", (1, 1, 2)), ("pcr", (2, 1, 1)), ("psor", (1, 2, 1))):
+        world = lib.cz_comm_local_world(2)
+        rets = [None, None]
+
+        def work(r):
+            lib.cz_comm_bootstrap_local(world, r)
+            cz = CZ("f32", quiet=True)
+            rets[r] = cz.setup([32, 32, 32, solver, 4, 1.2] + list(div))
+            cz.close()
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        [t.start() for t in th]
+        [t.join(timeout=120) for t in th]
+        lib.cz_comm_local_world_free(world)
+        assert rets == [0, 0], (solver, div, rets)
