@@ -318,7 +318,7 @@ class Kernels:
     def pcr_sweep_wide(self, name, sz, idx, pn, color, x, msk, rhs, wrk, omg, wide, res=0.0):
         """one sweep of a line-SOR variant with sum dp^2 also accumulated in double (oracle only)"""
         assert self.kind == "oracle"
-        order, final4 = {"pcr": (0, 1), "pcr_esa": (0, 1), "pcr_rb_esa": (1, 1), "pcr_j_esa": (2, 0)}[name]
+        order, final4 = {"pcr": (0, 1), "pcr_esa": (0, 1), "pcr_rb_esa": (1, 1), "pcr_j_esa": (2, 0), "pcr_rb_2x2": (1, 0)}[name]
         sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
         ints = [C.c_int(v) for v in (pn, order, color, final4)]
         r = C.c_double(res)

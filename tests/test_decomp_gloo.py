@@ -113,6 +113,15 @@ def _rank_main(rank, world, port, gsz, div, solver, nit, coef, prec, q):
             if solver == "jacobi":
                 k.jacobi(P, size, idx, cf, coef, RHS, WRK, wide=w)
                 halo(P)
+            elif solver == "pcr_rb":
+                # line SOR (whole k-lines per brick): GLOBAL colouring = the brick's rule shifted by its head, exchange per colour
+                if _ == 0:
+                    MSK = k.alloc(size)
+                    k.imask_k(MSK, size, idx)
+                    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+                for color in (0, 1):
+                    k.pcr_sweep_wide("pcr_rb_2x2", size, idx, pn, (color + head[0] + head[1]) & 1, P, MSK, RHS, None, coef, w)
+                    halo(P)
             else:
                 for color in (0, 1):
                     k.psor2sma_core(P, size, idx, cf, ofst, color, coef, RHS, wide=w)
@@ -130,6 +139,7 @@ DECOMP_CASES = [
     ("jacobi", (21, 19, 23), (2, 1, 1), 9, 0.8, "f64"),
     ("sor2sma", (21, 18, 23), (1, 1, 2), 10, 1.5, "f32"),
     ("sor2sma", (21, 19, 23), (2, 2, 1), 8, 1.5, "f32"),
+    ("pcr_rb", (21, 19, 18), (2, 2, 1), 6, 1.2, "f64"),
 ]
 
 
