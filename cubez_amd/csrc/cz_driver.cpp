@@ -19,6 +19,7 @@
 #include "cz_driver.h"
 
 #include <strings.h>
+#include <ctype.h>
 #include <unistd.h>
 
 #include <cfloat>
@@ -49,6 +50,11 @@ const char* printMethod(int t) {
     case LS_PCR_RB_ESA: return "PCR_RB_ESA";
     case LS_PCR_J_ESA: return "PCR_J_ESA";
     case LS_PSOR_MAF: return "PSOR_MAF";
+    case LS_PCR_MAF: return "PCR_MAF";
+    case LS_PCR_EDA_MAF: return "PCR_EDA_MAF";
+    case LS_PCR_ESA_MAF: return "PCR_ESA_MAF";
+    case LS_PCR_RB_MAF: return "PCR_RB_MAF";
+    case LS_PCR_RB_ESA_MAF: return "PCR_RB_ESA_MAF";
     case LS_JACOBI_MAF: return "JACOBI_MAF";
     case LS_SOR2SMA_MAF: return "SOR2SMA_MAF";
     case LS_BICGSTAB_MAF: return "PBiCGSTAB_MAF";
@@ -126,9 +132,13 @@ void CZ::setStrPre() {
   else if (!strcasecmp(precon.c_str(), "pcr")) pc_type = LS_PCR;                // :591-593
   else if (!strcasecmp(precon.c_str(), "psor")) pc_type = LS_PSOR;
   else if (!strcasecmp(precon.c_str(), "psor_maf")) pc_type = LS_PSOR_MAF, SW_maf = 1;
+  else if (!strcasecmp(precon.c_str(), "pcr_rb_maf")) pc_type = LS_PCR_RB_MAF, SW_maf = 1;          // :606-617
+  else if (!strcasecmp(precon.c_str(), "pcr_rb_esa_maf")) pc_type = LS_PCR_RB_ESA_MAF, SW_maf = 1;
+  else if (!strcasecmp(precon.c_str(), "pcr_maf")) pc_type = LS_PCR_MAF, SW_maf = 1;
+  else if (!strcasecmp(precon.c_str(), "pcr_eda_maf")) pc_type = LS_PCR_EDA_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "none")) pc_type = LS_NONE;
   else {
-    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | psor | sor2sma | pcr | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf)\n", precon.c_str());
+    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | psor | sor2sma | pcr | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf | pcr_maf | pcr_eda_maf | pcr_rb_maf | pcr_rb_esa_maf)\n", precon.c_str());
     exit(0);
   }
 }
@@ -151,6 +161,13 @@ void CZ::setLS(const char* q) {
   } else if (!strcasecmp(q, "psor_maf")) {  // :748-751
     ls_type = LS_PSOR_MAF;
     hist_name = "psor_maf.txt";
+    SW_maf = 1;
+  } else if (!strcasecmp(q, "pcr_rb_maf") || !strcasecmp(q, "pcr_rb_esa_maf") || !strcasecmp(q, "pcr_maf") || !strcasecmp(q, "pcr_eda_maf") ||
+             !strcasecmp(q, "pcr_esa_maf")) {  // :767-797, the MAF line solvers
+    ls_type = !strcasecmp(q, "pcr_rb_maf") ? LS_PCR_RB_MAF : !strcasecmp(q, "pcr_rb_esa_maf") ? LS_PCR_RB_ESA_MAF
+              : !strcasecmp(q, "pcr_maf") ? LS_PCR_MAF : !strcasecmp(q, "pcr_eda_maf") ? LS_PCR_EDA_MAF : LS_PCR_ESA_MAF;
+    hist_name = std::string(q) + ".txt";
+    for (char& ch : hist_name) ch = (char)tolower((unsigned char)ch);
     SW_maf = 1;
   } else if (!strcasecmp(q, "pcr_rb_esa")) {  // :712-716
     ls_type = LS_PCR_RB_ESA;
@@ -307,12 +324,14 @@ int CZ::Setup(int argc, char** argv) {
     Hostonly_ printf("psor : single-domain runs only in this build\n");
     return 0;
   }
-  auto is_line = [](int t) { return t == LS_PCR || t == LS_PCR_ESA || t == LS_PCR_RB || t == LS_PCR_RB_ESA || t == LS_PCR_J_ESA; };
+  auto is_line = [](int t) {
+    return t == LS_PCR || t == LS_PCR_ESA || t == LS_PCR_RB || t == LS_PCR_RB_ESA || t == LS_PCR_J_ESA || (t >= LS_PCR_MAF && t <= LS_PCR_RB_ESA_MAF);
+  };
   if (is_line(ls_type) || is_line(pc_type)) {
     // A k-line is solved by one wave: bricks must hold whole lines (no cut along k).  The colour and Jacobi orders exchange
     // ghost columns after each colour / iteration and reproduce the single-domain run; the lexicographic orders (pcr, pcr_esa)
     // are one wavefront through the grid and stay single-domain.
-    auto is_lex = [](int t) { return t == LS_PCR || t == LS_PCR_ESA; };
+    auto is_lex = [](int t) { return t == LS_PCR || t == LS_PCR_ESA || t == LS_PCR_MAF || t == LS_PCR_EDA_MAF || t == LS_PCR_ESA_MAF; };
     if (numProc > 1 && (G_div[2] > 1 || is_lex(ls_type) || is_lex(pc_type))) {
       Hostonly_ printf("line SOR (pcr*) : decomposed runs need whole k-lines (gdv_z = 1) and the colour or Jacobi order\n");
       return 0;
@@ -380,6 +399,13 @@ int CZ::Solve() {
     case LS_PCR_RB_ESA:
     case LS_PCR_J_ESA:
       if (0 == (itr = LSOR_PCR_VARIANT(res, P, RHS, ItrMax, flop, ls_type))) return 0;
+      break;
+    case LS_PCR_MAF:
+    case LS_PCR_EDA_MAF:
+    case LS_PCR_ESA_MAF:
+    case LS_PCR_RB_MAF:
+    case LS_PCR_RB_ESA_MAF:
+      if (0 == (itr = LSOR_PCR_MAF(res, P, RHS, ItrMax, flop, ls_type))) return 0;
       break;
     default:
       break;
@@ -906,6 +932,54 @@ int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_
   return itr;
 }
 
+// The line solvers of the MAF flavour (cz_Poisson.cpp:549-557, 665-683, 770-776, 853-859, 940-946 call pcr_rb_maf_, pcr_rb_esa_maf_,
+// pcr_maf_, pcr_eda_maf_, pcr_esa_maf_): coefficients from the metrics of the 1-D grids, pn-1 stages + 2x2 systems.
+int CZ::LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+  const int gc = GUIDE;
+  hipStream_t st = stream();
+  const int n = innerFidx[K_plus] - innerFidx[K_minus] + 1;
+  const int pn = pcr_num_stage(n);
+  if (pn < 0) {
+    printf("error : number of stage\n");
+    exit(0);
+  }
+  const bool rb = (s_type == LS_PCR_RB_MAF || s_type == LS_PCR_RB_ESA_MAF);
+  const double fin = (s_type == LS_PCR_EDA_MAF || s_type == LS_PCR_ESA_MAF) ? 9.0 : 11.0;
+  if (converge_check) {
+    ensure_hist(itr_max + 2);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+  }
+  int itr;
+  for (itr = 1; itr <= itr_max; itr++) {
+    if (rb) {
+      for (int color = 0; color < 2; color++) {  // global colouring, exchange per colour (as LSOR_PCR_RB)
+        pcr_maf_async(X, MSK, B, size, innerFidx, gc, pn, 0, (color + head[0] + head[1]) & 1, d_xc, d_yc, d_zc, ac1, d_res, color);
+        if (!Comm_S(X)) return 0;
+      }
+    } else {
+      pcr_maf_async(X, MSK, B, size, innerFidx, gc, pn, 1, 0, d_xc, d_yc, d_zc, ac1, d_res, 0);
+    }
+    flop += (npts() / n) * ((24.0 + 6.0 + 12.0) + n * 21.0 + (n - 2.0) * 6.0 + n * (double)(pn - 1) * 16.0 + (double)(1 << (pn - 1)) * fin + n * 6.0);
+    if (converge_check) {
+      if (!Comm_SUM_dev(d_res, 1)) return 0;
+      czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+      HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (h_flag[0]) break;
+    }
+  }
+  if (converge_check) {
+    const int n_exec = itr > itr_max ? itr_max : itr;
+    const size_t base = history.size();
+    history.resize(base + n_exec);
+    HIP_CHECK(hipMemcpy(history.data() + base, d_hist + 1, (size_t)n_exec * sizeof(double), hipMemcpyDeviceToHost));
+    res = history.back();
+  } else {
+    czhip_sync();
+  }
+  return itr;
+}
+
 // cz_Poisson.cpp:518-611.  Line SOR: every (i,j) column of one checkerboard colour is solved along k by parallel cyclic
 // reduction (pcr_rb_k), colour 0 then colour 1, in place.  Single-domain.
 int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
@@ -1007,6 +1081,12 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
     case LS_PCR:
     case LS_PCR_RB_ESA:  // (LS_PCR_J_ESA has no case in the reference either, cz_Poisson.cpp:282-321: it falls to the copy)
       LSOR_PCR_VARIANT(res, xx, bb, lc_max, flop, s_type, false);
+      break;
+    case LS_PCR_MAF:
+    case LS_PCR_EDA_MAF:
+    case LS_PCR_RB_MAF:
+    case LS_PCR_RB_ESA_MAF:  // :300-316
+      LSOR_PCR_MAF(res, xx, bb, lc_max, flop, s_type, false);
       break;
     default: {
       const size_t n = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE);

@@ -13,7 +13,7 @@ typedef CZ_REAL REAL_TYPE;  // cz_Define.h:28-37
 #define GUIDE 2             // cz_Define.h:40
 
 // cz_Define.h:68-89 (only the solvers of the hot path are accepted; the others are rejected by setLS)
-enum LinearSolver { LS_NONE = 0, LS_PSOR = 1, LS_SOR2SMA, LS_BICGSTAB, LS_JACOBI, LS_PCR = 5, LS_PCR_EDA, LS_PCR_ESA, LS_PCR_RB, LS_PCR_RB_ESA, LS_PCR_J_ESA, LS_PSOR_MAF = 11, LS_SOR2SMA_MAF, LS_BICGSTAB_MAF, LS_JACOBI_MAF };
+enum LinearSolver { LS_NONE = 0, LS_PSOR = 1, LS_SOR2SMA, LS_BICGSTAB, LS_JACOBI, LS_PCR = 5, LS_PCR_EDA, LS_PCR_ESA, LS_PCR_RB, LS_PCR_RB_ESA, LS_PCR_J_ESA, LS_PSOR_MAF = 11, LS_SOR2SMA_MAF, LS_BICGSTAB_MAF, LS_JACOBI_MAF, LS_PCR_MAF, LS_PCR_EDA_MAF, LS_PCR_ESA_MAF, LS_PCR_RB_MAF, LS_PCR_RB_ESA_MAF };
 
 // CB_Define_stub.h:64-70 / cz_fparam.fi:10-16
 enum { I_minus = 0, I_plus, J_minus, J_plus, K_minus, K_plus };
@@ -107,6 +107,7 @@ class CZ {
   int RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   int PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   int LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
+  int LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   int LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   REAL_TYPE Fdot1(REAL_TYPE* x, double& flop);
   REAL_TYPE Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop);

@@ -9,21 +9,23 @@ int num_stage(int n) {  // cz.h:293-300
   return -1;
 }
 
-template <int NW>
-bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, double* res_dev, int accumulate, size_t lds_cap) {
-  const long long ncol = (long long)g.nhalf * g.nj;
+template <int NW, int ORDER = 0, int MAF = 0>
+bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, double* res_dev, int accumulate, size_t lds_cap,
+                const MafArgs& ma = MafArgs()) {
+  const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj
+                                      : (long long)(std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1);
   const unsigned nblk = (unsigned)((ncol + NW - 1) / NW);
   const size_t lds = (size_t)NW * 6 * (g.n + 2) * sizeof(REAL) + 64 + 16 * sizeof(double);
   if (lds > lds_cap) return false;
   ensure_partials(nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW, ORDER, MAF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   ScopedTimer tm(LBL_PCR);
-  hipLaunchKernelGGL((pcr_rb_k<NW>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.partials, res_dev, accumulate,
-                     ctx.counter);
+  hipLaunchKernelGGL((pcr_rb_k<NW, ORDER, MAF>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.partials, res_dev,
+                     accumulate, ctx.counter, ma);
   HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -234,6 +236,33 @@ void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, cons
   if (try_pcr_rb<1>(x, msk, rhs, g, omg, res_dev, accumulate, 160 * 1024)) return;
   fprintf(stderr, "czhip: pcr_rb: a k-line of %d unknowns does not fit the 160 KiB of LDS\n", g.n);
   exit(1);
+}
+
+// the MAF line solvers (pcr_rb_maf, pcr_maf and their _eda / _esa forms): literal kernel, order 0 = colour `sel`, 1 = lexicographic
+void launch_pcr_maf(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int order, int sel, REAL omg,
+                    double* res_dev, int accumulate, const MafArgs& ma) {
+  if (b.empty) {
+    if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
+    return;
+  }
+  bool ok = true;
+  auto one = [&](const PcrGeom& g, int acc) {
+    if (order == 0) {
+      return try_pcr_rb<4, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, ma) || try_pcr_rb<2, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, ma) ||
+             try_pcr_rb<1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma);
+    }
+    return try_pcr_rb<1, 1, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma);
+  };
+  if (order == 1) {
+    const int ni = b.ii1 - b.ii0 + 1, nj = b.jj1 - b.jj0 + 1;
+    for (int dgn = 0; dgn <= ni + nj - 2 && ok; dgn++) ok = one(make_pcr_geom(b, idx, pn, dgn), accumulate || dgn > 0);
+  } else {
+    ok = one(make_pcr_geom(b, idx, pn, sel), accumulate);
+  }
+  if (!ok) {
+    fprintf(stderr, "czhip: pcr_*_maf: a k-line of %d unknowns does not fit the 160 KiB of LDS\n", b.kk1 - b.kk0 + 1);
+    exit(1);
+  }
 }
 
 // one lexicographic SOR sweep (psor / psor_maf): a launch per tile hyperplane, then the fixed-order sum of the tile partials

@@ -41,6 +41,8 @@ void pcr_rb_async(CZ_REAL* x, const CZ_REAL* msk, const CZ_REAL* rhs, const int*
                   CZ_REAL omg, double* res_dev, int accumulate);
 void pcr_variant_async(CZ_REAL* x, CZ_REAL* wout, const CZ_REAL* msk, const CZ_REAL* rhs, const int* sz, const int* idx, int g, int pn,
                        int order, int sel, int final4, CZ_REAL omg, double* res_dev, int accumulate);
+void pcr_maf_async(CZ_REAL* x, const CZ_REAL* msk, const CZ_REAL* rhs, const int* sz, const int* idx, int g, int pn, int order, int sel,
+                   const CZ_REAL* xc, const CZ_REAL* yc, const CZ_REAL* zc, CZ_REAL omg, double* res_dev, int accumulate);
 void imask_async(CZ_REAL* x, const int* sz, const int* idx, int g);
 void jacobi_maf_async(const CZ_REAL* p_in, CZ_REAL* p_out, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* xc,
                       const CZ_REAL* yc, const CZ_REAL* zc, CZ_REAL omg, double* res_dev, const int* skip, int check, double res_normal,

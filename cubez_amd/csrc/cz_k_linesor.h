@@ -17,10 +17,13 @@ struct PcrGeom {
   int nhalf;                    // columns of one colour per j row (upper bound)
 };
 
-template <int NW>
+// ORDER 0: one colour; ORDER 1: the columns of one diagonal (i-ist)+(j-jst) = g.color of the lexicographic order (see pcr_rb2_k).
+// MAF = 1: the matrix comes from the metrics of the 1-D grids (cz_maf.f90:442-1560: pcr_rb_maf, pcr_maf and their _eda/_esa
+// forms): it differs from line to line, so this literal form is the only one that applies.
+template <int NW, int ORDER, int MAF>
 __global__ void __launch_bounds__(64 * NW)
 pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, double* partials,
-         double* dst, int accumulate, unsigned* counter) {
+         double* dst, int accumulate, unsigned* counter, MafArgs ma) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
@@ -29,18 +32,27 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
   double* wsum = reinterpret_cast<double*>(reinterpret_cast<REAL*>(smem) + (size_t)NW * 6 * LD + 4);
   wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
 
-  const long long col = (long long)blockIdx.x * NW + wave;  // column ordinal among the colour's columns
-  const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
-  bool active = jrow < g.nj;
+  const long long col = (long long)blockIdx.x * NW + wave;  // column ordinal among the launch's columns
+  bool active;
   int ii = 0, jj = 0;
-  if (active) {
-    const int j1 = g.jst1 + jrow;
-    int i1 = g.ist1 + 2 * ih;
-    if (((i1 + j1) & 1) != g.color) i1 += 1;   // first i of this colour in the row
-    active = (i1 - g.ist1) < g.ni;
-    ii = g.ii0 + (i1 - g.ist1);
-    jj = g.jj0 + jrow;
+  if (ORDER == 0) {
+    const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+    active = jrow < g.nj;
+    if (active) {
+      const int j1 = g.jst1 + jrow;
+      int i1 = g.ist1 + 2 * ih;
+      if (((i1 + j1) & 1) != g.color) i1 += 1;   // first i of this colour in the row
+      active = (i1 - g.ist1) < g.ni;
+      ii = g.ii0 + (i1 - g.ist1);
+      jj = g.jj0 + jrow;
+    }
+  } else {
+    const int dlo = max(0, g.color - (g.nj - 1));
+    active = col < (long long)(min(g.ni - 1, g.color) - dlo + 1);
+    const int io = dlo + (int)col;
+    ii = g.ii0 + io, jj = g.jj0 + (g.color - io);
   }
+  if (!active) ii = g.ii0, jj = g.jj0;
   const REAL r = (REAL)1.0 / (REAL)6.0;
   const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
   const size_t c0 = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;  // element (kst, i, j)
@@ -55,14 +67,39 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
       for (int b = 0; b < 2; b++)
         for (int v = 0; v < 3; v++) A[b][v * LD] = (REAL)0, A[b][v * LD + n + 1] = (REAL)0;
     }
-    for (int k = lane; k < n; k += 64) {
-      const size_t e = c0 + k;
-      a[k + 1] = (k == 0) ? (REAL)0 : -r;
-      c[k + 1] = (k == n - 1) ? (REAL)0 : -r;
-      REAL dv = ((X[e - plane] + X[e + plane] + X[e - rowlen] + X[e + rowlen] - RHS[e]) * r) * MSK[e];
-      if (k == 0) dv = (dv + X[e - 1] * r) * MSK[e];
-      if (k == n - 1) dv = (dv + X[e + 1] * r) * MSK[e];
-      d[k + 1] = dv;
+    if (MAF) {  // cz_maf.f90:489-546 (padded index == index into xc / yc / zc for g = 2, see MafArgs)
+      const REAL GX = (REAL)2.0 / (ma.xc[ii + 1] - ma.xc[ii - 1]);
+      const REAL EY = (REAL)2.0 / (ma.yc[jj + 1] - ma.yc[jj - 1]);
+      const REAL C1 = GX * GX, C2 = EY * EY;
+      const REAL C7 = -(ma.xc[ii + 1] - (REAL)2.0 * ma.xc[ii] + ma.xc[ii - 1]) * C1 * GX;
+      const REAL C8 = -(ma.yc[jj + 1] - (REAL)2.0 * ma.yc[jj] + ma.yc[jj - 1]) * C2 * EY;
+      const REAL dd1 = C1 + (REAL)0.5 * C7, dd2 = C1 - (REAL)0.5 * C7, cc1 = C2 + (REAL)0.5 * C8, cc2 = C2 - (REAL)0.5 * C8;
+      for (int k = lane; k < n; k += 64) {
+        const size_t e = c0 + k;
+        const int kk = g.kk0 + k;
+        const REAL f1 = ma.zc[kk + 1], f2 = ma.zc[kk - 1];
+        const REAL TZ = (REAL)2.0 / (f1 - f2);
+        const REAL ZTT = f1 - (REAL)2.0 * ma.zc[kk] + f2;
+        const REAL f3 = TZ * TZ;
+        const REAL aw = f3, cw = -ZTT * f3 * TZ, dw = (REAL)0.5 / (C1 + C2 + f3);
+        a[k + 1] = (k == 0 && n > 1) ? (REAL)0 : -(aw - (REAL)0.5 * cw) * dw;  // (n = 1: :527 overwrites :513)
+        c[k + 1] = (k == n - 1) ? (REAL)0 : -(aw + (REAL)0.5 * cw) * dw;
+        const REAL mk = MSK[e];
+        REAL dv = (dd1 * X[e + rowlen] + dd2 * X[e - rowlen] + cc1 * X[e + plane] + cc2 * X[e - plane] - RHS[e]) * dw * mk;
+        if (k == 0) dv = (dv + (aw - (REAL)0.5 * cw) * dw * X[e - 1]) * mk;
+        if (k == n - 1) dv = (dv + (aw + (REAL)0.5 * cw) * dw * X[e + 1]) * mk;
+        d[k + 1] = dv;
+      }
+    } else {
+      for (int k = lane; k < n; k += 64) {
+        const size_t e = c0 + k;
+        a[k + 1] = (k == 0) ? (REAL)0 : -r;
+        c[k + 1] = (k == n - 1) ? (REAL)0 : -r;
+        REAL dv = ((X[e - plane] + X[e + plane] + X[e - rowlen] + X[e + rowlen] - RHS[e]) * r) * MSK[e];
+        if (k == 0) dv = (dv + X[e - 1] * r) * MSK[e];
+        if (k == n - 1) dv = (dv + X[e + 1] * r) * MSK[e];
+        d[k + 1] = dv;
+      }
     }
   }
   __syncthreads();

@@ -660,6 +660,67 @@ double pcr_flop(const int* idx, int stages, double fin) {
 }
 }  // namespace
 
+namespace {
+// cz_maf.f90:470-483 etc.
+double pcr_maf_flop(const int* idx, int pn, double fin) {
+  const double nk = idx[5] - idx[4] + 1;
+  return (double)((idx[3] - idx[2] + 1) * (idx[1] - idx[0] + 1)) *
+         ((24.0 + 3.0 * 2.0 + 12.0) + nk * (11.0 + 10.0) + (nk - 2.0) * 6.0 + nk * (double)(pn - 1) * 16.0 + (double)(1 << (pn - 1)) * fin + nk * 6.0);
+}
+void pcr_maf_dropin(int* sz, int* idx, int g, int pn, int order, int color, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY,
+                    CZ_REAL* ZZ, CZ_REAL omg, double* res) {
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty) return;
+  if (bx.g != 2) {
+    fprintf(stderr, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2))\n");
+    exit(1);
+  }
+  const MafArgs ma = upload_xyz(sz, g, XX, YY, ZZ, nullptr);
+  launch_pcr_maf(x, msk, rhs, bx, idx, pn, order, color, omg, ctx.scal_dev + 0, 0, ma);
+  *res += read_scalar(0);
+}
+}  // namespace
+
+// ---- the MAF line solvers, drop-in symbols (cz_Ffunc.h:211-315 <- cz_maf.f90:442-1560).  XX, YY, ZZ are host arrays like in
+// jacobi_maf_; the one-dimensional work arrays and tmp are ignored.
+void pcr_rb_maf_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY,
+                 CZ_REAL* ZZ, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp,
+                 double* flop) {
+  ensure_init();
+  (void)ofst, (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += pcr_maf_flop(idx, *pn, 11.0) * 0.5;
+  pcr_maf_dropin(sz, idx, *g, *pn, 0, *color, x, msk, rhs, XX, YY, ZZ, *omg, res);
+}
+void pcr_rb_esa_maf_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX,
+                     CZ_REAL* YY, CZ_REAL* ZZ, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res,
+                     CZ_REAL* tmp, double* flop) {
+  ensure_init();
+  (void)ofst, (void)s, (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += pcr_maf_flop(idx, *pn, 11.0) * 0.5;
+  pcr_maf_dropin(sz, idx, *g, *pn, 0, *color, x, msk, rhs, XX, YY, ZZ, *omg, res);
+}
+void pcr_maf_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY, CZ_REAL* ZZ, CZ_REAL* a,
+              CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp, double* flop) {
+  ensure_init();
+  (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += pcr_maf_flop(idx, *pn, 11.0);
+  pcr_maf_dropin(sz, idx, *g, *pn, 1, 0, x, msk, rhs, XX, YY, ZZ, *omg, res);
+}
+void pcr_eda_maf_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY, CZ_REAL* ZZ, CZ_REAL* aw,
+                  CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp, double* flop) {
+  ensure_init();
+  (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += pcr_maf_flop(idx, *pn, 9.0);
+  pcr_maf_dropin(sz, idx, *g, *pn, 1, 0, x, msk, rhs, XX, YY, ZZ, *omg, res);
+}
+void pcr_esa_maf_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY, CZ_REAL* ZZ,
+                  CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp, double* flop) {
+  ensure_init();
+  (void)s, (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += pcr_maf_flop(idx, *pn, 9.0);
+  pcr_maf_dropin(sz, idx, *g, *pn, 1, 0, x, msk, rhs, XX, YY, ZZ, *omg, res);
+}
+
 void pcr_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1,
           CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop) {
   ensure_init();
@@ -797,6 +858,13 @@ void pcr_variant_async(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, co
                        int sel, int final4, REAL omg, double* res_dev, int accumulate) {
   ensure_init();
   launch_pcr_variant(x, wout, msk, rhs, make_box(sz, idx, g), idx, pn, order, sel, final4, omg, res_dev, accumulate);
+}
+// MAF line solvers: order 0 = colour `sel` in place, 1 = lexicographic in place; xc, yc, zc device arrays
+void pcr_maf_async(REAL* x, const REAL* msk, const REAL* rhs, const int* sz, const int* idx, int g, int pn, int order, int sel,
+                   const REAL* xc, const REAL* yc, const REAL* zc, REAL omg, double* res_dev, int accumulate) {
+  ensure_init();
+  MafArgs ma{xc, yc, zc, nullptr};
+  launch_pcr_maf(x, msk, rhs, make_box(sz, idx, g), idx, pn, order, sel, omg, res_dev, accumulate, ma);
 }
 void imask_async(REAL* x, const int* sz, const int* idx, int g) { launch_imask(x, make_box(sz, idx, g)); }
 // MAF flavour, device-resident coordinates (xc|yc|zc and pvt are device pointers)

@@ -121,6 +121,21 @@ void pcr_rb_esa_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, int*
 /* cz_Ffunc.h:148-166 <- cz_solver.f90:1473-1676 */
 void pcr_j_esa_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d,
                 CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* src, CZ_REAL* wrk, CZ_REAL* omg, double* res, double* flop);
+/* The MAF line solvers (cz_Ffunc.h:211-315 <- cz_maf.f90:442-1560): the tridiagonal coefficients come from the metrics of the 1-D
+ * grids XX, YY, ZZ (host arrays as in jacobi_maf_), pn-1 PCR stages + 2x2 systems; one colour (pcr_rb_maf_, pcr_rb_esa_maf_) or
+ * lexicographic order (pcr_maf_, pcr_eda_maf_, pcr_esa_maf_; computed diagonal by diagonal).  Work arrays and tmp are ignored. */
+void pcr_rb_maf_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY,
+                 CZ_REAL* ZZ, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp,
+                 double* flop);
+void pcr_rb_esa_maf_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX,
+                     CZ_REAL* YY, CZ_REAL* ZZ, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res,
+                     CZ_REAL* tmp, double* flop);
+void pcr_maf_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY, CZ_REAL* ZZ, CZ_REAL* a,
+              CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp, double* flop);
+void pcr_eda_maf_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY, CZ_REAL* ZZ, CZ_REAL* aw,
+                  CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp, double* flop);
+void pcr_esa_maf_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* XX, CZ_REAL* YY, CZ_REAL* ZZ,
+                  CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* aw, CZ_REAL* cw, CZ_REAL* dw, CZ_REAL* omg, double* res, CZ_REAL* tmp, double* flop);
 /* cz_Ffunc.h:440-443 <- cz_blas.f90:24-104 */
 void imask_k_(CZ_REAL* x, int* sz, int* idx, int* g);
 

@@ -617,6 +617,154 @@ void oracle_pcr_j_esa(const int* sz, const int* idx, const int* gp, const int* p
   pcr_sweep(sz, idx, gp, *pn, 2, 0, 0, x, msk, rhs, wrk, *omg, res, NULL);
 }
 
+/* ---- the line-SOR kernels of the MAF flavour, cz_maf.f90:442-1560.  The five routines share one column solver: the
+ * tridiagonal coefficients come from the metrics of the 1-D grids (they differ from line to line through C1(i) + C2(j)),
+ * pn-1 PCR stages, 2x2 systems, relaxation; entries beyond a line are +0.0 (clamped index in pcr_rb_maf / pcr_maf, zero
+ * pads in the _eda / _esa forms).  Columns: one colour (pcr_rb_maf, pcr_rb_esa_maf) or lexicographic (pcr_maf, pcr_eda_maf,
+ * pcr_esa_maf), in place.  (tmp is the per-k partial-sum array of the reference's _SVR build, unused otherwise.) */
+static void pcr_maf_column(REAL* x, const REAL* msk, const REAL* rhs, const REAL* XX, const REAL* YY, const REAL* ZZ, int i, int j, int kst,
+                           size_t c0, size_t rowlen, size_t plane, int n, int pn, REAL omg, REAL* W, int P, REAL* res1, double* resw) {
+  const int LD = n + 2 * P;
+  REAL *a = W + P, *c = a + LD, *d = c + LD, *aw = d + LD, *cw = aw + LD, *dw = cw + LD; /* element k = 0..n-1 <-> kst+k */
+  for (int k = -P; k < n + P; k++) a[k] = c[k] = d[k] = aw[k] = cw[k] = dw[k] = (REAL)0.0;
+#define XG(ii) XX[(ii) + 1] /* X(-1:sz+2) */
+  const REAL GX = (REAL)2.0 / (XG(i + 1) - XG(i - 1));
+  const REAL EY = (REAL)2.0 / (YY[j + 1 + 1] - YY[j - 1 + 1]);
+  const REAL C1 = GX * GX, C2 = EY * EY;
+  const REAL C7 = -(XG(i + 1) - (REAL)2.0 * XG(i) + XG(i - 1)) * C1 * GX;
+  const REAL C8 = -(YY[j + 1 + 1] - (REAL)2.0 * YY[j + 1] + YY[j - 1 + 1]) * C2 * EY;
+  const REAL dd1 = C1 + (REAL)0.5 * C7, dd2 = C1 - (REAL)0.5 * C7, cc1 = C2 + (REAL)0.5 * C8, cc2 = C2 - (REAL)0.5 * C8;
+#undef XG
+  for (int k = 0; k < n; k++) { /* :501-510 */
+    const int kz = kst + k;
+    const REAL f1 = ZZ[kz + 1 + 1], f2 = ZZ[kz - 1 + 1];
+    const REAL TZ = (REAL)2.0 / (f1 - f2);
+    const REAL ZTT = f1 - (REAL)2.0 * ZZ[kz + 1] + f2;
+    const REAL f3 = TZ * TZ;
+    aw[k] = f3;
+    cw[k] = -ZTT * f3 * TZ;
+    dw[k] = (REAL)0.5 / (C1 + C2 + f3);
+  }
+  a[0] = (REAL)0.0; /* :513-527 */
+  c[0] = -(aw[0] + (REAL)0.5 * cw[0]) * dw[0];
+  for (int k = 1; k < n - 1; k++) {
+    const REAL f1 = aw[k], f2 = cw[k], aa3 = dw[k];
+    a[k] = -(f1 - (REAL)0.5 * f2) * aa3;
+    c[k] = -(f1 + (REAL)0.5 * f2) * aa3;
+  }
+  a[n - 1] = -(aw[n - 1] - (REAL)0.5 * cw[n - 1]) * dw[n - 1];
+  c[n - 1] = (REAL)0.0;
+  for (int k = 0; k < n; k++) { /* :530-538 */
+    const size_t e = c0 + (size_t)k;
+    d[k] = (dd1 * x[e + rowlen] + dd2 * x[e - rowlen] + cc1 * x[e + plane] + cc2 * x[e - plane] - rhs[e]) * dw[k] * msk[e];
+  }
+  d[0] = (d[0] + (aw[0] - (REAL)0.5 * cw[0]) * dw[0] * x[c0 - 1]) * msk[c0]; /* :545-546 */
+  d[n - 1] = (d[n - 1] + (aw[n - 1] + (REAL)0.5 * cw[n - 1]) * dw[n - 1] * x[c0 + (size_t)n]) * msk[c0 + (size_t)n - 1];
+  for (int p = 1; p <= pn - 1; p++) { /* :551-574 */
+    const int s = 1 << (p - 1);
+    for (int k = 0; k < n; k++) {
+      const REAL ap = a[k], cp = c[k];
+      const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * c[k - s] - cp * a[k + s]);
+      aw[k] = -e * ap * a[k - s];
+      cw[k] = -e * cp * c[k + s];
+      dw[k] = e * (d[k] - ap * d[k - s] - cp * d[k + s]);
+    }
+    for (int k = 0; k < n; k++) a[k] = aw[k], c[k] = cw[k], d[k] = dw[k];
+  }
+  {
+    const int s = 1 << (pn - 1); /* :578-596 */
+    for (int k = 0; k < s; k++) {
+      const REAL c1_ = c[k], aa2 = a[k + s], f1 = d[k], f2 = d[k + s];
+      const REAL jj = (REAL)1.0 / ((REAL)1.0 - aa2 * c1_);
+      dw[k] = (f1 - c1_ * f2) * jj;
+      dw[k + s] = (f2 - aa2 * f1) * jj;
+    }
+  }
+  for (int k = 0; k < n; k++) { /* :626-637 */
+    const size_t e = c0 + (size_t)k;
+    const REAL pp = x[e];
+    const REAL dp = (dw[k] - pp) * omg * msk[e];
+    x[e] = pp + dp;
+    const REAL d2 = dp * dp;
+    *res1 = *res1 + d2;
+    *resw += (double)d2;
+  }
+}
+
+/* order 0: lexicographic, 1: one colour */
+static void pcr_maf_sweep(const int* sz, const int* idx, const int* gp, int pn, int order, int color, REAL* x, const REAL* msk, const REAL* rhs,
+                          const REAL* XX, const REAL* YY, const REAL* ZZ, REAL omg, double* res, double* res_wide) {
+  UNPACK_SZ;
+  UNPACK_IDX;
+  const int n = ked - kst + 1, P = 1 << (pn > 1 ? pn : 1);
+  REAL* W = (REAL*)malloc((size_t)6 * (n + 2 * P) * sizeof(REAL));
+  REAL res1 = (REAL)0.0;
+  double resw = 0.0;
+  for (int j = jst; j <= jed; j++)
+    for (int i = ist; i <= ied; i++) {
+      if (order == 1 && (i + j) % 2 != color) continue;
+      pcr_maf_column(x, msk, rhs, XX, YY, ZZ, i, j, kst, IDX(kst, i, j), nk, nk * ni, n, pn, omg, W, P, &res1, &resw);
+    }
+  free(W);
+  *res = *res + (double)res1;
+  if (res_wide) *res_wide += resw;
+}
+
+#define PCR_MAF_FLOP(fin) \
+  ((double)((jed - jst + 1) * (ied - ist + 1)) * ((24.0 + 3.0 * 2.0 + 12.0) + (ked - kst + 1) * (11.0 + 10.0) + (ked - kst - 1) * 6.0 + \
+                                                   (ked - kst + 1) * (double)(*pn - 1) * 16.0 + (double)(1 << (*pn - 1)) * (fin) + (ked - kst + 1) * 6.0))
+
+void oracle_pcr_maf_sweep_w(const int* sz, const int* idx, const int* gp, const int* pn, const int* order, const int* color, REAL* x,
+                            const REAL* msk, const REAL* rhs, const REAL* XX, const REAL* YY, const REAL* ZZ, const REAL* omg, double* res,
+                            double* res_wide) {
+  pcr_maf_sweep(sz, idx, gp, *pn, *order, *color, x, msk, rhs, XX, YY, ZZ, *omg, res, res_wide);
+}
+
+/* pcr_rb_maf : cz_maf.f90:442-668 */
+void oracle_pcr_rb_maf(const int* sz, const int* idx, const int* gp, const int* pn, const int* ofst, const int* color, REAL* x, const REAL* msk,
+                       const REAL* rhs, const REAL* XX, const REAL* YY, const REAL* ZZ, REAL* a, REAL* c, REAL* d, REAL* aw, REAL* cw, REAL* dw,
+                       const REAL* omg, double* res, REAL* tmp, double* flop) {
+  UNPACK_IDX;
+  (void)ofst, (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += PCR_MAF_FLOP(11.0) * 0.5;
+  pcr_maf_sweep(sz, idx, gp, *pn, 1, *color, x, msk, rhs, XX, YY, ZZ, *omg, res, NULL);
+}
+/* pcr_rb_esa_maf : cz_maf.f90:1339-1560 */
+void oracle_pcr_rb_esa_maf(const int* sz, const int* idx, const int* gp, const int* pn, const int* ofst, const int* color, const int* s, REAL* x,
+                           const REAL* msk, const REAL* rhs, const REAL* XX, const REAL* YY, const REAL* ZZ, REAL* a, REAL* c, REAL* d, REAL* aw,
+                           REAL* cw, REAL* dw, const REAL* omg, double* res, REAL* tmp, double* flop) {
+  UNPACK_IDX;
+  (void)ofst, (void)s, (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += PCR_MAF_FLOP(11.0) * 0.5;
+  pcr_maf_sweep(sz, idx, gp, *pn, 1, *color, x, msk, rhs, XX, YY, ZZ, *omg, res, NULL);
+}
+/* pcr_maf : cz_maf.f90:672-892 */
+void oracle_pcr_maf(const int* sz, const int* idx, const int* gp, const int* pn, REAL* x, const REAL* msk, const REAL* rhs, const REAL* XX,
+                    const REAL* YY, const REAL* ZZ, REAL* a, REAL* c, REAL* d, REAL* aw, REAL* cw, REAL* dw, const REAL* omg, double* res,
+                    REAL* tmp, double* flop) {
+  UNPACK_IDX;
+  (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += PCR_MAF_FLOP(11.0);
+  pcr_maf_sweep(sz, idx, gp, *pn, 0, 0, x, msk, rhs, XX, YY, ZZ, *omg, res, NULL);
+}
+/* pcr_eda_maf : cz_maf.f90:896-1113 */
+void oracle_pcr_eda_maf(const int* sz, const int* idx, const int* gp, const int* pn, REAL* x, const REAL* msk, const REAL* rhs, const REAL* XX,
+                        const REAL* YY, const REAL* ZZ, REAL* aw, REAL* cw, REAL* dw, const REAL* omg, double* res, REAL* tmp, double* flop) {
+  UNPACK_IDX;
+  (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += PCR_MAF_FLOP(9.0);
+  pcr_maf_sweep(sz, idx, gp, *pn, 0, 0, x, msk, rhs, XX, YY, ZZ, *omg, res, NULL);
+}
+/* pcr_esa_maf : cz_maf.f90:1117-1335 */
+void oracle_pcr_esa_maf(const int* sz, const int* idx, const int* gp, const int* pn, const int* s, REAL* x, const REAL* msk, const REAL* rhs,
+                        const REAL* XX, const REAL* YY, const REAL* ZZ, REAL* a, REAL* c, REAL* d, REAL* aw, REAL* cw, REAL* dw, const REAL* omg,
+                        double* res, REAL* tmp, double* flop) {
+  UNPACK_IDX;
+  (void)s, (void)a, (void)c, (void)d, (void)aw, (void)cw, (void)dw, (void)tmp;
+  *flop += PCR_MAF_FLOP(9.0);
+  pcr_maf_sweep(sz, idx, gp, *pn, 0, 0, x, msk, rhs, XX, YY, ZZ, *omg, res, NULL);
+}
+
 /* ---- psor : cz_solver.f90:207-269.  Lexicographic in-place SOR (j outer, i, k inner): every update sees the new values of
  * its k-1, i-1, j-1 neighbours and the old ones of k+1, i+1, j+1.  SERIAL semantics: the reference's PARALLEL DO makes the
  * result depend on the thread count; this is what one thread computes. */

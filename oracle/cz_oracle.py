@@ -327,6 +327,28 @@ class Kernels:
                                     wide.ctypes.data_as(_c_dbl_p))
         return r.value
 
+    def pcr_maf(self, name, sz, idx, pn, color, x, msk, rhs, xc, yc, zc, omg, res=0.0, wide=None):
+        """the MAF line-SOR kernels, cz_maf.f90:442-1560; name in pcr_rb_maf, pcr_rb_esa_maf, pcr_maf, pcr_eda_maf, pcr_esa_maf"""
+        sz, idx, g, pnc = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn)
+        if wide is not None:
+            assert self.kind == "oracle"
+            order = C.c_int(1 if "_rb" in name else 0)
+            col, r = C.c_int(color), C.c_double(res)
+            self.lib.oracle_pcr_maf_sweep_w(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), C.byref(order), C.byref(col), self._rp(x),
+                                            self._rp(msk), self._rp(rhs), self._rp(xc), self._rp(yc), self._rp(zc), self._rs(omg), C.byref(r),
+                                            wide.ctypes.data_as(_c_dbl_p))
+            return r.value
+        w1, w = self._pcr_work(sz, pn)
+        tmp = np.zeros(int(sz[2]) + 4, dtype=self.real)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        o, c, ss = C.c_int(0), C.c_int(color), C.c_int((1 << pn) >> 2)
+        pre = {"pcr_rb_maf": [o, c], "pcr_rb_esa_maf": [o, c, ss], "pcr_maf": [], "pcr_eda_maf": [], "pcr_esa_maf": [ss]}[name]
+        work = [self._rp(v) for v in w1] if name == "pcr_eda_maf" else [self._rp(v) for v in w] + [self._rp(v) for v in w1]
+        self._f(name)(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), *[C.byref(v) for v in pre], self._rp(x), self._rp(msk),
+                      self._rp(rhs), self._rp(xc), self._rp(yc), self._rp(zc), *work, self._rs(omg), C.byref(r), self._rp(tmp), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
     def fileout_t(self, sz, s, dh, org, fname):
         """cz_utility.f90:17-47 (reference build with -D_aurora_=1 only): writes the .sph file `fname` (<= 20 characters)."""
         assert self.kind == "ref_sph" and len(fname) <= 20
@@ -567,6 +589,29 @@ class CZ:
             itr += 1
         return itr, res
 
+    # cz_Poisson.cpp: the MAF branches of LSOR_PCR_RB (:549-557), LSOR_PCR_RB_ESA (:665-683), LSOR_PCR (:770-776), LSOR_PCR_EDA, LSOR_PCR_ESA
+    def LSOR_PCR_MAF(self, X, B, itr_max, name, converge_check=True):
+        k, res, itr = self.k, 0.0, 1
+        pn = get_num_stage(self.idx[5] - self.idx[4] + 1)
+        if not hasattr(self, "MSK"):
+            self.MSK = k.alloc(self.size)
+            k.imask_k(self.MSK, self.size, self.idx)
+        while itr <= itr_max:
+            res = 0.0
+            w = np.zeros(1) if self.wide else None
+            for color in ((0, 1) if "_rb" in name else (0,)):
+                res = k.pcr_maf(name, self.size, self.idx, pn, color, X, self.MSK, B, self.xc, self.yc, self.zc, self.ac1, res=res, wide=w)
+            if self.wide:
+                res = float(w[0])
+            if converge_check:
+                res = math.sqrt(res * self.res_normal)
+                self.history.append((itr, res))
+                k.bc_k(self.size, X, self.pitch, self.origin, self.nID)
+                if res < self.eps:
+                    break
+            itr += 1
+        return itr, res
+
     def Preconditioner(self, xx, bb, pc):
         if pc in ("jacobi", "jacobi_maf"):
             self.JACOBI(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
@@ -576,6 +621,8 @@ class CZ:
             self.PSOR(xx, bb, LC_MAX, converge_check=False, maf=pc.endswith("_maf"))
         elif pc == "pcr_rb":
             self.LSOR_PCR_RB(xx, bb, LC_MAX, converge_check=False)
+        elif pc in ("pcr_rb_maf", "pcr_rb_esa_maf", "pcr_maf", "pcr_eda_maf"):
+            self.LSOR_PCR_MAF(xx, bb, LC_MAX, pc, converge_check=False)
         elif pc in ("pcr", "pcr_rb_esa"):  # cz_Poisson.cpp:300-316, cz_Evaluate.cpp:585-592
             self.LSOR_PCR_VARIANT(xx, bb, LC_MAX, pc, converge_check=False)
         # "pcr_j_esa" is accepted by cz_Evaluate.cpp:588-590 but CZ::Preconditioner has no case for it: it copies
@@ -671,6 +718,8 @@ def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", wit
         itr, res = cz.PSOR(cz.P, cz.RHS, itr_max, maf=solver.endswith("_maf"))
     elif solver == "pcr_rb":
         itr, res = cz.LSOR_PCR_RB(cz.P, cz.RHS, itr_max)
+    elif solver in ("pcr_rb_maf", "pcr_rb_esa_maf", "pcr_maf", "pcr_eda_maf", "pcr_esa_maf"):
+        itr, res = cz.LSOR_PCR_MAF(cz.P, cz.RHS, itr_max, solver)
     elif solver in ("pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa"):
         itr, res = cz.LSOR_PCR_VARIANT(cz.P, cz.RHS, itr_max, solver)
     elif solver in ("pbicgstab", "pbicgstab_maf"):

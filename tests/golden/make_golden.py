@@ -218,6 +218,13 @@ SOLVER_CASES = [
     ((32, 32, 32), "pcr_j_esa", 30, 0.9, None, "f64", None),
     ((32, 32, 32), "pbicgstab", 100, 1.2, "pcr_rb_esa", "f64", None),
     ((32, 32, 32), "pbicgstab", 100, 1.2, "pcr", "f64", None),
+    # MAF line solvers (cz_maf.f90:442-1560), serial reference build
+    ((32, 32, 32), "pcr_rb_maf", 30, 1.2, None, "f32", None),
+    ((32, 32, 32), "pcr_rb_esa_maf", 20, 1.2, None, "f64", None),
+    ((32, 32, 32), "pcr_maf", 20, 1.2, None, "f32", None),
+    ((32, 32, 32), "pcr_eda_maf", 20, 1.2, None, "f64", None),
+    ((32, 32, 32), "pcr_esa_maf", 20, 1.2, None, "f32", None),
+    ((32, 32, 32), "pbicgstab_maf", 100, 1.2, "pcr_rb_maf", "f64", None),
 ]
 
 

@@ -609,3 +609,35 @@ def test_empty_index_ranges_are_no_ops(prec):
     assert h.pcr(sz, idx, 4, dx, dm, db, 1.1, res=0.25) == 0.25
     assert h.psor2sma_core(dx, sz, idx, cf, 0, 1, 1.1, db, res=0.125) == 0.125
     assert dx.get().tobytes() == x0.tobytes()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", [(9, 8, 32), (12, 9, 40), (7, 11, 128), (6, 5, 5), (5, 4, 512)], ids=lambda b: "x".join(map(str, b)))
+def test_pcr_maf_variants_random_boxes_vs_oracle(prec, box):
+    """the five MAF line solvers (cz_maf.f90:442-1560) on stretched grids == the oracle (pinned against the serial reference build)"""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    xc, yc, zc = (np.cumsum(rng.uniform(0.5, 1.5, n + 4)).astype(R) for n in (ni, nj, nk))
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    for name in ("pcr_rb_maf", "pcr_rb_esa_maf", "pcr_maf", "pcr_eda_maf", "pcr_esa_maf"):
+        x1, dx = x0.copy(), h.alloc(sz, x0)
+        for it in range(2):
+            r1 = r2 = 0.0
+            w = np.zeros(1)
+            for color in ((0, 1) if "_rb" in name else (0,)):
+                x1w = x1.copy()
+                ko.pcr_maf(name, sz, idx, pn, color, x1w, msk, rhs, xc, yc, zc, 1.3, wide=w)
+                r1 = ko.pcr_maf(name, sz, idx, pn, color, x1, msk, rhs, xc, yc, zc, 1.3, res=r1)
+                r2 = h.pcr_maf(name, sz, idx, pn, color, dx, dm, dr, xc, yc, zc, 1.3, res=r2)
+                assert _beq(x1w, x1)
+            assert _beq(dx.get(), x1), (name, it)
+            assert _rel(r2, float(w[0])) < 1e-11, (name, r2, w)
+            assert h.last_flop == ko.last_flop, name
