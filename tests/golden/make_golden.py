@@ -241,7 +241,9 @@ def solver_cases():
                      errmax=r.errmax, errloc=list(r.errloc), cli=list(cli) if cli else None)
         if cli:
             assert r.itr == cli[0] and ("%e" % r.res) == cli[1], (tag, r.itr, "%e" % r.res, cli)
-        if max(gsz) <= 32:
+        # the whole field of a few cases (every case carries sha256(P), which pins all of them bit for bit)
+        if max(gsz) <= 28 or tag in ("jacobi_32x32x32_f32", "sor2sma_32x32x32_f64", "pbicgstab_jacobi_32x32x32_f64", "pcr_rb_32x32x32_f32",
+                                     "psor_32x32x32_f32", "jacobi_maf_32x32x32_f32"):
             np.save(os.path.join(HERE, f"field_{tag}.npy"), r.P)
             entry["field"] = f"field_{tag}.npy"
         index.append(entry)
