@@ -47,6 +47,7 @@ const char* printMethod(int t) {
     case LS_PCR_RB: return "PCR_RB";
     case LS_PCR: return "PCR";
     case LS_PCR_ESA: return "PCR_ESA";
+    case LS_PCR_EDA: return "PCR_EDA";
     case LS_PCR_RB_ESA: return "PCR_RB_ESA";
     case LS_PCR_J_ESA: return "PCR_J_ESA";
     case LS_PSOR_MAF: return "PSOR_MAF";
@@ -130,6 +131,7 @@ void CZ::setStrPre() {
   else if (!strcasecmp(precon.c_str(), "pcr_rb_esa")) pc_type = LS_PCR_RB_ESA;  // :585-587
   else if (!strcasecmp(precon.c_str(), "pcr_j_esa")) pc_type = LS_PCR_J_ESA;    // :588-590 (CZ::Preconditioner has no case for it: acts as none)
   else if (!strcasecmp(precon.c_str(), "pcr")) pc_type = LS_PCR;                // :591-593
+  else if (!strcasecmp(precon.c_str(), "pcr_eda")) pc_type = LS_PCR_EDA;        // :594-596
   else if (!strcasecmp(precon.c_str(), "psor")) pc_type = LS_PSOR;
   else if (!strcasecmp(precon.c_str(), "psor_maf")) pc_type = LS_PSOR_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "pcr_rb_maf")) pc_type = LS_PCR_RB_MAF, SW_maf = 1;          // :606-617
@@ -138,7 +140,7 @@ void CZ::setStrPre() {
   else if (!strcasecmp(precon.c_str(), "pcr_eda_maf")) pc_type = LS_PCR_EDA_MAF, SW_maf = 1;
   else if (!strcasecmp(precon.c_str(), "none")) pc_type = LS_NONE;
   else {
-    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | psor | sor2sma | pcr | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf | pcr_maf | pcr_eda_maf | pcr_rb_maf | pcr_rb_esa_maf)\n", precon.c_str());
+    Hostonly_ printf("Invalid preconditioner '%s' (this build: none | jacobi | psor | sor2sma | pcr | pcr_eda | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf | pcr_maf | pcr_eda_maf | pcr_rb_maf | pcr_rb_esa_maf)\n", precon.c_str());
     exit(0);
   }
 }
@@ -178,6 +180,9 @@ void CZ::setLS(const char* q) {
   } else if (!strcasecmp(q, "pcr")) {  // :724-727
     ls_type = LS_PCR;
     hist_name = "pcr.txt";
+  } else if (!strcasecmp(q, "pcr_eda")) {  // :729-732
+    ls_type = LS_PCR_EDA;
+    hist_name = "pcr_eda.txt";
   } else if (!strcasecmp(q, "pcr_esa")) {  // :734-737
     ls_type = LS_PCR_ESA;
     hist_name = "pcr_esa.txt";
@@ -325,13 +330,13 @@ int CZ::Setup(int argc, char** argv) {
     return 0;
   }
   auto is_line = [](int t) {
-    return t == LS_PCR || t == LS_PCR_ESA || t == LS_PCR_RB || t == LS_PCR_RB_ESA || t == LS_PCR_J_ESA || (t >= LS_PCR_MAF && t <= LS_PCR_RB_ESA_MAF);
+    return (t >= LS_PCR && t <= LS_PCR_J_ESA) || (t >= LS_PCR_MAF && t <= LS_PCR_RB_ESA_MAF);
   };
   if (is_line(ls_type) || is_line(pc_type)) {
     // A k-line is solved by one wave: bricks must hold whole lines (no cut along k).  The colour and Jacobi orders exchange
     // ghost columns after each colour / iteration and reproduce the single-domain run; the lexicographic orders (pcr, pcr_esa)
     // are one wavefront through the grid and stay single-domain.
-    auto is_lex = [](int t) { return t == LS_PCR || t == LS_PCR_ESA || t == LS_PCR_MAF || t == LS_PCR_EDA_MAF || t == LS_PCR_ESA_MAF; };
+    auto is_lex = [](int t) { return t == LS_PCR || t == LS_PCR_EDA || t == LS_PCR_ESA || t == LS_PCR_MAF || t == LS_PCR_EDA_MAF || t == LS_PCR_ESA_MAF; };
     if (numProc > 1 && (G_div[2] > 1 || is_lex(ls_type) || is_lex(pc_type))) {
       Hostonly_ printf("line SOR (pcr*) : decomposed runs need whole k-lines (gdv_z = 1) and the colour or Jacobi order\n");
       return 0;
@@ -395,6 +400,7 @@ int CZ::Solve() {
       if (0 == (itr = PSOR(res, P, RHS, ItrMax, flop, ls_type))) return 0;
       break;
     case LS_PCR:
+    case LS_PCR_EDA:
     case LS_PCR_ESA:
     case LS_PCR_RB_ESA:
     case LS_PCR_J_ESA:
@@ -476,14 +482,14 @@ int CZ::Evaluate(int argc, char** argv) {
 // (sweep, residual reduction, convergence bookkeeping) but eps disabled so that nothing is skipped.
 int CZ::Sweeps(int n) {
   if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA && ls_type != LS_JACOBI_MAF && ls_type != LS_SOR2SMA_MAF &&
-                  ls_type != LS_PCR_RB && ls_type != LS_PSOR && ls_type != LS_PSOR_MAF && ls_type != LS_PCR && ls_type != LS_PCR_ESA &&
+                  ls_type != LS_PCR_RB && ls_type != LS_PSOR && ls_type != LS_PSOR_MAF && ls_type != LS_PCR && ls_type != LS_PCR_EDA && ls_type != LS_PCR_ESA &&
                   ls_type != LS_PCR_RB_ESA && ls_type != LS_PCR_J_ESA))
     return 0;
   const double keep = eps;
   eps = -1.0;
   double res = 0.0, flop = 0.0;
   history.clear();
-  if (ls_type == LS_PCR || ls_type == LS_PCR_ESA || ls_type == LS_PCR_RB_ESA || ls_type == LS_PCR_J_ESA)
+  if (ls_type == LS_PCR || ls_type == LS_PCR_EDA || ls_type == LS_PCR_ESA || ls_type == LS_PCR_RB_ESA || ls_type == LS_PCR_J_ESA)
     LSOR_PCR_VARIANT(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_PSOR || ls_type == LS_PSOR_MAF) PSOR(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_PCR_RB) LSOR_PCR_RB(res, P, RHS, n, flop, ls_type);
@@ -885,7 +891,7 @@ int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_
     printf("error : number of stage\n");
     exit(0);
   }
-  const int final4 = (s_type == LS_PCR_J_ESA) ? 0 : 1;
+  const int final4 = (s_type == LS_PCR_J_ESA || s_type == LS_PCR_EDA) ? 0 : 1;
   const int order = (s_type == LS_PCR_RB_ESA) ? 0 : (s_type == LS_PCR_J_ESA) ? 2 : 1;
   const int stages = final4 ? pn - 2 : pn - 1;
   const double fin = final4 ? (double)(1 << (pn - 2)) * (s_type == LS_PCR ? 74.0 : 78.0) : (double)(1 << (pn - 1)) * 9.0;
@@ -1079,6 +1085,7 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
       PSOR(res, xx, bb, lc_max, flop, s_type, false);
       break;
     case LS_PCR:
+    case LS_PCR_EDA:
     case LS_PCR_RB_ESA:  // (LS_PCR_J_ESA has no case in the reference either, cz_Poisson.cpp:282-321: it falls to the copy)
       LSOR_PCR_VARIANT(res, xx, bb, lc_max, flop, s_type, false);
       break;

@@ -732,6 +732,17 @@ void pcr_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL*
   *res += read_scalar(0);
 }
 
+void pcr_eda_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg,
+              double* res, double* flop) {
+  ensure_init();
+  (void)a1, (void)c1, (void)d1;
+  *flop += pcr_flop(idx, *pn - 1, (double)(1 << (*pn - 1)) * 9.0);  // :908-915
+  const Box bx = make_box(sz, idx, *g);
+  if (bx.empty) return;
+  launch_pcr_variant(x, nullptr, msk, rhs, bx, idx, *pn, 1, 0, 0, *omg, ctx.scal_dev + 0, 0);
+  *res += read_scalar(0);
+}
+
 void pcr_esa_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d,
               CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop) {
   ensure_init();

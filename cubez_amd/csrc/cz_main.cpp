@@ -30,8 +30,8 @@ int main(int argc, char* argv[]) {
   if (argc != 7 && argc != 8 && argc != 10 && argc != 11) {  // main.cpp:19-31
     if (myRank == 0) {
       printf("\tUsage : ./cz gsz_x, gsz_y, gsz_z, linear_solver, IterationMax, acc_coef [precond] [gdv_x, gdv_y, gdv_z]\n");
-      printf("\t\tlinear_solver = {jacobi | psor | sor2sma | pbicgstab | pcr | pcr_esa | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf | pbicgstab_maf | pcr_maf | pcr_eda_maf | pcr_esa_maf | pcr_rb_maf | pcr_rb_esa_maf}\n");
-      printf("\t\tprecond = {none | jacobi | psor | sor2sma | pcr | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf | pcr_maf | pcr_eda_maf | pcr_rb_maf | pcr_rb_esa_maf}\n\n");
+      printf("\t\tlinear_solver = {jacobi | psor | sor2sma | pbicgstab | pcr | pcr_eda | pcr_esa | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf | pbicgstab_maf | pcr_maf | pcr_eda_maf | pcr_esa_maf | pcr_rb_maf | pcr_rb_esa_maf}\n");
+      printf("\t\tprecond = {none | jacobi | psor | sor2sma | pcr | pcr_eda | pcr_rb | pcr_rb_esa | pcr_j_esa | jacobi_maf | psor_maf | sor2sma_maf | pcr_maf | pcr_eda_maf | pcr_rb_maf | pcr_rb_esa_maf}\n\n");
       printf("\t$ ./cz 64 64 64 jacobi 4000 0.8 2 2 1\n");
       printf("\t$ ./cz 64 64 64 sor2sma 4000 1.5\n");
       printf("\t$ ./cz 64 64 64 pbicgstab 4000 1.1 sor2sma\n");

@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
     "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
     "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async", "czhip_jacobi_checked_async",
-    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_set_pcr_mode", "czhip_use_t2", "czhip_rbsor2_async", "czhip_jacobi2_from_zero_async", "czhip_check2_async", "czhip_pair_split_async", "psor_", "psor_maf_", "pcr_", "pcr_esa_", "pcr_rb_esa_", "pcr_j_esa_", "pcr_rb_maf_", "pcr_rb_esa_maf_", "pcr_maf_", "pcr_eda_maf_", "pcr_esa_maf_",
+    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_set_pcr_mode", "czhip_use_t2", "czhip_rbsor2_async", "czhip_jacobi2_from_zero_async", "czhip_check2_async", "czhip_pair_split_async", "psor_", "psor_maf_", "pcr_", "pcr_eda_", "pcr_esa_", "pcr_rb_esa_", "pcr_j_esa_", "pcr_rb_maf_", "pcr_rb_esa_maf_", "pcr_maf_", "pcr_eda_maf_", "pcr_esa_maf_",
     "cz_create", "cz_destroy", "cz_evaluate", "cz_setup", "cz_solve", "cz_sweeps", "cz_result_iter", "cz_result_res",
     "cz_history", "cz_field", "cz_local_size", "cz_error_max", "cz_set_quiet", "cz_last_solve_seconds", "cz_kernel_ms",
     "cz_set_debug", "cz_set_profile", "czhip_timing", "czhip_timing_read",
@@ -272,6 +272,15 @@ class CzHip:
 
     def pcr(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
         return self._pcr_call(self.lib.pcr_, sz, idx, pn, [], x, msk, rhs, [], omg, res)
+
+    def pcr_eda(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
+        (_, szp), (_, idxp), g = self._i(sz), self._i(idx), C.c_int(GUIDE)
+        w = [np.zeros(sz[2] + 4, dtype=self.real) for _ in range(3)]
+        r, fl, pnc = C.c_double(res), C.c_double(0.0), C.c_int(pn)
+        self.lib.pcr_eda_(szp, idxp, C.byref(g), C.byref(pnc), C.c_void_p(x.ptr), C.c_void_p(msk.ptr), C.c_void_p(rhs.ptr),
+                          *[v.ctypes.data_as(C.c_void_p) for v in w], self._s(omg), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
 
     def pcr_esa(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
         return self._pcr_call(self.lib.pcr_esa_, sz, idx, pn, [(1 << pn) >> 2], x, msk, rhs, [], omg, res)

@@ -112,6 +112,10 @@ void pcr_rb_(int* sz, int* idx, int* g, int* pn, int* ofst, int* color, CZ_REAL*
 /* cz_Ffunc.h:99-114 <- cz_solver.f90:666-878 */
 void pcr_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d, CZ_REAL* a1,
           CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop);
+/* cz_Ffunc.h:116-128 <- cz_solver.f90:883-1045 (lexicographic, pn-1 stages + 2x2 systems; its un-refreshed a(kst), c(ked) are +-0.0: fresh
+ * zeros here, see oracle/cz_oracle.c) */
+void pcr_eda_(int* sz, int* idx, int* g, int* pn, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg,
+              double* res, double* flop);
 /* cz_Ffunc.h:130-146 <- cz_solver.f90:1050-1257 */
 void pcr_esa_(int* sz, int* idx, int* g, int* pn, int* s, CZ_REAL* x, CZ_REAL* msk, CZ_REAL* rhs, CZ_REAL* a, CZ_REAL* c, CZ_REAL* d,
               CZ_REAL* a1, CZ_REAL* c1, CZ_REAL* d1, CZ_REAL* omg, double* res, double* flop);

@@ -588,6 +588,18 @@ void oracle_pcr(const int* sz, const int* idx, const int* gp, const int* pn, REA
   pcr_sweep(sz, idx, gp, *pn, 0, 0, 1, x, msk, rhs, NULL, *omg, res, NULL);
 }
 
+/* pcr_eda : cz_solver.f90:883-1045.  Lexicographic order, pn-1 stages + 2x2 systems, arrays extended by zeros.  The routine does
+ * not refresh a(kst) and c(ked) (:932,:936 are commented out): they keep the previous column's last-stage values, which are
+ * always +-0.0 -- the result can only differ from this restatement (fresh +0.0) in the sign of a zero when d(kst) or d(ked)
+ * is exactly -0.0.  It also indexes past its allocation unless n >= 3/4 * 2^pn (:985-995); zeros are read here. */
+void oracle_pcr_eda(const int* sz, const int* idx, const int* gp, const int* pn, REAL* x, const REAL* msk, const REAL* rhs, REAL* a1, REAL* c1,
+                    REAL* d1, const REAL* omg, double* res, double* flop) {
+  UNPACK_IDX;
+  (void)a1, (void)c1, (void)d1;
+  *flop += PCR_FLOP(*pn - 1, (double)(1 << (*pn - 1)) * 9.0); /* :908-915 */
+  pcr_sweep(sz, idx, gp, *pn, 0, 0, 0, x, msk, rhs, NULL, *omg, res, NULL);
+}
+
 /* pcr_esa : cz_solver.f90:1050-1257 */
 void oracle_pcr_esa(const int* sz, const int* idx, const int* gp, const int* pn, const int* s, REAL* x, const REAL* msk, const REAL* rhs,
                     REAL* a, REAL* c, REAL* d, REAL* a1, REAL* c1, REAL* d1, const REAL* omg, double* res, double* flop) {

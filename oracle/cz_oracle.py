@@ -282,6 +282,16 @@ class Kernels:
         self.last_flop = fl.value
         return r.value
 
+    def pcr_eda(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
+        """cz_solver.f90:883-1045 (allocates its own extended arrays; defined for n >= 3/4 * 2^pn)"""
+        sz, idx, g, pnc = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn)
+        w1, _ = self._pcr_work(sz, pn)
+        r, fl = C.c_double(res), C.c_double(0.0)
+        self._f("pcr_eda")(self._ip(sz), self._ip(idx), C.byref(g), C.byref(pnc), self._rp(x), self._rp(msk), self._rp(rhs),
+                           *[self._rp(v) for v in w1], self._rs(omg), C.byref(r), C.byref(fl))
+        self.last_flop = fl.value
+        return r.value
+
     def pcr_esa(self, sz, idx, pn, x, msk, rhs, omg, res=0.0):
         """cz_solver.f90:1050-1257"""
         sz, idx, g, pnc, ss = _ia(sz), _ia(idx), C.c_int(GUIDE), C.c_int(pn), C.c_int((1 << pn) >> 2)
@@ -318,7 +328,7 @@ class Kernels:
     def pcr_sweep_wide(self, name, sz, idx, pn, color, x, msk, rhs, wrk, omg, wide, res=0.0):
         """one sweep of a line-SOR variant with sum dp^2 also accumulated in double (oracle only)"""
         assert self.kind == "oracle"
-        order, final4 = {"pcr": (0, 1), "pcr_esa": (0, 1), "pcr_rb_esa": (1, 1), "pcr_j_esa": (2, 0), "pcr_rb_2x2": (1, 0)}[name]
+        order, final4 = {"pcr": (0, 1), "pcr_esa": (0, 1), "pcr_eda": (0, 0), "pcr_rb_esa": (1, 1), "pcr_j_esa": (2, 0), "pcr_rb_2x2": (1, 0)}[name]
         sz, idx, g = _ia(sz), _ia(idx), C.c_int(GUIDE)
         ints = [C.c_int(v) for v in (pn, order, color, final4)]
         r = C.c_double(res)
@@ -571,6 +581,8 @@ class CZ:
                 res = k.pcr(self.size, self.idx, pn, X, self.MSK, B, self.ac1)
             elif name == "pcr_esa":
                 res = k.pcr_esa(self.size, self.idx, pn, X, self.MSK, B, self.ac1)
+            elif name == "pcr_eda":
+                res = k.pcr_eda(self.size, self.idx, pn, X, self.MSK, B, self.ac1)
             elif name == "pcr_rb_esa":
                 for color in (0, 1):
                     res = k.pcr_rb_esa(self.size, self.idx, pn, 0, color, X, self.MSK, B, self.ac1, res=res)
@@ -623,7 +635,7 @@ class CZ:
             self.LSOR_PCR_RB(xx, bb, LC_MAX, converge_check=False)
         elif pc in ("pcr_rb_maf", "pcr_rb_esa_maf", "pcr_maf", "pcr_eda_maf"):
             self.LSOR_PCR_MAF(xx, bb, LC_MAX, pc, converge_check=False)
-        elif pc in ("pcr", "pcr_rb_esa"):  # cz_Poisson.cpp:300-316, cz_Evaluate.cpp:585-592
+        elif pc in ("pcr", "pcr_rb_esa", "pcr_eda"):  # cz_Poisson.cpp:300-316, cz_Evaluate.cpp:585-592
             self.LSOR_PCR_VARIANT(xx, bb, LC_MAX, pc, converge_check=False)
         # "pcr_j_esa" is accepted by cz_Evaluate.cpp:588-590 but CZ::Preconditioner has no case for it: it copies
         else:
@@ -720,7 +732,7 @@ def run(gsz, solver, itr_max, coef, precond=None, kind="oracle", prec="f32", wit
         itr, res = cz.LSOR_PCR_RB(cz.P, cz.RHS, itr_max)
     elif solver in ("pcr_rb_maf", "pcr_rb_esa_maf", "pcr_maf", "pcr_eda_maf", "pcr_esa_maf"):
         itr, res = cz.LSOR_PCR_MAF(cz.P, cz.RHS, itr_max, solver)
-    elif solver in ("pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa"):
+    elif solver in ("pcr", "pcr_esa", "pcr_eda", "pcr_rb_esa", "pcr_j_esa"):
         itr, res = cz.LSOR_PCR_VARIANT(cz.P, cz.RHS, itr_max, solver)
     elif solver in ("pbicgstab", "pbicgstab_maf"):
         itr, res = cz.PBiCGSTAB(cz.P, cz.RHS, itr_max, precond or "none", maf=solver.endswith("_maf"))

@@ -212,6 +212,7 @@ SOLVER_CASES = [
     ((32, 32, 32), "pbicgstab", 100, 1.2, "pcr_rb", "f64", None),
     ((32, 32, 32), "pcr", 30, 1.2, None, "f32", None),
     ((32, 32, 32), "pcr_esa", 30, 1.2, None, "f64", None),
+    ((32, 32, 32), "pcr_eda", 30, 1.2, None, "f32", None),
     ((32, 32, 32), "pcr_rb_esa", 30, 1.2, None, "f32", None),
     ((64, 64, 64), "pcr_rb_esa", 100000, 1.5, None, "f64", None),
     ((32, 32, 32), "pcr_j_esa", 30, 0.9, None, "f32", None),

@@ -26,7 +26,7 @@ def test_usage_on_wrong_argc(tmp_path):
 
 
 def test_invalid_solver_exits_like_the_reference(tmp_path):
-    r = _run("f32", [32, 32, 32, "pcr_eda", 10, 1.0], tmp_path)   # not restated (indexes past its arrays); same message as for unknown names
+    r = _run("f32", [32, 32, 32, "lsor_simd", 10, 1.0], tmp_path)   # a name the reference CLI does not know either
     assert r.returncode == 0 and "Invalid solver" in r.stdout
 
 

@@ -536,10 +536,12 @@ def test_pcr_variants_random_boxes_vs_oracle(prec, box):
     ko.imask_k(msk, sz, idx)
     pn = O.get_num_stage(idx[5] - idx[4] + 1)
     dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
-    for name in ("pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa"):
+    for name in ("pcr", "pcr_esa", "pcr_eda", "pcr_rb_esa", "pcr_j_esa"):
         x1, dx = x0.copy(), h.alloc(sz, x0)
         for it in range(2):
-            if name == "pcr":
+            if name == "pcr_eda":
+                r1, r2 = ko.pcr_eda(sz, idx, pn, x1, msk, rhs, 1.3), h.pcr_eda(sz, idx, pn, dx, dm, dr, 1.3)
+            elif name == "pcr":
                 r1, r2 = ko.pcr(sz, idx, pn, x1, msk, rhs, 1.3), h.pcr(sz, idx, pn, dx, dm, dr, 1.3)
             elif name == "pcr_esa":
                 r1, r2 = ko.pcr_esa(sz, idx, pn, x1, msk, rhs, 1.3), h.pcr_esa(sz, idx, pn, dx, dm, dr, 1.3)

@@ -37,7 +37,7 @@ def _run_gpu(c):
     return out
 
 
-STATIONARY = [c for c in CASES if c["solver"] in ("jacobi", "sor2sma", "jacobi_maf", "sor2sma_maf", "pcr_rb", "psor", "psor_maf", "pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa", "pcr_rb_maf", "pcr_rb_esa_maf", "pcr_maf", "pcr_eda_maf", "pcr_esa_maf")]
+STATIONARY = [c for c in CASES if c["solver"] in ("jacobi", "sor2sma", "jacobi_maf", "sor2sma_maf", "pcr_rb", "psor", "psor_maf", "pcr", "pcr_esa", "pcr_eda", "pcr_rb_esa", "pcr_j_esa", "pcr_rb_maf", "pcr_rb_esa_maf", "pcr_maf", "pcr_eda_maf", "pcr_esa_maf")]
 
 
 @pytest.mark.parametrize("case", STATIONARY, ids=[c["tag"] for c in STATIONARY])
