@@ -29,7 +29,8 @@ ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--n", type=int, default=512, help="cells per GPU and axis")
-ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor", "pcr", "pcr_esa", "pcr_rb_esa", "pcr_j_esa"])
+ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor", "pcr", "pcr_eda", "pcr_esa", "pcr_rb_esa", "pcr_j_esa", "jacobi_maf",
+                                                     "sor2sma_maf", "psor_maf", "pcr_rb_maf", "pcr_maf"])
 ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "sor2sma"])
 ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
 ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -57,7 +58,7 @@ if world not in DIVS:
 div = DIVS[world]
 n = args.n
 gsz = [n * div[0], n * div[1], n * div[2]]
-coef = 0.9 if args.solver == "pcr_j_esa" else 1.2 if args.solver in ("pcr_rb", "psor", "pcr", "pcr_esa", "pcr_rb_esa") else 1.5 if (args.solver == "sor2sma" or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
+coef = 0.9 if args.solver == "pcr_j_esa" else 1.2 if (args.solver.startswith("pcr") or args.solver.startswith("psor")) else 1.5 if (args.solver.startswith("sor2sma") or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
 
 if torch.cuda.is_available():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -113,9 +114,9 @@ else:
     cz.sweeps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-_jl = args.solver == "jacobi" or (args.solver == "pbicgstab" and args.precond == "jacobi")
+_jl = args.solver in ("jacobi", "jacobi_maf") or (args.solver == "pbicgstab" and args.precond == "jacobi")
 _line = args.solver.startswith("pcr")
-nk, kern_ms = cz.timing_read("jacobi" if _jl else "pcr_rb" if _line else "psor" if args.solver == "psor" else "rbsor")
+nk, kern_ms = cz.timing_read("jacobi" if _jl else "pcr_rb" if _line else "psor" if args.solver.startswith("psor") else "rbsor")
 nk2, kern2_ms = cz.timing_read("jacobi2" if _jl else "rbsor2")  # fused: 2 sweeps / both colours per launch
 cz.timing(False)
 
@@ -132,17 +133,17 @@ if rank == 0:
     word = 4 if args.prec == "f32" else 8
     # algorithmic bytes per lattice update: Jacobi reads p and b once, writes p' once = 3 words;
     # one RB-SOR colour launch updates half the points of the box: 4 words per point and iteration = 2 per launch
-    jac_like = args.solver == "jacobi" or (bicg and args.precond == "jacobi")
+    jac_like = args.solver in ("jacobi", "jacobi_maf") or (bicg and args.precond == "jacobi")
     alg_bytes_per_launch = my_points * word * (3 if jac_like else 2)
     kernel_name = "stencil_k<jacobi>" if jac_like else "stencil_k<rbsor colour>"
     tkey = f"{'jacobi' if jac_like else 'sor2sma'}_{n}_{args.prec}"
     if _line:
         # one iteration: every line reads x, rhs, msk and writes x (4 words), and is read once more as i/j neighbour (1 word);
         # pcr_rb / pcr_rb_esa: two colour launches per iteration, pcr / pcr_esa: one launch per (i+j) diagonal, pcr_j_esa: one
-        per_iter = {"pcr_rb": 2, "pcr_rb_esa": 2, "pcr_j_esa": 1}.get(args.solver, nk // max(args.steps, 1))
+        per_iter = {"pcr_rb": 2, "pcr_rb_esa": 2, "pcr_rb_maf": 2, "pcr_j_esa": 1}.get(args.solver, nk // max(args.steps, 1))
         alg_bytes_per_launch = my_points * word * 5 // max(per_iter, 1)
         kernel_name, tkey = f"pcr_rb2_k ({per_iter} launches of k-line solves per iteration)", f"{args.solver}_{n}_{args.prec}"
-    if args.solver == "psor":
+    if args.solver.startswith("psor"):
         # one sweep (all tile-hyperplane launches together): p read and written in place, b read: 3 words per point
         alg_bytes_per_launch = my_points * word * 3
         kernel_name, tkey = "psor_tile_k (one lexicographic sweep = 3N/16-2 tile-hyperplane launches)", f"psor_{n}_{args.prec}"

@@ -483,7 +483,7 @@ int CZ::Evaluate(int argc, char** argv) {
 int CZ::Sweeps(int n) {
   if (!set_up || (ls_type != LS_JACOBI && ls_type != LS_SOR2SMA && ls_type != LS_JACOBI_MAF && ls_type != LS_SOR2SMA_MAF &&
                   ls_type != LS_PCR_RB && ls_type != LS_PSOR && ls_type != LS_PSOR_MAF && ls_type != LS_PCR && ls_type != LS_PCR_EDA && ls_type != LS_PCR_ESA &&
-                  ls_type != LS_PCR_RB_ESA && ls_type != LS_PCR_J_ESA))
+                  ls_type != LS_PCR_RB_ESA && ls_type != LS_PCR_J_ESA && !(ls_type >= LS_PCR_MAF && ls_type <= LS_PCR_RB_ESA_MAF)))
     return 0;
   const double keep = eps;
   eps = -1.0;
@@ -491,6 +491,7 @@ int CZ::Sweeps(int n) {
   history.clear();
   if (ls_type == LS_PCR || ls_type == LS_PCR_EDA || ls_type == LS_PCR_ESA || ls_type == LS_PCR_RB_ESA || ls_type == LS_PCR_J_ESA)
     LSOR_PCR_VARIANT(res, P, RHS, n, flop, ls_type);
+  else if (ls_type >= LS_PCR_MAF && ls_type <= LS_PCR_RB_ESA_MAF) LSOR_PCR_MAF(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_PSOR || ls_type == LS_PSOR_MAF) PSOR(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_PCR_RB) LSOR_PCR_RB(res, P, RHS, n, flop, ls_type);
   else if (ls_type == LS_JACOBI || ls_type == LS_JACOBI_MAF) JACOBI(res, P, RHS, n, flop, ls_type);
