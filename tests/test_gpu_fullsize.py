@@ -170,3 +170,28 @@ def test_line_sor_512_three_kernel_forms_agree():
             cz.close()
     assert outs[0][0] == outs[1][0] == outs[2][0]
     assert np.allclose(outs[0][1], outs[2][1], rtol=1e-12, atol=0) and np.allclose(outs[1][1], outs[2][1], rtol=1e-12, atol=0)
+
+
+def test_arrays_beyond_2_to_31_elements():
+    """maximum sizes: 1300^3 cells = 2.2e9 elements (8.9 GB) per FP32 array -- every linear index needs 64 bits.  The fused-pair path and
+    the single-sweep path agree bit for bit, the Dirichlet data sit where the 64-bit index says."""
+    from cubez_amd import CZ
+    n = 1300
+    assert (n + 4) ** 3 > 2 ** 31
+    out = []
+    for t2 in (1, 0):
+        cz = CZ("f32", quiet=True)
+        cz.lib.czhip_set_tuning2(0, 0, -1, t2)
+        try:
+            assert cz.setup([n, n, n, "jacobi", 4, 0.8]) == 1
+            itr = cz.solve()
+            P = cz.field()
+            out.append((itr, cz.history(), hashlib.sha256(P.tobytes()).hexdigest(), float(P[n // 2 + 2, n // 2 + 2, 2])))
+            del P
+        finally:
+            cz.lib.czhip_set_tuning2(0, 0, -1, 1)
+            cz.close()
+    assert out[0][0] == out[1][0] == 5 and out[0][2] == out[1][2]
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-12, atol=0)
+    x = (n // 2) / (n - 1)
+    assert abs(out[0][3] - np.sin(np.pi * x) ** 2) < 1e-5
