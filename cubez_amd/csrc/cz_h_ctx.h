@@ -13,6 +13,7 @@ struct Tuning {
 #else
   int t2_threads = 512, t2_mv = 2, t2_tj = 16;   // best at 512^3 FP32
 #endif  // two-sweep kernel: threads, vectors/thread, planes/chunk
+  int t2_band = 1;                                // two-sweep kernel: XCD band mapping of workgroups (CZHIP_T2_BAND)
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
 

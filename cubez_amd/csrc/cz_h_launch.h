@@ -124,8 +124,14 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   if (tj > nplanes) tj = nplanes;
   g.TJ = tj;
   int nchunk = (nplanes + tj - 1) / tj;
-  if (((long long)nchunk * g.nseg) % 8 != 0 && nchunk >= 8) nchunk = ((nchunk + 7) / 8) * 8;
-  const long long nblk = (long long)nchunk * g.nseg;
+  long long nblk;
+  g.band = (ctx.tune.t2_band && g.nseg >= 8) ? 1 : 0;
+  if (g.band) {
+    nblk = 8LL * ((g.nseg + 7) / 8) * nchunk;
+  } else {
+    if (((long long)nchunk * g.nseg) % 8 != 0 && nchunk >= 8) nchunk = ((nchunk + 7) / 8) * 8;
+    nblk = (long long)nchunk * g.nseg;
+  }
   const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double);
   if (lds > 160 * 1024) return false;
   if (probe) return true;

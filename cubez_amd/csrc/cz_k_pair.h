@@ -30,6 +30,7 @@ struct Geom2 {
   int nseg, TJ, S;  // S = TB*MV - 2R
   int par;          // RB: colour 0 = points with (kk + ii + jj + par) even
   int zero_u;       // the input field is identically zero (a freshly cleared preconditioner vector): u is not read
+  int band;         // workgroup id -> (segment, chunk) by XCD bands (see jacobi2_k)
 };
 
 struct Fin2 {
@@ -90,10 +91,24 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
 
   int lb = blockIdx.x;
   const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) lb = (lb & 7) * (nblk >> 3) + (lb >> 3);
-  const int seg = lb % g.nseg;
-  const int chunk = lb / g.nseg;
-  const long long fb = g.F0 + (long long)seg * g.S;
+  int seg, chunk;
+  if (g.band) {
+    // XCD bands: the hardware deals workgroup ids round-robin over the 8 XCDs; XCD x owns a contiguous band of segments of EVERY
+    // chunk (row-adjacent segments meet in one L2) and walks it chunk by chunk -- all XCDs carry the same load whatever the
+    // number of chunks is.  Ids beyond a shorter band are idle.
+    const int x = lb & 7, r = lb >> 3;
+    const int base = g.nseg >> 3, rem = g.nseg & 7, bmax = base + (rem ? 1 : 0);
+    const int blen = base + (x < rem ? 1 : 0);
+    const int sl = r % bmax;
+    chunk = r / bmax;
+    seg = (sl < blen) ? x * base + min(x, rem) + sl : g.nseg;  // nseg = no work
+  } else {
+    if ((nblk & 7) == 0) lb = (lb & 7) * (nblk >> 3) + (lb >> 3);
+    seg = lb % g.nseg;
+    chunk = lb / g.nseg;
+  }
+  lb = blockIdx.x;  // slot of this workgroup's partial sums
+  const long long fb = (seg < g.nseg) ? g.F0 + (long long)seg * g.S : g.Fend;
   const int ja = g.jj0 + chunk * g.TJ;
   int jb = ja + g.TJ - 1;
   if (jb > g.jj1) jb = g.jj1;

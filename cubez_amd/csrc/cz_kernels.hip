@@ -160,6 +160,7 @@ int czhip_init(int device) {
     const int n = sscanf(t2, "%d,%d,%d,%d", &en, &a, &b2, &c2);
     if (n >= 1) czhip_set_tuning2(n >= 2 ? a : 0, n >= 3 ? b2 : 0, n >= 4 ? c2 : -1, en);
   }
+  if (const char* bd = getenv("CZHIP_T2_BAND")) ctx.tune.t2_band = atoi(bd);
   if (const char* pc = getenv("CZHIP_PCR")) {  // "fast[,variant]"
     int f = 1, v = 0;
     sscanf(pc, "%d,%d", &f, &v);
