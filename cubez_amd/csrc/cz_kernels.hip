@@ -185,6 +185,13 @@ void czhip_finalize(void) {
   if (ctx.pcr_tab_perm) (void)hipFree(ctx.pcr_tab_perm);
   (void)hipFree(ctx.scal_dev);
   (void)hipHostFree(ctx.scal_host);
+  if (ctx.counter) (void)hipFree(ctx.counter);
+  if (ctx.xyz) (void)hipFree(ctx.xyz);
+  for (auto* list : {&ctx.ev_used, &ctx.ev_free})
+    for (auto& e : *list) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
   (void)hipStreamDestroy(ctx.stream);
   ctx = Ctx();
 }
