@@ -534,7 +534,11 @@ void CZ::plan_overlap() {
   n_shell = pair_plan(innerFidx, nID, shell_boxes, interior, interior1);
   if (n_shell == 0) return;
   if (!comm_stream) {
-    HIP_CHECK(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+    // highest priority: pack / send-recv / unpack must get workgroup slots while the interior sweep (thousands of queued
+    // workgroups on the compute stream) keeps the GPU full, or the overlap would turn into a tail
+    int prio_least = 0, prio_greatest = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIP_CHECK(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, prio_greatest));
     HIP_CHECK(hipEventCreateWithFlags(&ev_shell, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
   }
