@@ -118,6 +118,7 @@ _jl = args.solver in ("jacobi", "jacobi_maf") or (args.solver == "pbicgstab" and
 _line = args.solver.startswith("pcr")
 nk, kern_ms = cz.timing_read("jacobi" if _jl else "pcr_rb" if _line else "psor" if args.solver.startswith("psor") else "rbsor")
 nk2, kern2_ms = cz.timing_read("jacobi2" if _jl else "rbsor2")  # fused: 2 sweeps / both colours per launch
+cz_shell = cz.timing_read("pair_shell")
 cz.timing(False)
 
 tot_points = float(my_points)
@@ -189,6 +190,16 @@ if rank == 0:
                      "kernel_avg_ms": kern_avg_s * 1e3, "kernel_launches_timed": nk,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
+    if world > 1 and nk2 > 0 and not bicg:
+        # exposed (non-overlapped) communication per step = wall time per step minus the rank-0 kernel time per step
+        # (shell slabs + interior of a fused pass cover two steps); the exchange itself runs on a second stream behind the interior
+        try:
+            n_sh, sh_ms = cz_shell
+            per_step_kernel_ms = (kern2_ms + sh_ms) / nk2 / (2.0 if jac_like else 1.0)
+            out["multi_gpu"] = {"kernel_ms_per_step_rank0": per_step_kernel_ms, "exposed_ms_per_step": dt / args.steps * 1e3 - per_step_kernel_ms,
+                                "per_gpu_algorithmic_GBps": achieved, "overlap": os.environ.get("CZ_OVERLAP", "1") != "0"}
+        except Exception as e:  # reporting only
+            out["multi_gpu"] = {"error": repr(e)}
     if bicg:
         out["config"]["step"] = "one BiCGSTAB iteration: 2 x 8 preconditioner sweeps, 2 SpMV, 5 dots, 4 axpy-type updates (cz_Poisson.cpp:373-500)"
         # 76 words per point and iteration with the Jacobi preconditioner

@@ -54,5 +54,13 @@ while True:
     if dt >= args.seconds or n >= 1000:
         break
 lups = float(N - 2) ** 3 * n
+cpu_model = "unknown CPU"
+try:
+    for line in open("/proc/cpuinfo"):
+        if line.startswith("model name"):
+            cpu_model = line.split(":", 1)[1].strip()
+            break
+except OSError:
+    pass
 print(json.dumps({"value": lups / dt / 1e6, "unit": "MLUPS", "cores": cores, "kind": "reference" if kind == "ref" else "port",
-                  "sample": f"{n} {args.solver} sweeps of the {N}^3 {args.prec} grid in {dt:.1f} s, OMP_NUM_THREADS={cores}"}))
+                  "sample": f"{n} {args.solver} sweeps of the {N}^3 {args.prec} grid in {dt:.1f} s, OMP_NUM_THREADS={cores}, {cpu_model}"}))
