@@ -159,3 +159,17 @@ def test_line_sor_refuses_a_cut_along_k():
         [t.join(timeout=120) for t in th]
         lib.cz_comm_local_world_free(world)
         assert rets == [0, 0], (solver, div, rets)
+
+
+@pytest.mark.parametrize("solver,div", [("jacobi_maf", (2, 1, 1)), ("sor2sma_maf", (1, 2, 2)), ("pcr_rb_maf", (2, 2, 1))])
+def test_decomposed_maf_flavour(solver, div):
+    """The MAF kernels take the metrics from 1-D coordinate arrays that every brick fills from its LOCAL index (cz_Evaluate.cpp:342-363
+    adds no brick origin).  On the uniform grid the metrics are differences of neighbouring coordinates, equal up to rounding on
+    every brick: the decomposed run follows the single-domain run to rounding, not bit for bit."""
+    prec, gsz = "f64", (40, 36, 32)
+    coef = 0.8 if solver.startswith("jacobi") else 1.2
+    itr1, res1, hist1, P1 = _single(prec, gsz, solver, 12, coef)
+    results, G = _decomposed(prec, gsz, solver, 12, coef, div)
+    assert all(r[0] == itr1 for r in results)
+    assert np.allclose(results[0][2], hist1, rtol=1e-9, atol=0)
+    assert np.abs(G[2:-2, 2:-2, 2:-2] - P1[2:-2, 2:-2, 2:-2]).max() < 1e-12
