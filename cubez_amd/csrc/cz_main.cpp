@@ -40,6 +40,7 @@ int main(int argc, char* argv[]) {
     return 0;
   }
 
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // dmabuf IPC between the ranks' processes (RCCL); must be set before HIP starts
   czhip_init(-1);  // LOCAL_RANK selects the GPU
   if (nproc > 1) {
     const int nb = cz_comm_unique_id_bytes();
