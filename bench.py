@@ -33,6 +33,7 @@ ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbi
                                                      "sor2sma_maf", "psor_maf", "pcr_rb_maf", "pcr_maf"])
 ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "sor2sma"])
 ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
+ap.add_argument("--div", default=None, help="Cartesian division of the ranks, e.g. 1,8,1 (default: 1x2x1, 2x2x1, 2x2x2 for 2, 4, 8 GPUs)")
 ap.add_argument("--no-cpu-baseline", action="store_true")
 ap.add_argument("--cpu-seconds", type=float, default=12.0)
 args = ap.parse_args()
@@ -53,9 +54,14 @@ import torch.distributed as dist  # noqa: E402
 from cubez_amd import CZ  # noqa: E402
 
 DIVS = {1: (1, 1, 1), 2: (1, 2, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
-if world not in DIVS:
-    raise SystemExit("supported GPU counts: 1, 2, 4, 8")
-div = DIVS[world]
+if args.div:
+    div = tuple(int(v) for v in args.div.replace("x", ",").split(","))
+    if len(div) != 3 or div[0] * div[1] * div[2] != world:
+        raise SystemExit(f"--div {args.div} does not multiply to {world} ranks")
+elif world in DIVS:
+    div = DIVS[world]
+else:
+    raise SystemExit("supported GPU counts without --div: 1, 2, 4, 8")
 n = args.n
 gsz = [n * div[0], n * div[1], n * div[2]]
 coef = 0.9 if args.solver == "pcr_j_esa" else 1.2 if (args.solver.startswith("pcr") or args.solver.startswith("psor")) else 1.5 if (args.solver.startswith("sor2sma") or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
