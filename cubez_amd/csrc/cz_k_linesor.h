@@ -8,6 +8,13 @@
 // 2^(p-1), then the 2x2 systems of stride 2^(pn-1), then the relaxation -- operation for operation the reference's
 // arithmetic (serial build: entries outside kst..ked are zero, kept in two pad slots).  sum dp^2 is accumulated in double.
 // ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_sync() {
+  // the lanes of ONE wave hand data to each other through LDS: order the accesses, no workgroup barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct PcrGeom {
   int nkp, nip;                 // padded extents
   int kk0, n;                   // padded index of kst, number of unknowns per column
@@ -102,7 +109,7 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
       }
     }
   }
-  __syncthreads();
+  wave_lds_sync();  // a line never leaves its wave: no workgroup barrier between the stages
   // ---- PCR stages (:572-595)
   int cur = 0;
   for (int p = 1; p <= g.pn - 1; p++) {
@@ -125,7 +132,7 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
         d1[x] = e * (d[x] - ap * d[kl] - cp * d[kr]);
       }
     }
-    __syncthreads();
+    wave_lds_sync();
     cur ^= 1;
   }
   // ---- 2x2 systems of the last stage (:599-616), result into the d slot of the other buffer
@@ -147,7 +154,7 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
         if (kr <= n) d1[kr] = dd2;  // (the reference also stores the k = ked+1 dummy, which nothing reads)
       }
     }
-    __syncthreads();
+    wave_lds_sync();
   }
   // ---- relaxation (:626-633)
   if (active) {
@@ -357,13 +364,6 @@ pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin, int final4) {
       F[4 * nfin + k] = aa2, F[5 * nfin + k] = aa3, F[6 * nfin + k] = aa4;
     }
   }
-}
-
-__device__ __forceinline__ void wave_lds_sync() {
-  // the lanes of ONE wave hand data to each other through LDS: order the accesses, no workgroup barrier
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ORDER selects the columns of one launch (the line-SOR variants of cz_solver.f90 differ in the column order):
