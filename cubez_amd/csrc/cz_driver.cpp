@@ -79,11 +79,12 @@ CZ::CZ() {
   HIP_CHECK(hipHostMalloc(&h_flag, 2 * POLL_SLOTS * sizeof(int), hipHostMallocDefault));
   const char* ov = getenv("CZ_OVERLAP");
   if (ov) overlap = atoi(ov);
+  if (const char* lg = getenv("CZ_LAG_REDUCE")) lag_reduce = atoi(lg);
 }
 
 CZ::~CZ() {
   czhip_sync();
-  REAL_TYPE* arrs[] = {WRK, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt, MSK};
+  REAL_TYPE* arrs[] = {WRK, WRK2, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt, MSK};
   if (d_xc) (void)hipFree(d_xc);
   if (d_yc) (void)hipFree(d_yc);
   if (d_zc) (void)hipFree(d_zc);
@@ -97,6 +98,9 @@ CZ::~CZ() {
   if (comm) comm_destroy(comm);
   if (ev_shell) (void)hipEventDestroy(ev_shell);
   if (ev_comm) (void)hipEventDestroy(ev_comm);
+  if (ev_int) (void)hipEventDestroy(ev_int);
+  for (hipEvent_t e : ev_chk)
+    if (e) (void)hipEventDestroy(e);
   if (comm_stream) (void)hipStreamDestroy(comm_stream);
   if (fph) fclose(fph);
 }
@@ -541,6 +545,9 @@ void CZ::plan_overlap() {
     HIP_CHECK(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, prio_greatest));
     HIP_CHECK(hipEventCreateWithFlags(&ev_shell, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_int, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_chk[0], hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_chk[1], hipEventDisableTiming));
   }
 }
 
@@ -550,14 +557,15 @@ void CZ::plan_overlap() {
 //   comm_stream :                 wait ev_shell -> pack, send/recv, unpack -> [ev_comm]
 // The slabs and the interior write disjoint cells of dst and read only src; the unpack writes ghost cells of dst.
 // Returns false (nothing launched) when the split does not apply; the caller then takes the unsplit path.
-bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip) {
+bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot) {
   if (n_shell == 0) return false;
+  double* rs = res_slot ? res_slot : d_res;
   const int gc = GUIDE;
   hipStream_t st = stream();
   if (!pair_probe(src, dst, B, size, interior, interior1, gc)) return false;
   pair_shell_async(src, dst, B, size, idx1, shell_boxes, n_shell, gc, cf, ac1, rb, skip);
   HIP_CHECK(hipEventRecord(ev_shell, st));
-  if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, d_res, 1, skip)) {
+  if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, rs, 1, skip)) {
     printf("error : interior launch refused after a successful probe\n");
     exit(1);
   }
@@ -597,7 +605,8 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
   hipStream_t st = stream();
   // ping-pong partner: same guide cells / Dirichlet faces as X
   copy_shell_async(WRK, X, size, innerFidx, gc);
-  REAL_TYPE* buf[2] = {X, WRK};
+  REAL_TYPE* buf[3] = {X, WRK, nullptr};
+  int nbuf = 2;
   const int* skip = nullptr;
   if (converge_check) {
     ensure_hist(itr_max + 3);
@@ -618,15 +627,39 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     if (!Comm_S2(X) || !Comm_S2(B)) return 0;
     copy_shell_async(WRK, X, size, innerFidx, gc);
   }
+  // Decomposed, checked runs: the residual all-reduce and the convergence test of pass n run on the exchange stream while pass n+1
+  // is being swept (one pass of lag: pass n+2 waits for the test of pass n).  A pass may therefore run beyond convergence once; with
+  // THREE rotating buffers it cannot touch the source or the destination of the converged pass, so the exact-iteration fix-up below
+  // still finds both.
+  const bool lag = can_pair && numProc > 1 && converge_check && n_shell > 0 && lag_reduce != 0;
+  if (lag) {
+    if (!WRK2) WRK2 = czhip_alloc_s3d(size);
+    copy_shell_async(WRK2, X, size, innerFidx, gc);
+    buf[2] = WRK2;
+    nbuf = 3;
+  }
   hipEvent_t ev[POLL_SLOTS];
   int npoll = 0, cur = 0;
   bool stop = false;
   int itr = 1;
   while (itr <= itr_max && !stop) {
     REAL_TYPE* src = buf[cur];
-    REAL_TYPE* dst = buf[cur ^ 1];
+    REAL_TYPE* dst = buf[(cur + 1) % nbuf];
     int done = 0;
-    if (x_is_zero && itr == 1) {
+    if (lag && itr + 1 <= itr_max) {
+      const int p = (int)launches.size();
+      if (p >= 2) HIP_CHECK(hipStreamWaitEvent(st, ev_chk[p & 1], 0));  // the test of pass p-2
+      double* rs = d_res + ((p & 1) ? 10 : 0);
+      if (pair_overlapped(src, dst, B, idx1, -1, skip, rs)) {
+        done = 2;
+        HIP_CHECK(hipEventRecord(ev_int, st));
+        HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
+        if (!comm_allreduce_sum(comm, rs, 2, comm_stream)) return 0;                                            // :67, both sweeps
+        check2_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);                     // :69-77
+        HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
+      }
+    }
+    if (!done && x_is_zero && itr == 1) {
       // start vector identically zero (preconditioner): neither cleared in memory nor read -- if the fused kernel takes it
       if (can_pair && itr + 1 <= itr_max && !converge_check)
         done = 2 * czhip_jacobi2_from_zero_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res);
@@ -637,6 +670,10 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
         const size_t nbytes = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
         HIP_CHECK(hipMemsetAsync(src, 0, nbytes, st));
       }
+    }
+    if (lag && !done) {  // an odd last sweep (or a refused split): the tests still in flight on the exchange stream come first
+      HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
+      HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
     }
     if (!done && can_pair && itr + 1 <= itr_max && numProc > 1 && pair_overlapped(src, dst, B, idx1, -1, skip)) {
       done = 2;  // :58 twice, :63 hidden behind the interior
@@ -679,7 +716,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     flop += (maf ? 66.0 : 18.0) * npts() * done;
     launches.push_back({itr, done, cur});
     itr += done;
-    cur ^= 1;
+    cur = (cur + 1) % nbuf;
     if (converge_check && launches.size() % (POLL_EVERY / 2) == 0 && itr <= itr_max) {
       // lagging, non-blocking view of the flag: look at the copy issued two polls ago
       const int slot = npoll % POLL_SLOTS;
@@ -696,6 +733,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     }
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
+  if (lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
 
   // which buffer holds the iterate of the last executed sweep?
@@ -711,19 +749,20 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       if (last->nsweep == 2 && ret == last->first_itr) {
         // the first sweep of a fused pair converged: the pair wrote time n+2 into its destination; its source is
         // untouched, so one plain sweep reproduces the converged iterate (exactly what the sequential loop holds)
-        czhip_jacobi_async(buf[last->src], buf[last->src ^ 1], B, size, innerFidx, gc, cf, ac1, d_res + 4, 0, nullptr);  // (never MAF: pairs are not formed there)
+        czhip_jacobi_async(buf[last->src], buf[(last->src + 1) % nbuf], B, size, innerFidx, gc, cf, ac1, d_res + 4, 0, nullptr);  // (never MAF: pairs are not formed there)
       }
     }
-    final_buf = last->src ^ 1;
+    final_buf = (last->src + 1) % nbuf;
   }
-  if (final_buf == 1) {
-    // the result is in WRK.  The arrays are ours: swap the roles instead of copying back.
+  if (final_buf != 0) {
+    // the result is in WRK (or WRK2).  The arrays are ours: swap the roles instead of copying back.
     if (X == P) {
       REAL_TYPE* t = P;
-      P = WRK;
-      WRK = t;
+      P = buf[final_buf];
+      if (final_buf == 1) WRK = t;
+      else WRK2 = t;
     } else {
-      copy_inner_async(X, WRK, size, innerFidx, gc);
+      copy_inner_async(X, buf[final_buf], size, innerFidx, gc);
     }
   }
   return ret;

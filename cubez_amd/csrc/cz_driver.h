@@ -66,7 +66,9 @@ class CZ {
   CommCtx* comm = nullptr;
   // decomposed runs: the exchange of a fused pair runs on comm_stream while the interior is being swept
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_shell = nullptr, ev_comm = nullptr;
+  hipEvent_t ev_shell = nullptr, ev_comm = nullptr, ev_int = nullptr, ev_chk[2] = {nullptr, nullptr};
+  int lag_reduce = 1;            // CZ_LAG_REDUCE=0: residual all-reduce + test on the compute stream after every pass (no lag)
+  REAL_TYPE* WRK2 = nullptr;     // third rotation buffer of the lagged mode
   int overlap = 1;               // CZ_OVERLAP=0 turns it off (exchange after the whole sweep, same results)
   int n_shell = 0;               // shell boxes (cells within two layers of a rank-internal face), 1-based index ranges
   int shell_boxes[36];
@@ -119,7 +121,7 @@ class CZ {
   bool Comm_S2(REAL_TYPE* X, const int* skip_flag = nullptr);  // two layers + edges (fused Jacobi pairs)
   bool Comm_SUM_dev(double* d_val, int count, const int* skip_flag = nullptr);
   void plan_overlap();
-  bool pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip);
+  bool pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot = nullptr);
   bool Comm_SUM_1(double* host_val);
 
   int finish_stationary(int itr_max, int first_itr, bool converge_check, double& res);
