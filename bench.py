@@ -203,7 +203,8 @@ if rank == 0:
             n_sh, sh_ms = cz_shell
             per_step_kernel_ms = (kern2_ms + sh_ms) / nk2 / (2.0 if jac_like else 1.0)
             out["multi_gpu"] = {"kernel_ms_per_step_rank0": per_step_kernel_ms, "exposed_ms_per_step": dt / args.steps * 1e3 - per_step_kernel_ms,
-                                "per_gpu_algorithmic_GBps": achieved, "overlap": os.environ.get("CZ_OVERLAP", "1") != "0"}
+                                "per_gpu_algorithmic_GBps": achieved, "overlap": os.environ.get("CZ_OVERLAP", "1") != "0",
+                                "lagged_reduce": os.environ.get("CZ_LAG_REDUCE", "1") != "0" and args.solver == "jacobi"}
         except Exception as e:  # reporting only
             out["multi_gpu"] = {"error": repr(e)}
     if bicg:
