@@ -313,6 +313,14 @@ int CZ::Setup(int argc, char** argv) {
   RHS = czhip_alloc_s3d(size);
   P = czhip_alloc_s3d(size);
   WRK = czhip_alloc_s3d(size);
+  if (numProc > 1) {
+    // The fused pass needs the two-layer exchange, single sweeps the one-layer exchange: all bricks must take the same path.
+    // Bricks of an uneven division can differ (k-extent multiple of the vector width or not): agree on the weakest.
+    int idx1[6];
+    for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
+    const double mine = pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE) ? 0.0 : 1.0;
+    pairs_ok = comm_allreduce_max_host(comm, mine) == 0.0;
+  }
   const bool bicg = ls_type == LS_BICGSTAB || ls_type == LS_BICGSTAB_MAF;
   if (bicg) {
     pcg_p = czhip_alloc_s3d(size), pcg_p_ = czhip_alloc_s3d(size), pcg_r = czhip_alloc_s3d(size);
@@ -619,7 +627,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     int first_itr, nsweep, src;
   };
   std::vector<Launch> launches;
-  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2 && !maf;  // the MAF flavour runs sweep by sweep
+  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2 && !maf && pairs_ok;  // the MAF flavour runs sweep by sweep
   int idx1[6];  // index range of the first sweep of a pair: one layer into the ghost cells across rank-internal faces
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
   if (can_pair && numProc > 1) {
@@ -721,6 +729,12 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       // lagging, non-blocking view of the flag: look at the copy issued two polls ago
       const int slot = npoll % POLL_SLOTS;
       if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
+      if (lag) {
+        // every rank must read the same flag here (they all stop issuing passes at the same one): the copy follows the tests of
+        // all passes issued so far, which run on the other stream
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
+      }
       HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
       HIP_CHECK(hipEventRecord(ev[slot], st));
@@ -787,14 +801,23 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   // Preferred form: the whole iteration (colour 0, then colour 1) in ONE pass over memory, out of place X <-> WRK
   // (czhip_rbsor2_async); decomposed runs then exchange two ghost layers once per iteration.  Fallback: the reference's
   // two in-place colour launches with an exchange after each colour.
-  bool fused = czhip_use_t2() != 0 && !maf;
+  bool fused = czhip_use_t2() != 0 && !maf && pairs_ok;
   int idx1[6];
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
-  REAL_TYPE* buf[2] = {X, WRK};
-  int cur = 0, n_fused = 0;
+  REAL_TYPE* buf[3] = {X, WRK, nullptr};
+  int cur = 0, n_fused = 0, nbuf = 2;
   if (fused) {
     if (numProc > 1 && (!Comm_S2(X) || !Comm_S2(B))) return 0;
     copy_shell_async(WRK, X, size, innerFidx, gc);
+  }
+  // decomposed, checked runs: residual all-reduce + test one iteration behind on the exchange stream, three rotating buffers
+  // (see CZ::JACOBI); the iterate of iteration k is in buf[k % nbuf]
+  const bool lag = fused && numProc > 1 && converge_check && n_shell > 0 && lag_reduce != 0;
+  if (lag) {
+    if (!WRK2) WRK2 = czhip_alloc_s3d(size);
+    copy_shell_async(WRK2, X, size, innerFidx, gc);
+    buf[2] = WRK2;
+    nbuf = 3;
   }
   hipEvent_t ev[POLL_SLOTS];
   int npoll = 0;
@@ -803,19 +826,38 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   for (itr = 1; itr <= itr_max && !stop; itr++) {
     const bool in_kernel_check = converge_check && numProc == 1;
     bool done = false;
-    if (fused && numProc > 1 && pair_overlapped(buf[cur], buf[cur ^ 1], B, idx1, rb_par(gc, innerFidx, ip), skip)) {
+    if (lag && fused) {
+      const int p = itr - 1;
+      if (p >= 2) HIP_CHECK(hipStreamWaitEvent(st, ev_chk[p & 1], 0));  // the test of iteration itr-2
+      double* rs = d_res + ((p & 1) ? 10 : 0);
+      if (pair_overlapped(buf[cur], buf[(cur + 1) % nbuf], B, idx1, rb_par(gc, innerFidx, ip), skip, rs)) {
+        flop += 18.0 * npts();
+        HIP_CHECK(hipEventRecord(ev_int, st));
+        HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
+        if (!comm_allreduce_sum(comm, rs, 1, comm_stream)) return 0;
+        check_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+        HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
+        cur = (cur + 1) % nbuf;
+        n_fused++;
+        done = true;
+      } else {  // the split was refused: the tests in flight come first, then the paths below
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
+      }
+    }
+    if (!done && fused && numProc > 1 && pair_overlapped(buf[cur], buf[(cur + 1) % nbuf], B, idx1, rb_par(gc, innerFidx, ip), skip)) {
       flop += 18.0 * npts();
       if (converge_check) {
         if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
         czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
-      cur ^= 1;
+      cur = (cur + 1) % nbuf;
       n_fused++;
       done = true;
     }
     if (fused && !done) {
       REAL_TYPE* src = buf[cur];
-      REAL_TYPE* dst = buf[cur ^ 1];
+      REAL_TYPE* dst = buf[(cur + 1) % nbuf];
       if (czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
                              in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip)) {  // :205-209 (+ :218-230)
         flop += 18.0 * npts();
@@ -826,7 +868,7 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
             czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
           }
         }
-        cur ^= 1;
+        cur = (cur + 1) % nbuf;
         n_fused++;
         done = true;
       } else {
@@ -856,6 +898,10 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
     if (converge_check && itr % POLL_EVERY == 0 && itr < itr_max) {
       const int slot = npoll % POLL_SLOTS;
       if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
+      if (lag) {  // the same flag on every rank: after the tests of all iterations issued so far (see CZ::JACOBI)
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
+      }
       HIP_CHECK(hipMemcpyAsync(h_flag + 2 * slot + 0, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipEventCreateWithFlags(&ev[slot], hipEventDisableTiming));
       HIP_CHECK(hipEventRecord(ev[slot], st));
@@ -868,17 +914,21 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
     }
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
+  if (lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
   if (n_fused > 0) {
-    // out-of-place iterations executed = all of them up to convergence (later launches were no-ops)
+    // out-of-place iterations: the iterate of iteration k is in buf[k % nbuf] (launches after convergence were no-ops, or -- lagged
+    // mode -- wrote the third buffer)
     const int n_exec = converge_check ? (ret > itr_max ? itr_max : ret) : itr_max;
-    if (n_exec & 1) {
+    const int fb = n_exec % nbuf;
+    if (fb != 0) {
       if (X == P) {
         REAL_TYPE* t = P;
-        P = WRK;
-        WRK = t;
+        P = buf[fb];
+        if (fb == 1) WRK = t;
+        else WRK2 = t;
       } else {
-        copy_inner_async(X, WRK, size, innerFidx, gc);
+        copy_inner_async(X, buf[fb], size, innerFidx, gc);
       }
     }
   }

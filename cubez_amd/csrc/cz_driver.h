@@ -67,6 +67,7 @@ class CZ {
   // decomposed runs: the exchange of a fused pair runs on comm_stream while the interior is being swept
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_shell = nullptr, ev_comm = nullptr, ev_int = nullptr, ev_chk[2] = {nullptr, nullptr};
+  bool pairs_ok = true;          // decomposed runs: EVERY brick can run the fused pass (agreed at set-up; the exchange pattern depends on it)
   int lag_reduce = 1;            // CZ_LAG_REDUCE=0: residual all-reduce + test on the compute stream after every pass (no lag)
   REAL_TYPE* WRK2 = nullptr;     // third rotation buffer of the lagged mode
   int overlap = 1;               // CZ_OVERLAP=0 turns it off (exchange after the whole sweep, same results)

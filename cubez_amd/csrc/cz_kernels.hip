@@ -885,6 +885,12 @@ void check2_on_stream(hipStream_t st, const double* res_dev, double res_normal, 
   hipLaunchKernelGGL(check2_k, dim3(1), dim3(1), 0, st, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
   HIP_CHECK(hipGetLastError());
 }
+void check_on_stream(hipStream_t st, const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
+                     int* conv_itr_dev) {
+  ensure_init();
+  hipLaunchKernelGGL(check_k, dim3(1), dim3(1), 0, st, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+  HIP_CHECK(hipGetLastError());
+}
 // MAF line solvers: order 0 = colour `sel` in place, 1 = lexicographic in place; xc, yc, zc device arrays
 void pcr_maf_async(REAL* x, const REAL* msk, const REAL* rhs, const int* sz, const int* idx, int g, int pn, int order, int sel,
                    const REAL* xc, const REAL* yc, const REAL* zc, REAL omg, double* res_dev, int accumulate) {
