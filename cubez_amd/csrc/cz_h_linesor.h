@@ -246,7 +246,39 @@ void launch_pcr_maf(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, con
     return;
   }
   bool ok = true;
+  auto reg = [&](const PcrGeom& g, int acc) -> bool {  // register form: lines of up to 1024 unknowns
+    const int n = g.n, nstage = g.pn - 1;
+    if (!ctx.tune.pcr_fast || g.pn < 1 || n > 1024) return false;
+    int M = 2;
+    while (64 * M < n) M *= 2;
+    if ((1 << nstage) < M) return false;
+    const long long ncol = (order == 0) ? (long long)g.nhalf * g.nj
+                                        : (long long)(std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1);
+    auto go = [&](auto kern, int NW, int L) {
+      const long long ngroups = (ncol + L - 1) / L;
+      const unsigned nblk = (unsigned)std::max<long long>(1, std::min<long long>((ngroups + NW - 1) / NW, (long long)ctx.num_cu * (32 / NW)));
+      ensure_partials(nblk);
+      ScopedTimer tm(LBL_PCR);
+      hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * NW), 0, ctx.stream, x, msk, rhs, g, omg, ma, ctx.partials, res_dev, acc, ctx.counter);
+      HIP_CHECK(hipGetLastError());
+      return true;
+    };
+#define CZ_PCR_MAF(M_)                                                                 \
+  if (M == M_) {                                                                       \
+    if (order == 1) return go(pcr_line_reg_maf_k<M_, 1, 1, 1>, 1, 1);                   \
+    if (ctx.tune.pcr_variant == 161) return go(pcr_line_reg_maf_k<M_, 16, 1, 0>, 16, 1); \
+    if (ctx.tune.pcr_variant == 41) return go(pcr_line_reg_maf_k<M_, 4, 1, 0>, 4, 1);   \
+    if (ctx.tune.pcr_variant == 82) return go(pcr_line_reg_maf_k<M_, 8, 2, 0>, 8, 2);   \
+    if (ctx.tune.pcr_variant == 81) return go(pcr_line_reg_maf_k<M_, 8, 1, 0>, 8, 1);   \
+    /* measured at 512^3 FP32: 4 x 1 0.749 ms, 16 x 1 0.761, 8 x 1 0.885, 8 x 2 0.876 */  \
+    return go(pcr_line_reg_maf_k<M_, 4, 1, 0>, 4, 1);                                   \
+  }
+    CZ_PCR_MAF(2) CZ_PCR_MAF(4) CZ_PCR_MAF(8) CZ_PCR_MAF(16)
+#undef CZ_PCR_MAF
+    return false;
+  };
   auto one = [&](const PcrGeom& g, int acc) {
+    if (reg(g, acc)) return true;
     if (order == 0) {
       return try_pcr_rb<4, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, ma) || try_pcr_rb<2, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, ma) ||
              try_pcr_rb<1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma);

@@ -817,6 +817,190 @@ pcr_line_reg_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Register form of the MAF line solvers (cz_maf.f90:442-1560): the matrix differs from line to line (metrics of the 1-D grids), so
+// a, c AND d of a line live in the registers of its wave (lane = M consecutive entries, as in pcr_line_reg_k) and all three are
+// reduced: e = 1/(1 - ap*c(kl) - cp*a(kr)), a1 = -e*ap*a(kl), c1 = -e*cp*c(kr), d1 = e*(d - ap*d(kl) - cp*d(kr)) (:551-574), then
+// the 2x2 systems (:578-596).  No table, no LDS memory, no barrier.  ORDER 0: one colour; ORDER 1: one diagonal of the lexicographic order.
+// ------------------------------------------------------------------------------------------------------------
+template <int M, int NW, int L, int ORDER>
+__global__ void __launch_bounds__(64 * NW)
+pcr_line_reg_maf_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, MafArgs ma, double* partials,
+                   double* dst, int accumulate, unsigned* counter) {
+  __shared__ double wsum[NW + 20];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = g.n;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const int dlo = (ORDER == 1) ? max(0, g.color - (g.nj - 1)) : 0;
+  const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj : (long long)(min(g.ni - 1, g.color) - dlo + 1);
+  const long long ngroups = (ncol + L - 1) / L;
+  const int nstage = g.pn - 1;
+  const int k0 = lane * M;
+  double acc = 0.0;
+  for (long long q = (long long)blockIdx.x * NW + wave; q < ngroups; q += (long long)gridDim.x * NW) {
+    size_t c0[L];
+    bool act[L];
+    int iis[L], jjs[L];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      const long long col = q * L + l;
+      int ii = g.ii0, jj = g.jj0;
+      if (ORDER == 0) {
+        const int jrow = (int)(col / g.nhalf), ih = (int)(col % g.nhalf);
+        act[l] = jrow < g.nj;
+        if (act[l]) {
+          const int j1 = g.jst1 + jrow;
+          int i1 = g.ist1 + 2 * ih;
+          if (((i1 + j1) & 1) != g.color) i1 += 1;
+          act[l] = (i1 - g.ist1) < g.ni;
+          if (act[l]) ii = g.ii0 + (i1 - g.ist1), jj = g.jj0 + jrow;
+        }
+      } else {
+        act[l] = col < ncol;
+        if (act[l]) ii = g.ii0 + dlo + (int)col, jj = g.jj0 + (g.color - dlo - (int)col);
+      }
+      iis[l] = ii, jjs[l] = jj;
+      c0[l] = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;
+    }
+    // ---- coefficients and source term (:489-546)
+    REAL a[L][M], c[L][M], d[L][M];
+#pragma unroll
+    for (int l = 0; l < L; l++) {
+      if (act[l] && k0 < n) {
+        const int ii = iis[l], jj = jjs[l];
+        const REAL GX = (REAL)2.0 / (ma.xc[ii + 1] - ma.xc[ii - 1]);
+        const REAL EY = (REAL)2.0 / (ma.yc[jj + 1] - ma.yc[jj - 1]);
+        const REAL C1 = GX * GX, C2 = EY * EY;
+        const REAL C7 = -(ma.xc[ii + 1] - (REAL)2.0 * ma.xc[ii] + ma.xc[ii - 1]) * C1 * GX;
+        const REAL C8 = -(ma.yc[jj + 1] - (REAL)2.0 * ma.yc[jj] + ma.yc[jj - 1]) * C2 * EY;
+        const REAL dd1 = C1 + (REAL)0.5 * C7, dd2 = C1 - (REAL)0.5 * C7, cc1 = C2 + (REAL)0.5 * C8, cc2 = C2 - (REAL)0.5 * C8;
+        const size_t e0 = c0[l] + k0;
+        REAL xip[M], xim[M], xjp[M], xjm[M], rh[M], mk[M];
+        load_run<M>(X + e0 + rowlen, xip);
+        load_run<M>(X + e0 - rowlen, xim);
+        load_run<M>(X + e0 + plane, xjp);
+        load_run<M>(X + e0 - plane, xjm);
+        load_run<M>(RHS + e0, rh);
+        load_run<M>(MSK + e0, mk);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const int k = k0 + m;
+          const int kk = g.kk0 + (k < n ? k : 0);
+          const REAL f1 = ma.zc[kk + 1], f2 = ma.zc[kk - 1];
+          const REAL TZ = (REAL)2.0 / (f1 - f2);
+          const REAL ZTT = f1 - (REAL)2.0 * ma.zc[kk] + f2;
+          const REAL f3 = TZ * TZ;
+          const REAL aw = f3, cw = -ZTT * f3 * TZ, dw = (REAL)0.5 / (C1 + C2 + f3);
+          const REAL av = (k == 0 && n > 1) ? (REAL)0 : -(aw - (REAL)0.5 * cw) * dw;
+          const REAL cv = (k == n - 1) ? (REAL)0 : -(aw + (REAL)0.5 * cw) * dw;
+          REAL dv = (dd1 * xip[m] + dd2 * xim[m] + cc1 * xjp[m] + cc2 * xjm[m] - rh[m]) * dw * mk[m];
+          if (k == 0) dv = (dv + (aw - (REAL)0.5 * cw) * dw * X[e0 - 1]) * mk[m];
+          if (k == n - 1) dv = (dv + (aw + (REAL)0.5 * cw) * dw * X[e0 + m + 1]) * mk[m];
+          a[l][m] = (k < n) ? av : (REAL)0, c[l][m] = (k < n) ? cv : (REAL)0, d[l][m] = (k < n) ? dv : (REAL)0;
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < M; m++) a[l][m] = c[l][m] = d[l][m] = (REAL)0;
+      }
+    }
+    // ---- PCR stages (:551-574)
+#pragma unroll
+    for (int sidx = 0; sidx < 20; sidx++) {
+      if ((1 << sidx) >= 64 * M) break;  // compile time
+      if (sidx < nstage) {
+        const int s = 1 << sidx;
+        REAL na[L][M], nc[L][M], nd[L][M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+#pragma unroll
+          for (int l = 0; l < L; l++) {
+            REAL al, cl, dl, ar, cr, dr;
+            if (s < M) {
+              if (m - s >= 0) {
+                al = a[l][(m - s >= 0) ? m - s : 0], cl = c[l][(m - s >= 0) ? m - s : 0], dl = d[l][(m - s >= 0) ? m - s : 0];
+              } else {
+                al = lane_up(a[l][(m - s + M) % M], 1, lane), cl = lane_up(c[l][(m - s + M) % M], 1, lane), dl = lane_up(d[l][(m - s + M) % M], 1, lane);
+              }
+              if (m + s < M) {
+                ar = a[l][(m + s < M) ? m + s : 0], cr = c[l][(m + s < M) ? m + s : 0], dr = d[l][(m + s < M) ? m + s : 0];
+              } else {
+                ar = lane_down(a[l][(m + s) % M], 1, lane), cr = lane_down(c[l][(m + s) % M], 1, lane), dr = lane_down(d[l][(m + s) % M], 1, lane);
+              }
+            } else {
+              al = lane_up(a[l][m], s / M, lane), cl = lane_up(c[l][m], s / M, lane), dl = lane_up(d[l][m], s / M, lane);
+              ar = lane_down(a[l][m], s / M, lane), cr = lane_down(c[l][m], s / M, lane), dr = lane_down(d[l][m], s / M, lane);
+            }
+            const REAL ap = a[l][m], cp = c[l][m];
+            const REAL e = (REAL)1.0 / ((REAL)1.0 - ap * cl - cp * ar);
+            na[l][m] = -e * ap * al;
+            nc[l][m] = -e * cp * cr;
+            nd[l][m] = e * (d[l][m] - ap * dl - cp * dr);
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < L; l++)
+#pragma unroll
+          for (int m = 0; m < M; m++) {
+            const bool in = k0 + m < n;
+            a[l][m] = in ? na[l][m] : (REAL)0, c[l][m] = in ? nc[l][m] : (REAL)0, d[l][m] = in ? nd[l][m] : (REAL)0;
+          }
+      }
+    }
+    // ---- 2x2 systems (:578-596), every entry solves for itself, then the relaxation (:626-637)
+    {
+      const int qf = (1 << nstage) / M;
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        REAL sol[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const int rr = (k0 + m) >> nstage;
+          const REAL a_dn = lane_down(a[l][m], qf, lane), d_dn = lane_down(d[l][m], qf, lane);
+          const REAL c_up = lane_up(c[l][m], qf, lane), d_up = lane_up(d[l][m], qf, lane);
+          const REAL cc1 = rr == 0 ? c[l][m] : c_up, aa2 = rr == 0 ? a_dn : a[l][m];
+          const REAL f1 = rr == 0 ? d[l][m] : d_up, f2 = rr == 0 ? d_dn : d[l][m];
+          const REAL jj2 = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+          sol[m] = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;
+        }
+        if (!act[l] || k0 >= n) continue;
+        const size_t e0 = c0[l] + k0;
+        REAL pp[M], mk[M], out[M];
+        load_run<M>(X + e0, pp);
+        load_run<M>(MSK + e0, mk);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+          const REAL dp = (sol[m] - pp[m]) * omg * mk[m];
+          out[m] = pp[m] + dp;
+          const REAL d2 = dp * dp;
+          if (k0 + m < n) acc += (double)d2;
+        }
+        store_run<M>(X + e0, out, n - k0);
+      }
+    }
+  }
+  // ---- residual (as in pcr_line_reg_k)
+  const double sblk = block_sum<64 * NW>(acc, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + NW + 2);
+  const int nblk = gridDim.x;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) {
+    double x = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64 * NW) x += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum<64 * NW>(x, wsum);
+    if (threadIdx.x == 0) {
+      dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
 // imask_k (cz_blas.f90:24-104): 1 on the inner box, 0 elsewhere (whole padded array)
 __global__ void __launch_bounds__(256)
 imask_k(REAL* X, int nkp, int nip, int njp, int kk0, int kk1, int ii0, int ii1, int jj0, int jj1) {
