@@ -71,6 +71,7 @@ if torch.cuda.is_available():
 cz = CZ(args.prec, quiet=True, device=local_rank)
 lib = cz.lib
 if world > 1:
+    os.environ.setdefault("CZ_COMM_DEBUG", "1")  # one diagnostic line per rank on stderr (stdout carries the JSON line only)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     nb = lib.cz_comm_unique_id_bytes()
     buf = C.create_string_buffer(nb)

@@ -320,6 +320,15 @@ int CZ::Setup(int argc, char** argv) {
     for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
     const double mine = pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE) ? 0.0 : 1.0;
     pairs_ok = comm_allreduce_max_host(comm, mine) == 0.0;
+    if (getenv("CZ_COMM_DEBUG")) {  // one line per rank on stderr: what a multi-GPU run decided
+      int dev = -1;
+      (void)hipGetDevice(&dev);
+      fprintf(stderr,
+              "cz rank %d/%d device %d: div %dx%dx%d size %dx%dx%d head %d,%d,%d nID %d %d %d %d %d %d fused_pass=%d shell_slabs=%d overlap=%d "
+              "lagged_reduce=%d\n",
+              myRank, numProc, dev, G_div[0], G_div[1], G_div[2], size[0], size[1], size[2], head[0], head[1], head[2], nID[0], nID[1], nID[2],
+              nID[3], nID[4], nID[5], (int)pairs_ok, n_shell, overlap, lag_reduce);
+    }
   }
   const bool bicg = ls_type == LS_BICGSTAB || ls_type == LS_BICGSTAB_MAF;
   if (bicg) {
