@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the CubeZ hot path on MI355X (contract: see the task statement / DESIGN.md 6).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: this process starts the N ranks itself, see below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-(--solver sor2sma / pbicgstab time the other BASELINE configs the same way: step = one RB-SOR iteration / one BiCGSTAB
-iteration incl. its 2 x 8 preconditioner sweeps; pbicgstab defaults to --prec f64 as in configs[3].)
-A "step" is one relaxed-Jacobi sweep of the FP32 cube with everything the reference's checked loop does per
-iteration (sweep, residual reduction, normalise + history + eps test; cz_Poisson.cpp:39-79), inputs resident in HBM.
-N=1: BASELINE.json configs[1], `cz 512 512 512 jacobi K 0.8`.  N>1: weak scaling, 512^3 cells per GPU
-(2: 1x2x1, 4: 2x2x1, 8: 2x2x2 = configs[4], the 1024^3 cube), halo exchange + residual all-reduce over RCCL.
+A "step" is one relaxed-Jacobi sweep of the FP32 cube with everything the reference's checked loop does per iteration (sweep,
+residual reduction, normalise + history + eps test; cz_Poisson.cpp:39-79), inputs resident in HBM.
+N=1: BASELINE.json configs[1], `cz 512 512 512 jacobi K 0.8`.  N>1: weak scaling, 512^3 cells per GPU (2: 1x2x1, 4: 2x2x1,
+8: 2x2x2 = configs[4], the 1024^3 cube), halo exchange + residual all-reduce over RCCL.
+The K steps are timed `--repeats` times (each between barriers); the line reports the median repeat.
+--solver sor2sma / pbicgstab time the other BASELINE configs the same way: step = one RB-SOR iteration / one BiCGSTAB iteration incl.
+its 2 x 8 preconditioner sweeps; pbicgstab defaults to --prec f64 as in configs[3].
 Prints ONE JSON line on rank 0.
+
+`--gpus N` without a launcher (the reference starts all ranks with one command too, `mpirun -np 8 ./cz ... 2 2 2`, main.cpp:24-35):
+the parent does not import torch and does not touch the GPU; it starts `python -m torch.distributed.run ... bench.py <same args>` as a
+CHILD process, relays rank 0's JSON line and exits with the child's code (non-zero on failure, time-out or a missing line).
+--dry-launch: rendezvous + broadcast of the communicator id only (no solver, no ncclCommInitRank); runs without a GPU.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import signal
+import socket
+import statistics
 import subprocess
 import sys
 import time
@@ -24,34 +32,71 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before HIP starts
 
+SOLVERS = ["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor", "pcr", "pcr_eda", "pcr_esa", "pcr_rb_esa", "pcr_j_esa", "jacobi_maf", "sor2sma_maf",
+           "psor_maf", "pcr_rb_maf", "pcr_maf"]
 ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
+ap.add_argument("--repeats", type=int, default=5, help="how many times the --steps region is timed (median reported)")
 ap.add_argument("--n", type=int, default=512, help="cells per GPU and axis")
-ap.add_argument("--solver", default="jacobi", choices=["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor", "pcr", "pcr_eda", "pcr_esa", "pcr_rb_esa", "pcr_j_esa", "jacobi_maf",
-                                                     "sor2sma_maf", "psor_maf", "pcr_rb_maf", "pcr_maf"])
+ap.add_argument("--solver", default="jacobi", choices=SOLVERS)
 ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "sor2sma"])
-ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
+ap.add_argument("--prec", default=None, choices=["f32", "f64"])
 ap.add_argument("--div", default=None, help="Cartesian division of the ranks, e.g. 1,8,1 (default: 1x2x1, 2x2x1, 2x2x2 for 2, 4, 8 GPUs)")
 ap.add_argument("--no-cpu-baseline", action="store_true")
 ap.add_argument("--cpu-seconds", type=float, default=12.0)
+ap.add_argument("--dry-launch", action="store_true", help="rendezvous and id broadcast only; works without a GPU")
+ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launched job may take")
 args = ap.parse_args()
-if args.solver == "pbicgstab" and "--prec" not in " ".join(sys.argv):
-    args.prec = "f64"
+if args.prec is None:
+    args.prec = "f64" if args.solver == "pbicgstab" else "f32"
+
+
+def self_launch() -> int:
+    """Parent of a multi-GPU run: start the ranks as a child job, relay rank 0's JSON line.  No torch, no HIP in this process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)  # stderr passes through
+    try:
+        out, _ = child.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(child.pid, signal.SIGKILL)  # exactly the process group started above
+        child.wait()
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank job did not finish within {args.launch_timeout:.0f} s -- killed\n")
+        return 124
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")  # anything else the ranks printed
+    if child.returncode != 0:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank job exited with code {child.returncode}\n")
+        return child.returncode
+    if line is None:
+        sys.stderr.write("bench.py: the ranks finished without a result line\n")
+        return 1
+    print(line)
+    return 0
+
+
+if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(self_launch())
 
 rank = int(os.environ.get("RANK", "0"))
 world = int(os.environ.get("WORLD_SIZE", "1"))
 local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-if world != args.gpus and world > 1:
+if world != args.gpus:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-if args.gpus > 1 and world == 1:
-    raise SystemExit("launch multi-GPU runs with python -m torch.distributed.run --nproc-per-node N (one rank per GPU)")
+
+import ctypes as C  # noqa: E402
 
 import torch  # noqa: E402  (plumbing only: rendezvous, barrier, max-reduce of the timings)
 import torch.distributed as dist  # noqa: E402
-
-from cubez_amd import CZ  # noqa: E402
 
 DIVS = {1: (1, 1, 1), 2: (1, 2, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 if args.div:
@@ -64,14 +109,45 @@ else:
     raise SystemExit("supported GPU counts without --div: 1, 2, 4, 8")
 n = args.n
 gsz = [n * div[0], n * div[1], n * div[2]]
-coef = 0.9 if args.solver == "pcr_j_esa" else 1.2 if (args.solver.startswith("pcr") or args.solver.startswith("psor")) else 1.5 if (args.solver.startswith("sor2sma") or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
+coef = 0.9 if args.solver == "pcr_j_esa" else 1.2 if (args.solver.startswith("pcr") or args.solver.startswith("psor")) else 1.5 if (
+    args.solver.startswith("sor2sma") or (args.solver == "pbicgstab" and args.precond == "sor2sma")) else 0.8
+
+import cubez_amd  # noqa: E402
+
+if args.dry_launch:
+    # the bootstrap of a multi-rank run without its GPU half: gloo rendezvous, rank 0 makes the communicator id, broadcast, compare
+    lib = cubez_amd.load(args.prec)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    nb = lib.cz_comm_unique_id_bytes()
+    have_gpu = torch.cuda.device_count() > 0
+    buf = C.create_string_buffer(nb)
+    if rank == 0:
+        if have_gpu:
+            lib.cz_comm_get_unique_id(buf)  # ncclGetUniqueId needs a device
+        else:
+            buf.raw = os.urandom(nb)
+    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    dist.broadcast(t, src=0)
+    chk = torch.tensor([int(t.to(torch.int64).sum())], dtype=torch.int64)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry launch (rendezvous + communicator id broadcast, no solver)", "value": None, "unit": None, "n_gpus": world,
+                          "dry_launch": True, "id_bytes": nb, "id_source": "ncclGetUniqueId" if have_gpu else "placeholder (no GPU here)",
+                          "id_agrees_on_all_ranks": bool(int(lo[0]) == int(hi[0])), "division": list(div), "global_grid": gsz}))
+    dist.destroy_process_group()
+    sys.exit(0)
+
+from cubez_amd import CZ  # noqa: E402
 
 if torch.cuda.is_available():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
 cz = CZ(args.prec, quiet=True, device=local_rank)
 lib = cz.lib
 if world > 1:
-    os.environ.setdefault("CZ_COMM_DEBUG", "1")  # one diagnostic line per rank on stderr (stdout carries the JSON line only)
+    os.environ.setdefault("CZ_COMM_DEBUG", "1")  # one diagnostic line per rank on stderr + the collective watchdog (cz_comm.cpp)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     nb = lib.cz_comm_unique_id_bytes()
     buf = C.create_string_buffer(nb)
@@ -82,7 +158,7 @@ if world > 1:
     lib.cz_comm_bootstrap(rank, world, bytes(t.numpy().tobytes()))
 
 bicg = args.solver == "pbicgstab"
-argv = gsz + [args.solver, (args.warmup + 1) if bicg else (args.steps + args.warmup), coef] + ([args.precond] if bicg else [])
+argv = gsz + [args.solver, (args.warmup + 1) if bicg else (args.steps * args.repeats + args.warmup), coef] + ([args.precond] if bicg else [])
 if world > 1:
     argv += list(div)
 assert cz.setup(argv) == 1, "cz_setup failed"
@@ -99,43 +175,55 @@ def barrier():
         dist.barrier()
 
 
-if bicg:
-    # the Krylov loop has no "continue" entry point: warm up with one solve of W iterations, time a second one of K
-    cz.solve()
-    cz.close()
-    cz = CZ(args.prec, quiet=True, device=local_rank)
-    argv[4] = args.steps + 1
-    assert cz.setup(argv) == 1
+def timed(fn):
     barrier()
-    cz.timing(True)
     t0 = time.perf_counter()
-    cz.solve()
+    fn()
     barrier()
     dt = time.perf_counter() - t0
-    assert len(cz.history()) == args.steps, "BiCGSTAB converged before the requested number of iterations"
+    if world > 1:  # the slowest rank
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    return dt
+
+
+dts = []
+if bicg:
+    # the Krylov loop has no "continue" entry point: warm up with one solve of W iterations, then time solves of K iterations
+    cz.solve()
+    for rep in range(args.repeats):
+        cz.close()
+        cz = CZ(args.prec, quiet=True, device=local_rank)
+        argv[4] = args.steps + 1
+        assert cz.setup(argv) == 1
+        if rep == args.repeats - 1:
+            cz.timing(True)
+        dts.append(timed(cz.solve))
+        assert len(cz.history()) == args.steps, "BiCGSTAB converged before the requested number of iterations"
 else:
     cz.sweeps(args.warmup)
     barrier()
     cz.timing(True)
-    t0 = time.perf_counter()
-    cz.sweeps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    for rep in range(args.repeats):
+        dts.append(timed(lambda: cz.sweeps(args.steps)))
+dt = statistics.median(dts)
 _jl = args.solver in ("jacobi", "jacobi_maf") or (args.solver == "pbicgstab" and args.precond == "jacobi")
 _line = args.solver.startswith("pcr")
 nk, kern_ms = cz.timing_read("jacobi" if _jl else "pcr_rb" if _line else "psor" if args.solver.startswith("psor") else "rbsor")
 nk2, kern2_ms = cz.timing_read("jacobi2" if _jl else "rbsor2")  # fused: 2 sweeps / both colours per launch
 cz_shell = cz.timing_read("pair_shell")
 cz.timing(False)
+info = cz.info()
+timed_steps = args.steps * (1 if bicg else args.repeats)  # the event-timed launches cover this many steps
 
 tot_points = float(my_points)
 if world > 1:
-    tt = torch.tensor([dt], dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt[0])
     tp = torch.tensor([tot_points], dtype=torch.float64)
     dist.all_reduce(tp, op=dist.ReduceOp.SUM)
     tot_points = float(tp[0])
+    devs = [None] * world
+    dist.all_gather_object(devs, {"rank": rank, "device": torch.cuda.current_device() if torch.cuda.is_available() else None, "rccl_ranks": info["rccl_ranks"]})
 
 if rank == 0:
     word = 4 if args.prec == "f32" else 8
@@ -148,7 +236,7 @@ if rank == 0:
     if _line:
         # one iteration: every line reads x, rhs, msk and writes x (4 words), and is read once more as i/j neighbour (1 word);
         # pcr_rb / pcr_rb_esa: two colour launches per iteration, pcr / pcr_esa: one launch per (i+j) diagonal, pcr_j_esa: one
-        per_iter = {"pcr_rb": 2, "pcr_rb_esa": 2, "pcr_rb_maf": 2, "pcr_j_esa": 1}.get(args.solver, nk // max(args.steps, 1))
+        per_iter = {"pcr_rb": 2, "pcr_rb_esa": 2, "pcr_rb_maf": 2, "pcr_j_esa": 1}.get(args.solver, nk // max(timed_steps, 1))
         alg_bytes_per_launch = my_points * word * 5 // max(per_iter, 1)
         kernel_name, tkey = f"pcr_rb2_k ({per_iter} launches of k-line solves per iteration)", f"{args.solver}_{n}_{args.prec}"
     if args.solver.startswith("psor"):
@@ -158,9 +246,9 @@ if rank == 0:
     if nk2 > nk:  # the dominant kernel is the fused one: 2 Jacobi sweeps (2 x 3 words) or both RB colours (2 x 2 words)
         nk, kern_ms, alg_bytes_per_launch = nk2, kern2_ms, 2 * alg_bytes_per_launch
         if jac_like:
-            kernel_name, tkey = "jacobi2_k<RB=0> (two fused sweeps per launch)", f"jacobi2_{n}_{args.prec}"
+            kernel_name, tkey = "jacobi2p_k<RB=0> (two fused sweeps per launch)", f"jacobi2_{n}_{args.prec}"
         else:
-            kernel_name, tkey = "jacobi2_k<RB=1> (both colours of one iteration per launch)", f"rbsor2_{n}_{args.prec}"
+            kernel_name, tkey = "jacobi2p_k<RB=1> (both colours of one iteration per launch)", f"rbsor2_{n}_{args.prec}"
     kern_avg_s = (kern_ms / nk) * 1e-3 if nk else float("nan")
     achieved = alg_bytes_per_launch / kern_avg_s / 1e9 if nk else None
     traffic = None
@@ -182,6 +270,10 @@ if rank == 0:
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "repeats": args.repeats,
+        "ms_per_step_min": min(dts) / args.steps * 1e3,
+        "ms_per_step_median": dt / args.steps * 1e3,
+        "ms_per_step_all": [d / args.steps * 1e3 for d in dts],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -197,17 +289,16 @@ if rank == 0:
                      "kernel_avg_ms": kern_avg_s * 1e3, "kernel_launches_timed": nk,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch},
     }
-    if world > 1 and nk2 > 0 and not bicg:
-        # exposed (non-overlapped) communication per step = wall time per step minus the rank-0 kernel time per step
-        # (shell slabs + interior of a fused pass cover two steps); the exchange itself runs on a second stream behind the interior
-        try:
+    if world > 1:
+        out["multi_gpu"] = {"ranks": devs, "rccl_ranks": info["rccl_ranks"], "fused_pass": bool(info["fused_pass"]), "shell_slabs_rank0": info["shell_slabs"],
+                            "overlap": bool(info["overlap"]), "lagged_reduce": bool(info["lagged_reduce"])}
+        if nk2 > 0 and not bicg:
+            # exposed (non-overlapped) communication per step = wall time per step minus the rank-0 kernel time per step
+            # (shell slabs + interior of a fused pass cover two steps); the exchange itself runs on a second stream behind the interior
             n_sh, sh_ms = cz_shell
             per_step_kernel_ms = (kern2_ms + sh_ms) / nk2 / (2.0 if jac_like else 1.0)
-            out["multi_gpu"] = {"kernel_ms_per_step_rank0": per_step_kernel_ms, "exposed_ms_per_step": dt / args.steps * 1e3 - per_step_kernel_ms,
-                                "per_gpu_algorithmic_GBps": achieved, "overlap": os.environ.get("CZ_OVERLAP", "1") != "0",
-                                "lagged_reduce": os.environ.get("CZ_LAG_REDUCE", "1") != "0" and args.solver == "jacobi"}
-        except Exception as e:  # reporting only
-            out["multi_gpu"] = {"error": repr(e)}
+            out["multi_gpu"].update({"kernel_ms_per_step_rank0": per_step_kernel_ms, "exposed_ms_per_step": dt / args.steps * 1e3 - per_step_kernel_ms,
+                                     "per_gpu_algorithmic_GBps": achieved})
     if bicg:
         out["config"]["step"] = "one BiCGSTAB iteration: 2 x 8 preconditioner sweeps, 2 SpMV, 5 dots, 4 axpy-type updates (cz_Poisson.cpp:373-500)"
         # 76 words per point and iteration with the Jacobi preconditioner

@@ -12,12 +12,18 @@
 
 #include <rccl/rccl.h>
 
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "cz_internal.h"
@@ -34,6 +40,16 @@
 
 namespace {
 
+double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Seconds a collective may stay incomplete before the job is ended with a diagnostic: CZ_COMM_TIMEOUT, default 300 when CZ_COMM_DEBUG
+// is set (bench.py sets it for N > 1), 0 = wait for ever (RCCL) / 120 (LOCAL test transport, whose waits are host-side).
+double comm_timeout_s(bool local) {
+  if (const char* t = getenv("CZ_COMM_TIMEOUT")) return atof(t);
+  if (local) return 120.0;
+  return getenv("CZ_COMM_DEBUG") ? 300.0 : 0.0;
+}
+
 // ---- in-process world (LOCAL transport)
 struct LocalWorld {
   int n = 0;
@@ -43,7 +59,9 @@ struct LocalWorld {
   long generation = 0;
   std::vector<CommCtx*> ranks;
   std::vector<double> red;
-  void barrier() {
+  // every wait is bounded: ranks that issue different sequences of collectives (the failure of commit 24dd087's parent: bricks disagreeing
+  // on the pass they run) end the process with the rank and the barrier number instead of blocking for ever
+  void barrier(int rank = -1) {
     std::unique_lock<std::mutex> lk(mu);
     const long gen = generation;
     if (++arrived == n) {
@@ -51,8 +69,88 @@ struct LocalWorld {
       generation++;
       cv.notify_all();
     } else {
-      cv.wait(lk, [&] { return generation != gen; });
+      const double lim = comm_timeout_s(true);
+      if (!cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return generation != gen; })) {
+        fprintf(stderr, "cz rank %d: LOCAL barrier #%ld: only %d of %d ranks arrived within %.0f s -- the ranks issue different collectives\n", rank,
+                gen, arrived, n, lim);
+        fflush(stderr);
+        _exit(3);
+      }
     }
+  }
+};
+
+// ---- watchdog of the stream-ordered collectives (RCCL): every exchange / all-reduce gets a sequence number and an event behind it;
+// a helper thread ends the process when the oldest incomplete one is older than the limit, naming rank, number and kind.  With RCCL a
+// rank that issues a different sequence than its peers blocks the whole job silently; this turns it into an exit code and one line.
+struct Watch {
+  struct Item {
+    hipEvent_t ev;
+    long seq;
+    const char* what;
+    double t;
+  };
+  bool on = false;
+  double limit = 0.0;
+  int rank = 0, device = 0, verbose = 0;
+  long seq = 0, done = 0;
+  std::mutex mu;
+  std::deque<Item> q;
+  std::vector<hipEvent_t> pool;
+  std::thread th;
+  std::atomic<bool> quit{false};
+
+  void start(int rank_, double limit_) {
+    rank = rank_, limit = limit_;
+    if (const char* d = getenv("CZ_COMM_DEBUG")) verbose = atoi(d);
+    if (limit <= 0.0) return;
+    HIP_CHECK(hipGetDevice(&device));
+    on = true;
+    th = std::thread([this] { run(); });
+  }
+  void note(const char* what, hipStream_t st) {
+    seq++;
+    if (verbose >= 2) fprintf(stderr, "cz rank %d: collective #%ld %s\n", rank, seq, what);
+    if (!on) return;
+    hipEvent_t ev;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!pool.empty()) {
+        ev = pool.back();
+        pool.pop_back();
+      } else {
+        HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      }
+    }
+    HIP_CHECK(hipEventRecord(ev, st));
+    std::lock_guard<std::mutex> lk(mu);
+    q.push_back({ev, seq, what, wall_s()});
+  }
+  void run() {
+    (void)hipSetDevice(device);
+    while (!quit.load()) {
+      usleep(100000);
+      std::lock_guard<std::mutex> lk(mu);
+      while (!q.empty() && hipEventQuery(q.front().ev) == hipSuccess) {
+        done = q.front().seq;
+        pool.push_back(q.front().ev);
+        q.pop_front();
+      }
+      if (!q.empty() && wall_s() - q.front().t > limit) {
+        fprintf(stderr, "cz rank %d: collective #%ld (%s) has not completed %.0f s after it was issued (last completed: #%ld, issued so far: #%ld) -- "
+                        "the ranks are out of step or a peer is gone\n", rank, q.front().seq, q.front().what, limit, done, seq);
+        fflush(stderr);
+        _exit(3);
+      }
+    }
+  }
+  void stop() {
+    if (!on) return;
+    quit.store(true);
+    th.join();
+    for (auto& i : q) (void)hipEventDestroy(i.ev);
+    for (auto& e : pool) (void)hipEventDestroy(e);
+    on = false;
   }
 };
 
@@ -121,6 +219,7 @@ struct CommCtx {
   double* h_red = nullptr;
   Pattern shallow, deep;   // depth 1 faces / depth 2 faces + edges
   const Pattern* cur = nullptr;  // LOCAL: pattern being exchanged (published for the neighbours)
+  Watch watch;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -245,7 +344,7 @@ bool exchange(CommCtx* c, const Pattern& p, T* X, const int* skip, hipStream_t s
   } else {  // LOCAL: every rank has packed; copy what each neighbour packed for me (its message in direction -d)
     c->cur = &p;
     HIP_CHECK(hipStreamSynchronize(st));
-    c->world->barrier();
+    c->world->barrier(c->rank);
     for (int m = 0; m < p.nmsg; m++) {
       const CommCtx* nb = c->world->ranks[p.peer[m]];
       const Pattern* q = nb->cur;
@@ -260,10 +359,11 @@ bool exchange(CommCtx* c, const Pattern& p, T* X, const int* skip, hipStream_t s
                                hipMemcpyDeviceToDevice, st));
     }
     HIP_CHECK(hipStreamSynchronize(st));
-    c->world->barrier();  // nobody repacks before everyone has copied
+    c->world->barrier(c->rank);  // nobody repacks before everyone has copied
   }
   hipLaunchKernelGGL((box_copy_k<T, 1>), grid, dim3(256), 0, st, (T*)p.recvbuf, X, p.recv, nkp, nip, skip);
   HIP_CHECK(hipGetLastError());
+  c->watch.note(&p == &c->deep ? "halo exchange, two layers + edges" : "halo exchange, one layer", st);
   return true;
 }
 }  // namespace
@@ -286,11 +386,13 @@ CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], i
     std::lock_guard<std::mutex> lk(c->world->mu);
     c->world->ranks[rank] = c;
   }
+  c->watch.start(rank, c->tr == T_RCCL ? comm_timeout_s(false) : 0.0);  // (the LOCAL transport bounds its own host-side waits)
   return c;
 }
 
 void comm_destroy(CommCtx* c) {
   if (!c) return;
+  c->watch.stop();
   for (Pattern* p : {&c->shallow, &c->deep}) {
     if (p->sendbuf) (void)hipFree(p->sendbuf);
     if (p->recvbuf) (void)hipFree(p->recvbuf);
@@ -314,19 +416,20 @@ bool comm_allreduce_sum(CommCtx* c, double* d_val, int count, hipStream_t st) {
   if (!c) return true;
   if (c->tr == T_RCCL) {
     NCCL_CHECK(ncclAllReduce(d_val, d_val, count, ncclDouble, ncclSum, c->nccl, st));
+    c->watch.note("all-reduce (sum)", st);
     return true;
   }
   LocalWorld* w = c->world;
   HIP_CHECK(hipMemcpyAsync(c->h_red, d_val, count * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
   for (int i = 0; i < count; i++) w->red[(size_t)c->rank * 16 + i] = c->h_red[i];
-  w->barrier();
+  w->barrier(c->rank);
   for (int i = 0; i < count; i++) {
     double s = 0.0;
     for (int r = 0; r < w->n; r++) s += w->red[(size_t)r * 16 + i];
     c->h_red[i] = s;
   }
-  w->barrier();
+  w->barrier(c->rank);
   HIP_CHECK(hipMemcpyAsync(d_val, c->h_red, count * sizeof(double), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipStreamSynchronize(st));
   return true;
@@ -339,6 +442,7 @@ double comm_allreduce_max_host(CommCtx* c, double v) {
     HIP_CHECK(hipMalloc(&d, sizeof(double)));
     HIP_CHECK(hipMemcpy(d, &v, sizeof(double), hipMemcpyHostToDevice));
     NCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclMax, c->nccl, czhip_internal::stream()));
+    c->watch.note("all-reduce (max)", czhip_internal::stream());
     HIP_CHECK(hipStreamSynchronize(czhip_internal::stream()));
     HIP_CHECK(hipMemcpy(&v, d, sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(d);
@@ -346,11 +450,18 @@ double comm_allreduce_max_host(CommCtx* c, double v) {
   }
   LocalWorld* w = c->world;
   w->red[(size_t)c->rank * 16] = v;
-  w->barrier();
+  w->barrier(c->rank);
   double m = v;
   for (int r = 0; r < w->n; r++) m = std::max(m, w->red[(size_t)r * 16]);
-  w->barrier();
+  w->barrier(c->rank);
   return m;
+}
+
+int comm_transport_ranks(const CommCtx* c) {
+  if (!c || c->tr != T_RCCL || !c->nccl) return 0;
+  int n = 0;
+  NCCL_CHECK(ncclCommCount(c->nccl, &n));
+  return n;
 }
 
 // ============================================================================================================

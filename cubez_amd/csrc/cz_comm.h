@@ -28,5 +28,7 @@ bool comm_halo(CommCtx*, void* X, const int* skip_flag_dev, hipStream_t st);
 bool comm_halo2(CommCtx*, void* X, const int* skip_flag_dev, hipStream_t st);
 bool comm_allreduce_sum(CommCtx*, double* d_val, int count, hipStream_t st);
 double comm_allreduce_max_host(CommCtx*, double v);
+// ranks of the RCCL communicator behind the context (ncclCommCount); 0 for the LOCAL transport or no context
+int comm_transport_ranks(const CommCtx*);
 
 #endif

@@ -80,6 +80,7 @@ CZ::CZ() {
   const char* ov = getenv("CZ_OVERLAP");
   if (ov) overlap = atoi(ov);
   if (const char* lg = getenv("CZ_LAG_REDUCE")) lag_reduce = atoi(lg);
+  if (const char* sk = getenv("CZ_TEST_SKEW")) sscanf(sk, "%d,%d", &skew_rank, &skew_ms);  // tests: "rank,milliseconds"
 }
 
 CZ::~CZ() {
@@ -535,7 +536,9 @@ bool CZ::Comm_S2(REAL_TYPE* X, const int* skip_flag) {
 }
 bool CZ::Comm_SUM_dev(double* d_val, int count, const int* skip_flag) {
   if (numProc == 1) return true;
-  (void)skip_flag;  // all ranks see the same flag, so the collective is issued by all or by none
+  // INVARIANT: collectives are issued unconditionally -- never gated by a device flag the host has not read, never by host timing.
+  // What a rank issues depends only on its argv, on the agreed launch count and on `stop` (see the poll in CZ::JACOBI).
+  (void)skip_flag;
   return comm_allreduce_sum(comm, d_val, count, stream());
 }
 bool CZ::Comm_SUM_1(double* host_val) {
@@ -546,6 +549,10 @@ bool CZ::Comm_SUM_1(double* host_val) {
   HIP_CHECK(hipStreamSynchronize(stream()));
   *host_val = h_scal[8];
   return true;
+}
+
+void CZ::skew_wait() const {
+  if (skew_ms > 0 && myRank == skew_rank) usleep((useconds_t)skew_ms * 1000u);
 }
 
 // Split of the inner box for overlapped exchanges (pair_plan, cz_kernels.hip); n_shell = 0 when there is nothing to overlap.
@@ -625,9 +632,10 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
   REAL_TYPE* buf[3] = {X, WRK, nullptr};
   int nbuf = 2;
   const int* skip = nullptr;
+  reset_ticket();
   if (converge_check) {
     ensure_hist(itr_max + 3);
-    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));  // flag, iteration, the two snapshots of the lagged mode
     skip = d_flag;
   }
   // Single-domain runs apply the sweeps two at a time (czhip_jacobi2_async: temporal blocking, the intermediate field
@@ -667,12 +675,16 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       const int p = (int)launches.size();
       if (p >= 2) HIP_CHECK(hipStreamWaitEvent(st, ev_chk[p & 1], 0));  // the test of pass p-2
       double* rs = d_res + ((p & 1) ? 10 : 0);
-      if (pair_overlapped(src, dst, B, idx1, -1, skip, rs)) {
+      // Pass p looks at the flag as the test of pass p-2 left it (d_flag[2 + (p & 1)], written by that test and by nothing else until
+      // pass p is over): every workgroup of the pass, its pack and its unpack take the same decision.  The live flag d_flag[0] may be
+      // set by the test of pass p-1 while pass p is running.
+      int* snap = d_flag + 2 + (p & 1);
+      if (pair_overlapped(src, dst, B, idx1, -1, snap, rs)) {
         done = 2;
         HIP_CHECK(hipEventRecord(ev_int, st));
         HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
         if (!comm_allreduce_sum(comm, rs, 2, comm_stream)) return 0;                                            // :67, both sweeps
-        check2_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);                     // :69-77
+        check2_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1, snap);               // :69-77
         HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
       }
     }
@@ -749,7 +761,12 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       HIP_CHECK(hipEventRecord(ev[slot], st));
       npoll++;
       if (npoll >= 3) {
+        // INVARIANT (rank lock step): `stop` decides whether this rank issues further passes, i.e. further collectives.  It is a
+        // function of h_flag[2 * old] only: a copy of the device flag taken at a fixed position of the stream (behind the tests of all
+        // passes issued up to poll npoll-3), and the flag is computed from all-reduced sums -- the same bits on every rank.  When the
+        // host gets to look at the copy (skew_wait: a test delays one rank here) cannot change what it reads.
         const int old = (npoll - 3) % POLL_SLOTS;
+        skew_wait();
         HIP_CHECK(hipEventSynchronize(ev[old]));
         if (h_flag[2 * old] != 0) stop = true;
       }
@@ -757,6 +774,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
   if (lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
+  last_lag = lag ? 1 : 0;
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
 
   // which buffer holds the iterate of the last executed sweep?
@@ -797,9 +815,10 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   const int gc = GUIDE;
   hipStream_t st = stream();
   const int* skip = nullptr;
+  reset_ticket();
   if (converge_check) {
     ensure_hist(itr_max + 2);
-    HIP_CHECK(hipMemsetAsync(d_flag, 0, 2 * sizeof(int), st));
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));
     skip = d_flag;
   }
   // :178-186.  ip makes colour 0 the points of even GLOBAL i+j+k; the kernel's parity is relative to kst
@@ -839,12 +858,13 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
       const int p = itr - 1;
       if (p >= 2) HIP_CHECK(hipStreamWaitEvent(st, ev_chk[p & 1], 0));  // the test of iteration itr-2
       double* rs = d_res + ((p & 1) ? 10 : 0);
-      if (pair_overlapped(buf[cur], buf[(cur + 1) % nbuf], B, idx1, rb_par(gc, innerFidx, ip), skip, rs)) {
+      int* snap = d_flag + 2 + (p & 1);  // the flag as the test of iteration itr-2 left it (see CZ::JACOBI)
+      if (pair_overlapped(buf[cur], buf[(cur + 1) % nbuf], B, idx1, rb_par(gc, innerFidx, ip), snap, rs)) {
         flop += 18.0 * npts();
         HIP_CHECK(hipEventRecord(ev_int, st));
         HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
         if (!comm_allreduce_sum(comm, rs, 1, comm_stream)) return 0;
-        check_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+        check_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1, snap);
         HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
         cur = (cur + 1) % nbuf;
         n_fused++;
@@ -916,7 +936,8 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
       HIP_CHECK(hipEventRecord(ev[slot], st));
       npoll++;
       if (npoll >= 3) {
-        const int old = (npoll - 3) % POLL_SLOTS;
+        const int old = (npoll - 3) % POLL_SLOTS;  // same invariant as in CZ::JACOBI: a stream-ordered copy of all-reduced state
+        skew_wait();
         HIP_CHECK(hipEventSynchronize(ev[old]));
         if (h_flag[2 * old] != 0) stop = true;
       }
@@ -924,6 +945,7 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
   if (lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
+  last_lag = lag ? 1 : 0;
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
   if (n_fused > 0) {
     // out-of-place iterations: the iterate of iteration k is in buf[k % nbuf] (launches after convergence were no-ops, or -- lagged
@@ -949,6 +971,7 @@ int CZ::PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double&
   const bool maf = (s_type == LS_PSOR_MAF);  // :108-114
   const int gc = GUIDE;
   hipStream_t st = stream();
+  reset_ticket();
   const int* skip = nullptr;
   if (converge_check) {
     ensure_hist(itr_max + 2);
@@ -988,6 +1011,7 @@ int CZ::PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double&
 int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
   const int gc = GUIDE;
   hipStream_t st = stream();
+  reset_ticket();
   const int n = innerFidx[K_plus] - innerFidx[K_minus] + 1;
   const int pn = pcr_num_stage(n);
   if (pn < 0) {
@@ -1046,6 +1070,7 @@ int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_
 int CZ::LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
   const int gc = GUIDE;
   hipStream_t st = stream();
+  reset_ticket();
   const int n = innerFidx[K_plus] - innerFidx[K_minus] + 1;
   const int pn = pcr_num_stage(n);
   if (pn < 0) {
@@ -1095,6 +1120,7 @@ int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, 
   (void)s_type;
   const int gc = GUIDE;
   hipStream_t st = stream();
+  reset_ticket();
   const int n = innerFidx[K_plus] - innerFidx[K_minus] + 1;
   const int pn = pcr_num_stage(n);  // :535-538
   if (pn < 0) {
@@ -1537,6 +1563,18 @@ void cz_set_quiet(cz_handle* h, int q) { h->cz.quiet = q != 0; }
 void cz_set_debug(cz_handle* h, int m) { h->cz.debug_mode = m; }
 void cz_set_profile(cz_handle* h, int on) { h->cz.profile = on != 0; }
 double cz_last_solve_seconds(const cz_handle* h) { return h->cz.solve_seconds; }
+int cz_info(const cz_handle* h, int what) {
+  const CZ& c = h->cz;
+  switch (what) {
+    case 0: return c.numProc;
+    case 1: return c.pairs_ok ? 1 : 0;
+    case 2: return c.n_shell;
+    case 3: return c.overlap;
+    case 4: return c.last_lag;
+    case 5: return comm_transport_ranks(c.comm);
+    default: return -1;
+  }
+}
 double cz_kernel_ms(const cz_handle* h, const char* label) {
   (void)h;
   double tot = 0.0;

@@ -68,6 +68,9 @@ class CZ {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_shell = nullptr, ev_comm = nullptr, ev_int = nullptr, ev_chk[2] = {nullptr, nullptr};
   bool pairs_ok = true;          // decomposed runs: EVERY brick can run the fused pass (agreed at set-up; the exchange pattern depends on it)
+  int last_lag = 0;              // the last stationary solve ran its all-reduce + test one pass behind (cz_info)
+  int skew_rank = -1, skew_ms = 0;  // CZ_TEST_SKEW=rank,ms: that rank sleeps before each look at the convergence flag (tests)
+  void skew_wait() const;
   int lag_reduce = 1;            // CZ_LAG_REDUCE=0: residual all-reduce + test on the compute stream after every pass (no lag)
   REAL_TYPE* WRK2 = nullptr;     // third rotation buffer of the lagged mode
   int overlap = 1;               // CZ_OVERLAP=0 turns it off (exchange after the whole sweep, same results)

@@ -8,12 +8,8 @@ struct Tuning {
   int fuse_fin = 1;
   int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
                                       // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
-  #ifdef CZ_REAL_IS_DOUBLE
-  int t2_threads = 1024, t2_mv = 2, t2_tj = 64;  // best of tools/tune_jacobi2.py at 512^3 FP64 (profiles/r01)
-#else
-  int t2_threads = 512, t2_mv = 2, t2_tj = 16;   // best at 512^3 FP32
-#endif  // two-sweep kernel: threads, vectors/thread, planes/chunk
-  int t2_band = 1;                                // two-sweep kernel: XCD band mapping of workgroups (CZHIP_T2_BAND)
+  int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
+                                              // the balance model (pair_tj_model, cz_h_launch.h); CZHIP_T2=enable,threads,2,tj fixes them
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
 

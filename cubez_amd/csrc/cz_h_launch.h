@@ -98,15 +98,36 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 }
 
 
-// two fused sweeps; returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
-template <int TB, int MV, int RB>
+// Planes per chunk of the two-stage pass.  A workgroup of chunk length tj costs about tj + 3.5 plane steps (two redundant planes and
+// the un-overlapped prologue); each XCD serves its band of segments with num_cu/8 * wg_per_cu resident workgroups, so a launch takes
+// ceil(band * nchunk / slots) rounds of that (tools/pair_lab sweeps, profiles/r02/pair_lab_sweep_*.txt: the model ranks the measured
+// times of both shapes and both precisions).  Returns the cost in units of plane steps; *tj_out the best chunk length.
+inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, int* tj_out) {
+  const int band = (nseg + 7) / 8;
+  const int slots = std::max(1, ctx.num_cu / 8) * wg_per_cu;
+  double best = 1e300;
+  int best_tj = std::min(16, nplanes);
+  for (int tj = std::min(12, nplanes); tj <= std::min(nplanes, 128); tj++) {
+    const int nchunk = (nplanes + tj - 1) / tj;
+    if (tj > 12 && (nplanes + tj - 2) / (tj - 1) == nchunk) continue;  // a shorter chunk gives the same count: not a candidate
+    const long long items = (long long)band * nchunk;
+    const double cost = (double)((items + slots - 1) / slots) * (tj + 3.5);
+    if (cost < best) best = cost, best_tj = tj;
+  }
+  *tj_out = best_tj;
+  return best;
+}
+
+// two fused sweeps (jacobi2p_k); returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
+template <int TB, int MV, int RB, int ZU>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
-                         const int* skip, const Fin2& fin_in, int par, int zero_u, bool probe) {
+                         const int* skip, const Fin2& fin_in, int par, bool probe, double* model_cost) {
   constexpr int V = VW;
   Geom2 g;
   g.R = b.nkp / V;
-  if (2 * g.R >= TB * MV / 2 || g.R > TB) return false;  // halo rows would dominate / do not fit the loader
+  if (2 * g.R > TB || 4 * g.R >= TB * MV) return false;  // the outer rows are staged by 2R threads / halo rows would dominate
   g.PSV = (long long)g.R * b.nip;
+  if (g.PSV * (long long)sizeof(Vec<V>) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
   g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
   g.F0 = (long long)b.ii0 * g.R;
   g.Fend = (long long)(b.ii1 + 1) * g.R;
@@ -115,30 +136,26 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   g.Fenda = (long long)(ba.ii1 + 1) * g.R;
   g.S = TB * MV - 2 * g.R;
   g.par = par;
-  g.zero_u = zero_u;
+  g.zero_u = ZU;
   const long long nf = g.Fend - g.F0;
   g.nseg = (int)((nf + g.S - 1) / g.S);
   const int nplanes = b.jj1 - b.jj0 + 1;
-  int tj = tj_req;
-  if (tj <= 0) tj = 16;
-  if (tj > nplanes) tj = nplanes;
-  g.TJ = tj;
-  int nchunk = (nplanes + tj - 1) / tj;
-  long long nblk;
-  g.band = (ctx.tune.t2_band && g.nseg >= 8) ? 1 : 0;
-  if (g.band) {
-    nblk = 8LL * ((g.nseg + 7) / 8) * nchunk;
-  } else {
-    if (((long long)nchunk * g.nseg) % 8 != 0 && nchunk >= 8) nchunk = ((nchunk + 7) / 8) * 8;
-    nblk = (long long)nchunk * g.nseg;
-  }
   const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double);
   if (lds > 160 * 1024) return false;
+  const int wg_per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / TB));
+  int tj = tj_req;
+  const double cost = pair_tj_model(g.nseg, nplanes, wg_per_cu, tj > 0 ? &g.TJ : &tj);
+  if (model_cost) *model_cost = cost * wg_per_cu * (double)(TB * MV + g.S);  // plane steps x work per CU and step
+  if (tj > nplanes) tj = nplanes;
+  g.TJ = tj;
+  const int nchunk = (nplanes + tj - 1) / tj;
+  g.band = 1;
+  const long long nblk = 8LL * ((g.nseg + 7) / 8) * nchunk;
   if (probe) return true;
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2_k<V, TB, MV, RB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
@@ -146,7 +163,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   fin.counter = ctx.counter;
   {
     ScopedTimer tm(RB ? LBL_RBSOR2 : LBL_JACOBI2);
-    hipLaunchKernelGGL((jacobi2_k<V, TB, MV, RB>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
+    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
   }
   HIP_CHECK(hipGetLastError());
   return true;
@@ -163,11 +180,22 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   // the two-stage march reads two layers around the box
   if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
   const Tuning& tu = ctx.tune;
-#define CZ_INST2(TB_, MV_) \
-  if (tu.t2_threads == TB_ && tu.t2_mv == MV_) return launch_jacobi2_inst<TB_, MV_, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u, probe);
-  CZ_INST2(256, 4) CZ_INST2(512, 2) CZ_INST2(512, 3) CZ_INST2(1024, 2)
-#undef CZ_INST2
-  return launch_jacobi2_inst<512, 2, RB>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, zero_u, probe);
+  // shape: 512 threads (two workgroups per CU) or 1024 threads (one, less redundant first-stage work); fixed by CZHIP_T2 or chosen by the
+  // cost model of pair_tj_model
+  int tb = tu.t2_threads;
+  if (tb == 0) {
+    double c512 = 0.0, c1024 = 0.0;
+    const bool ok512 = launch_jacobi2_inst<512, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, true, &c512);
+    const bool ok1024 = launch_jacobi2_inst<1024, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, true, &c1024);
+    if (!ok512 && !ok1024) return false;
+    tb = (ok512 && (!ok1024 || c512 <= c1024)) ? 512 : 1024;
+  }
+  if (RB == 0 && zero_u) {
+    if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+    return launch_jacobi2_inst<1024, 2, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+  }
+  if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+  return launch_jacobi2_inst<1024, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
 }
 
 // the shell boxes of a decomposed brick, all in one launch (pair_shell_k); boxes: n x (ist,ied,jst,jed,kst,ked), 1-based

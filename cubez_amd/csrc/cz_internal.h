@@ -42,9 +42,10 @@ void pcr_rb_async(CZ_REAL* x, const CZ_REAL* msk, const CZ_REAL* rhs, const int*
 void pcr_variant_async(CZ_REAL* x, CZ_REAL* wout, const CZ_REAL* msk, const CZ_REAL* rhs, const int* sz, const int* idx, int g, int pn,
                        int order, int sel, int final4, CZ_REAL omg, double* res_dev, int accumulate);
 void check2_on_stream(hipStream_t st, const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
-                      int* conv_itr_dev);
+                      int* conv_itr_dev, int* snap_dev);
 void check_on_stream(hipStream_t st, const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
-                     int* conv_itr_dev);
+                     int* conv_itr_dev, int* snap_dev);
+void reset_ticket();
 void pcr_maf_async(CZ_REAL* x, const CZ_REAL* msk, const CZ_REAL* rhs, const int* sz, const int* idx, int g, int pn, int order, int sel,
                    const CZ_REAL* xc, const CZ_REAL* yc, const CZ_REAL* zc, CZ_REAL omg, double* res_dev, int accumulate);
 void imask_async(CZ_REAL* x, const int* sz, const int* idx, int g);

@@ -12,37 +12,43 @@ reduce_partials_k(const double* __restrict__ partials, int n, double* __restrict
   if (threadIdx.x == 0) dst[0] = accumulate ? dst[0] + s : s;
 }
 
-// cz_Poisson.cpp:67-77 on the device
+// cz_Poisson.cpp:67-77 on the device.  snap (optional) receives the flag as it stands after this test: the lagged loops of
+// CZ::JACOBI / CZ::RBSOR hand that copy -- which no later test can change -- to the pass two passes further on, so that every
+// workgroup of a pass sees the same value (the flag itself may be rewritten by the next test while the pass is running).
 __global__ void check_k(const double* res_dev, double res_normal, double eps, int itr, double* hist, int* flag,
-                        int* conv_itr) {
-  if (*flag != 0) return;
-  double r = res_dev[0];
-  r *= res_normal;
-  r = sqrt(r);
-  hist[itr] = r;
-  if (r < eps) {
-    *flag = 1;
-    *conv_itr = itr;
+                        int* conv_itr, int* snap) {
+  if (*flag == 0) {
+    double r = res_dev[0];
+    r *= res_normal;
+    r = sqrt(r);
+    hist[itr] = r;
+    if (r < eps) {
+      *flag = 1;
+      *conv_itr = itr;
+    }
   }
+  if (snap) *snap = *flag;
 }
 
 // the same bookkeeping for a fused pair (iterations itr, itr+1) whose two sums were all-reduced first
 __global__ void check2_k(const double* res_dev, double res_normal, double eps, int itr, double* hist, int* flag,
-                         int* conv_itr) {
-  if (*flag != 0) return;
-  double r = sqrt(res_dev[0] * res_normal);
-  hist[itr] = r;
-  if (r < eps) {
-    *flag = 1;
-    *conv_itr = itr;
-    return;
+                         int* conv_itr, int* snap) {
+  if (*flag == 0) {
+    double r = sqrt(res_dev[0] * res_normal);
+    hist[itr] = r;
+    if (r < eps) {
+      *flag = 1;
+      *conv_itr = itr;
+    } else {
+      r = sqrt(res_dev[1] * res_normal);
+      hist[itr + 1] = r;
+      if (r < eps) {
+        *flag = 1;
+        *conv_itr = itr + 1;
+      }
+    }
   }
-  r = sqrt(res_dev[1] * res_normal);
-  hist[itr + 1] = r;
-  if (r < eps) {
-    *flag = 1;
-    *conv_itr = itr + 1;
-  }
+  if (snap) *snap = *flag;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -73,6 +73,58 @@ __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, 
   return o;
 }
 
+// The workgroup whose ticket came last sums all per-workgroup partials in a fixed order (sc1 loads, see stencil_k) and does the
+// bookkeeping of cz_Poisson.cpp:67-77 for the one or two iterations of the pass.  Called by every thread of that workgroup.
+template <int TB>
+__device__ __forceinline__ void pair_finalize(const double* partials, int nblk, const Fin2& fin, double* wsum) {
+  const int t = threadIdx.x;
+  double x1 = 0.0, x2 = 0.0;
+  for (int i = t; i < nblk; i += TB) {
+    x1 += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x2 += __hip_atomic_load(&partials[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int i = t; i < fin.n_extra; i += TB) {  // written by an earlier launch on this stream
+    x1 += fin.extra[i];
+    x2 += fin.extra[fin.n_extra + i];
+  }
+  __syncthreads();
+  const double t1 = block_sum<TB>(x1, wsum);
+  __syncthreads();
+  const double t2 = block_sum<TB>(x2, wsum);
+  if (t == 0 && fin.single) {
+    const double tot = t1 + t2;  // colour 0 + colour 1 (cz_Poisson.cpp:205-209 accumulate into one res)
+    fin.dst[0] = tot;
+    if (fin.do_check) {
+      const double r = sqrt(tot * fin.res_normal);
+      fin.hist[fin.itr] = r;
+      if (r < fin.eps) {
+        *fin.flag = 1;
+        *fin.conv_itr = fin.itr;
+      }
+    }
+    *fin.counter = 0u;
+  } else if (t == 0) {
+    fin.dst[0] = t1;
+    fin.dst[1] = t2;
+    if (fin.do_check) {  // cz_Poisson.cpp:69-77 for iteration itr, then itr+1
+      double r = sqrt(t1 * fin.res_normal);
+      fin.hist[fin.itr] = r;
+      if (r < fin.eps) {
+        *fin.flag = 1;
+        *fin.conv_itr = fin.itr;
+      } else {
+        r = sqrt(t2 * fin.res_normal);
+        fin.hist[fin.itr + 1] = r;
+        if (r < fin.eps) {
+          *fin.flag = 1;
+          *fin.conv_itr = fin.itr + 1;
+        }
+      }
+    }
+    *fin.counter = 0u;
+  }
+}
+
 // RB = 0: two Jacobi sweeps.  RB = 1: one red-black SOR iteration (cz_solver.f90:466-480 for colour 0 then colour 1):
 // stage 1 updates the points of colour 0, stage 2 those of colour 1 from the freshly updated colour-0 neighbours; the
 // other colour passes through each stage unchanged.  Out of place (U -> W) like the Jacobi pair.
@@ -277,53 +329,7 @@ jacobi2_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restri
     *last_flag = (ticket == (unsigned)nblk - 1u);
   }
   __syncthreads();
-  if (*last_flag) {
-    double x1 = 0.0, x2 = 0.0;
-    for (int i = t; i < nblk; i += TB) {
-      x1 += __hip_atomic_load(&partials[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      x2 += __hip_atomic_load(&partials[nblk + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (int i = t; i < fin.n_extra; i += TB) {  // written by an earlier launch on this stream
-      x1 += fin.extra[i];
-      x2 += fin.extra[fin.n_extra + i];
-    }
-    __syncthreads();
-    const double t1 = block_sum<TB>(x1, wsum);
-    __syncthreads();
-    const double t2 = block_sum<TB>(x2, wsum);
-    if (t == 0 && fin.single) {
-      const double tot = t1 + t2;  // colour 0 + colour 1 (cz_Poisson.cpp:205-209 accumulate into one res)
-      fin.dst[0] = tot;
-      if (fin.do_check) {
-        const double r = sqrt(tot * fin.res_normal);
-        fin.hist[fin.itr] = r;
-        if (r < fin.eps) {
-          *fin.flag = 1;
-          *fin.conv_itr = fin.itr;
-        }
-      }
-      *fin.counter = 0u;
-    } else if (t == 0) {
-      fin.dst[0] = t1;
-      fin.dst[1] = t2;
-      if (fin.do_check) {  // cz_Poisson.cpp:69-77 for iteration itr, then itr+1
-        double r = sqrt(t1 * fin.res_normal);
-        fin.hist[fin.itr] = r;
-        if (r < fin.eps) {
-          *fin.flag = 1;
-          *fin.conv_itr = fin.itr;
-        } else {
-          r = sqrt(t2 * fin.res_normal);
-          fin.hist[fin.itr + 1] = r;
-          if (r < fin.eps) {
-            *fin.flag = 1;
-            *fin.conv_itr = fin.itr + 1;
-          }
-        }
-      }
-      *fin.counter = 0u;
-    }
-  }
+  if (*last_flag) pair_finalize<TB>(partials, nblk, fin, wsum);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,291 @@
+// cz_k_pair2.h -- part of cz_kernels.hip (ONE translation unit per precision; included inside its anonymous namespace after
+// cz_k_pair.h): jacobi2p_k, the software-pipelined form of the two-stage pass (two Jacobi sweeps / one red-black iteration
+// per pass over memory; cz_solver.f90:334-351, 466-480).
+// ------------------------------------------------------------------------------------------------------------
+// Same tiling, same per-point arithmetic and the same results as jacobi2_k (cz_k_pair.h) -- what changes is WHEN things move:
+//   * the loads of plane q+2 of u and of plane q+1 of b are issued at the top of step q and consumed in step q+1 (one plane
+//     of prefetch).  jacobi2_k issued the loads of a step and waited for them a few instructions later, and the compiler's
+//     s_waitcnt vmcnt(0) in front of the LDS publish drained the step's W stores as well: a memory round trip and a store
+//     round trip on the critical path of every plane (profiles/r02/isa_notes.md).  Here every global access of the main loop
+//     is unconditional (clamped addresses instead of predicates), so the compiler can count the younger loads and wait with
+//     vmcnt(N > 0).
+//   * the registers for that come from the j-1 operands: u(q-1) and v(q-2) of the thread's own vectors are re-read from the
+//     LDS buffer that still holds them (same thread wrote them, same thread overwrites them later in program order) instead
+//     of being carried in two register queues.
+//   * the vector-crossing k neighbours come from the lane next door (DPP wave shift) with one broadcast LDS read per wave for
+//     the lane at the end of the wave, instead of two stride-4 ds_read_b32 per vector (4-way bank conflicts, 32 % of all LDS
+//     cycles in jacobi2_k, profiles/r01/pmc_jacobi2_512_f32.csv).
+// LDS: u(q) on E2 = own segment +- 2 rows and u(q-1), v(q-1) on E1 = own +- 1 row and v(q-2); two buffers each, one barrier
+// per plane.
+// ------------------------------------------------------------------------------------------------------------
+template <int V>
+__device__ __forceinline__ Vec<V> ld16(const char* plane, unsigned byte_off) {
+  typedef typename NatVec<V>::type nv;
+  const nv x = *reinterpret_cast<const nv*>(plane + byte_off);
+  Vec<V> r;
+  __builtin_memcpy(&r, &x, sizeof(r));
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void st16(char* plane, unsigned byte_off, const Vec<V>& x) {
+  typedef typename NatVec<V>::type nv;
+  nv y;
+  __builtin_memcpy(&y, &x, sizeof(y));
+  *reinterpret_cast<nv*>(plane + byte_off) = y;
+}
+
+// one ds_read_b128 per vector: left to itself the compiler re-reads overlapping pieces of a vector with ds_read_b32 / ds_read2_b32
+// (operand pairs for packed FP32 math) -- stride-16-byte scalar reads, i.e. the 4-way bank conflicts this kernel set out to remove
+template <int V>
+__device__ __forceinline__ Vec<V> lds_ld(const Vec<V>* p) {
+  typedef typename NatVec<V>::type nv;
+  nv x = *reinterpret_cast<const nv*>(p);
+  asm("" : "+v"(x));  // the value is needed whole, in consecutive registers: keeps the read one ds_read_b128
+  Vec<V> r;
+  __builtin_memcpy(&r, &x, sizeof(r));
+  return r;
+}
+
+// value of `x` in the previous (SHR) / next (SHL) lane of the wave; lane 0 / lane 63 receive `edge`
+__device__ __forceinline__ float lane_shr1(float edge, float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_shl1(float edge, float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double lane_shr1(double edge, double x) {
+  const long long e = __builtin_bit_cast(long long, edge), v = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp((int)e, (int)v, 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(v >> 32), 0x138, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double lane_shl1(double edge, double x) {
+  const long long e = __builtin_bit_cast(long long, edge), v = __builtin_bit_cast(long long, x);
+  const int lo = __builtin_amdgcn_update_dpp((int)e, (int)v, 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(e >> 32), (int)(v >> 32), 0x130, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// ZU = 1: the input field is identically zero and is not read (the first pair of a preconditioner solve).
+template <int V, int TB, int MV, int RB, int ZU>
+__global__ void __launch_bounds__(TB, TB == 512 ? 4 : 1)
+jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
+           const int* __restrict__ skip, Fin2 fin) {
+  if (skip != nullptr && *skip != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int R = g.R;
+  constexpr int LV = TB * MV;       // E1: own segment +- one row (S = LV - 2R)
+  const int LU = LV + 2 * R;        // E2: own segment +- two rows
+  Vec<V>* ldsU = reinterpret_cast<Vec<V>*>(smem);                   // 2 buffers of LU vectors
+  Vec<V>* ldsV = ldsU + (size_t)2 * LU;                              // 2 buffers of LV vectors
+  double* wsum = reinterpret_cast<double*>(ldsV + (size_t)2 * LV);   // 16 doubles + flag
+
+  int lb = blockIdx.x;
+  const int nblk = gridDim.x;
+  int seg, chunk;
+  {
+    // XCD bands (see jacobi2_k): XCD x owns a contiguous band of segments of every chunk and walks it chunk by chunk
+    const int x = lb & 7, r = lb >> 3;
+    const int base = g.nseg >> 3, rem = g.nseg & 7, bmax = base + (rem ? 1 : 0);
+    const int blen = base + (x < rem ? 1 : 0);
+    const int sl = r % bmax;
+    chunk = r / bmax;
+    seg = (sl < blen) ? x * base + min(x, rem) + sl : g.nseg;  // nseg = no work
+  }
+  const long long fb = (seg < g.nseg) ? g.F0 + (long long)seg * g.S : g.Fend;
+  const int ja = g.jj0 + chunk * g.TJ;
+  int jb = ja + g.TJ - 1;
+  if (jb > g.jj1) jb = g.jj1;
+
+  double acc1 = 0.0, acc2 = 0.0;
+
+  if (ja <= jb && fb < g.Fend) {
+    const long long e1_0 = fb - R;      // first vector of E1
+    const long long e2_0 = fb - 2 * R;  // first vector of E2
+    const long long vlast = g.PSV - 1;
+    const size_t PB = (size_t)g.PSV * sizeof(Vec<V>);  // bytes per plane
+    unsigned bo[MV];   // byte offset of the thread's m-th vector inside a plane (clamped into the plane: such lanes are masked)
+    unsigned ka[MV];   // stage-1 bits: components of the vector inside the stage-1 box (0 when the row is outside)
+    unsigned own[MV];  // stage-2 bits if this workgroup owns the vector (stores, residual counts), else 0
+    int pbase[MV];     // RB: (kk + ii + par) of component 0; component cc on plane jj has colour (pbase + cc + jj) & 1
+#pragma unroll
+    for (int m = 0; m < MV; m++) {
+      const int e = t + m * TB;
+      const long long f = e1_0 + e;
+      const long long fc = f < vlast ? f : vlast;
+      bo[m] = (unsigned)(fc * (long long)sizeof(Vec<V>));
+      const long long row = f / R;
+      const int kv = (int)(f - row * R);
+      unsigned bits1 = 0, bits2 = 0;
+#pragma unroll
+      for (int cc = 0; cc < V; cc++) {
+        const int kk = kv * V + cc;
+        if (kk >= g.kk0a && kk <= g.kk1a) bits1 |= 1u << cc;
+        if (kk >= g.kk0 && kk <= g.kk1) bits2 |= 1u << cc;
+      }
+      pbase[m] = kv * V + (int)row + g.par;
+      ka[m] = (f >= g.F0a && f < g.Fenda) ? bits1 : 0u;
+      own[m] = (e >= R && e < LV - R && f >= g.F0 && f < g.Fend) ? bits2 : 0u;
+    }
+    // the two outer rows of E2: the first R threads stage the lower one, the last R threads the upper one (2R <= TB)
+    const bool has_halo = (t < R) || (t >= TB - R);
+    const int hl = (t < R) ? t : (LV + R + (t - (TB - R)));  // index inside an LDS u buffer
+    unsigned hbo;
+    {
+      long long fh = e2_0 + hl;
+      if (!has_halo) fh = e1_0 + t;
+      if (fh > vlast) fh = vlast;
+      hbo = (unsigned)(fh * (long long)sizeof(Vec<V>));
+    }
+    const char* Ub = reinterpret_cast<const char*>(U);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    char* Wb = reinterpret_cast<char*>(W);
+
+    // Register sets.  Two of each, used alternately by even and odd steps, so that nothing in flight is ever copied (a v_mov of a
+    // register with a pending load would wait for it): u(q+1) / u(q+2) and b(q) / b(q+1).
+    Vec<V> uA[MV], uB[MV], bA[MV], bB[MV], b2[MV], vc[MV], hx;
+    // prologue: LDS_U[1] <- u(ja-2) (own vectors), LDS_U[0] <- u(ja-1) on E2; in flight: u(ja) and b(ja-1)
+    {
+      const char* P2 = Ub + (size_t)(ja - 2) * PB;
+      const char* P1 = Ub + (size_t)(ja - 1) * PB;
+      const char* P0 = Ub + (size_t)ja * PB;
+      const char* Q1 = Bb + (size_t)(ja - 1) * PB;
+      Vec<V> t2[MV], t1[MV], h1;
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        t2[m] = ZU ? zerov<V>() : ld16<V>(P2, bo[m]);
+        t1[m] = ZU ? zerov<V>() : ld16<V>(P1, bo[m]);
+      }
+      h1 = ZU ? zerov<V>() : ld16<V>(P1, hbo);
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        uA[m] = ZU ? zerov<V>() : ld16<V>(P0, bo[m]);
+        bA[m] = ld16<V>(Q1, bo[m]);
+        b2[m] = zerov<V>();
+      }
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        ldsU[LU + R + t + m * TB] = t2[m];
+        ldsU[R + t + m * TB] = t1[m];
+      }
+      if (has_halo) ldsU[hl] = h1;
+    }
+    __syncthreads();
+
+    // One plane step.  cur: LDS buffer holding u(q) / v(q-1).  uc = u(q+1) and b1 = b(q) were requested one step ago; un, hn, bn
+    // receive this step's requests (u(q+2), b(q+1)).
+    auto step = [&](const int q, const int cur, Vec<V>* uc, Vec<V>* un, Vec<V>* b1, Vec<V>* bn) __attribute__((always_inline)) {
+      const bool plane_inner = (q >= g.jj0a && q <= g.jj1a);
+      const bool count1 = (q >= ja && q <= jb);
+      const bool do2 = (q - 1 >= ja);
+      // ---- requests for the NEXT step (the last step re-reads a plane it already has: no branch around a load)
+      {
+        const int qu = (q + 2 <= jb + 2) ? q + 2 : jb + 2;
+        const int qb = (q + 1 <= jb + 1) ? q + 1 : jb + 1;
+        const char* Un = Ub + (size_t)qu * PB;
+        const char* Bn = Bb + (size_t)qb * PB;
+        // the outer rows of u(q+1) go to LDS at the end of THIS step (one register set; the oldest request of the step)
+        hx = ZU ? zerov<V>() : ld16<V>(Ub + (size_t)(q + 1) * PB, hbo);
+#pragma unroll
+        for (int m = 0; m < MV; m++) un[m] = ZU ? zerov<V>() : ld16<V>(Un, bo[m]);
+#pragma unroll
+        for (int m = 0; m < MV; m++) bn[m] = ld16<V>(Bn, bo[m]);
+      }
+      const Vec<V>* cU = ldsU + (size_t)cur * LU;        // u(q) on E2
+      Vec<V>* pU = ldsU + (size_t)(cur ^ 1) * LU;        // u(q-1), own vectors; receives u(q+1)
+      const Vec<V>* cV = ldsV + (size_t)cur * LV;        // v(q-1) on E1
+      Vec<V>* pV = ldsV + (size_t)(cur ^ 1) * LV;        // v(q-2), own vectors; receives v(q)
+      const int w0 = (t & ~63);                          // first lane of the wave
+
+      // ---- stage 1: v(q) on E1
+      if (plane_inner) {
+#pragma unroll
+        for (int m = 0; m < MV; m++) {
+          const int x = R + t + m * TB;
+          const int xw = R + w0 + m * TB;
+          const Vec<V> pc = lds_ld<V>(cU + x);
+          const Vec<V> im = lds_ld<V>(cU + x - R);
+          const Vec<V> ip = lds_ld<V>(cU + x + R);
+          const Vec<V> pm = lds_ld<V>(pU + x);
+          // the k neighbours beyond the ends of the wave's run of vectors: one broadcast read per wave, the rest from the next lane
+          const REAL elo = reinterpret_cast<const REAL*>(cU)[(size_t)xw * V - 1];
+          const REAL ehi = reinterpret_cast<const REAL*>(cU)[(size_t)(xw + 64) * V];
+          const REAL kl = lane_shr1(elo, pc.v[V - 1]);
+          const REAL kr = lane_shl1(ehi, pc.v[0]);
+          unsigned msk = ka[m];
+          if (RB) msk &= colour_bits<V>(pbase[m] + q);  // colour 0 on plane q
+          vc[m] = relax_vec<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], c, msk, count1 ? (own[m] & msk) : 0u, acc1);
+        }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MV; m++) vc[m] = lds_ld<V>(cU + R + t + m * TB);  // outside the stage-1 box: the first sweep leaves the plane alone
+      }
+
+      // ---- stage 2: w(q-1) on the own segment
+      if (do2) {
+        char* Wq = Wb + (size_t)(q - 1) * PB;
+#pragma unroll
+        for (int m = 0; m < MV; m++) {
+          const int e = t + m * TB;
+          const int ew = w0 + m * TB;
+          // (all lanes: the lane shifts need every lane's own value)
+          const REAL elo = reinterpret_cast<const REAL*>(cV)[ew > 0 ? (size_t)ew * V - 1 : 0];
+          const REAL ehi = reinterpret_cast<const REAL*>(cV)[ew + 64 < LV ? (size_t)(ew + 64) * V : 0];
+          const Vec<V> vb = lds_ld<V>(cV + e);  // v(q-1) of the own vector
+          const REAL kl = lane_shr1(elo, vb.v[V - 1]);
+          const REAL kr = lane_shl1(ehi, vb.v[0]);
+          if (own[m] != 0) {
+            const Vec<V> im = lds_ld<V>(cV + e - R);
+            const Vec<V> ip = lds_ld<V>(cV + e + R);
+            const Vec<V> pm = lds_ld<V>(pV + e);
+            unsigned m2 = own[m];
+            if (RB) m2 &= colour_bits<V>(pbase[m] + q);  // colour 1 on plane q-1
+            const Vec<V> o = relax_vec<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], c, m2, m2, acc2);
+            if (own[m] == (1u << V) - 1) {
+              st16<V>(Wq, bo[m], o);
+            } else {
+              REAL* wp = reinterpret_cast<REAL*>(Wq + bo[m]);
+#pragma unroll
+              for (int cc = 0; cc < V; cc++)
+                if (own[m] & (1u << cc)) wp[cc] = o.v[cc];
+            }
+          }
+        }
+      }
+
+      // ---- publish v(q) and the next u centre plane (u(q+1), requested one step ago)
+#pragma unroll
+      for (int m = 0; m < MV; m++) pV[t + m * TB] = vc[m];
+#pragma unroll
+      for (int m = 0; m < MV; m++) pU[R + t + m * TB] = uc[m];
+      if (has_halo) pU[hl] = hx;
+#pragma unroll
+      for (int m = 0; m < MV; m++) b2[m] = b1[m];  // b(q) for the next step's stage 2 (complete: stage 1 used it)
+      __syncthreads();
+    };
+
+    for (int q = ja - 1;; q += 2) {
+      step(q, 0, uA, uB, bA, bB);
+      if (q + 1 > jb + 1) break;
+      step(q + 1, 1, uB, uA, bB, bA);
+      if (q + 2 > jb + 1) break;
+    }
+  }
+
+  // ---- residuals: per-workgroup partials, finalised by the last workgroup (write-through hand-off, see stencil_k)
+  __syncthreads();
+  const double s1 = block_sum<TB>(acc1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<TB>(acc2, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  if (t == 0) {
+    __hip_atomic_store(&partials[lb], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[nblk + lb], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (ticket == (unsigned)nblk - 1u);
+  }
+  __syncthreads();
+  if (*last_flag) pair_finalize<TB>(partials, nblk, fin, wsum);
+}

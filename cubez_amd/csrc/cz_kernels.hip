@@ -38,6 +38,7 @@ namespace {
 #include "cz_k_common.h"
 #include "cz_k_stencil.h"
 #include "cz_k_pair.h"
+#include "cz_k_pair2.h"
 #include "cz_k_linesor.h"
 #include "cz_k_blas.h"
 #include "cz_h_ctx.h"
@@ -160,7 +161,6 @@ int czhip_init(int device) {
     const int n = sscanf(t2, "%d,%d,%d,%d", &en, &a, &b2, &c2);
     if (n >= 1) czhip_set_tuning2(n >= 2 ? a : 0, n >= 3 ? b2 : 0, n >= 4 ? c2 : -1, en);
   }
-  if (const char* bd = getenv("CZHIP_T2_BAND")) ctx.tune.t2_band = atoi(bd);
   if (const char* pc = getenv("CZHIP_PCR")) {  // "fast[,variant]"
     int f = 1, v = 0;
     sscanf(pc, "%d,%d", &f, &v);
@@ -413,11 +413,11 @@ int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable) {
   Tuning t = ctx.tune;
   if (threads > 0) t.t2_threads = threads;
+  if (threads == -2) t.t2_threads = 0;  // chosen per launch
   if (vec_per_thread > 0) t.t2_mv = vec_per_thread;
-  if (planes_per_chunk >= 0) t.t2_tj = planes_per_chunk;
+  if (planes_per_chunk >= 0) t.t2_tj = planes_per_chunk;  // 0: chosen per launch
   if (enable >= 0) t.use_t2 = enable;
-  const int k = t.t2_threads * 100 + t.t2_mv;
-  if (k != 25604 && k != 51202 && k != 51203 && k != 102402) return 1;
+  if ((t.t2_threads != 0 && t.t2_threads != 512 && t.t2_threads != 1024) || t.t2_mv != 2) return 1;
   ctx.tune = t;
   return 0;
 }
@@ -437,14 +437,14 @@ int czhip_set_pcr_mode(int form, int variant) {
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev) {
   ensure_init();
-  hipLaunchKernelGGL(check2_k, dim3(1), dim3(1), 0, ctx.stream, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+  hipLaunchKernelGGL(check2_k, dim3(1), dim3(1), 0, ctx.stream, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev, (int*)nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
 void czhip_check_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                        int* conv_itr_dev) {
   ensure_init();
-  hipLaunchKernelGGL(check_k, dim3(1), dim3(1), 0, ctx.stream, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+  hipLaunchKernelGGL(check_k, dim3(1), dim3(1), 0, ctx.stream, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev, (int*)nullptr);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -878,18 +878,25 @@ void pcr_variant_async(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, co
   ensure_init();
   launch_pcr_variant(x, wout, msk, rhs, make_box(sz, idx, g), idx, pn, order, sel, final4, omg, res_dev, accumulate);
 }
-// the bookkeeping of a fused pair on another stream of the caller (decomposed runs: all-reduce + test on the exchange stream)
+// the bookkeeping of a fused pair on another stream of the caller (decomposed runs: all-reduce + test on the exchange stream);
+// snap_dev: see check_k
 void check2_on_stream(hipStream_t st, const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
-                      int* conv_itr_dev) {
+                      int* conv_itr_dev, int* snap_dev) {
   ensure_init();
-  hipLaunchKernelGGL(check2_k, dim3(1), dim3(1), 0, st, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+  hipLaunchKernelGGL(check2_k, dim3(1), dim3(1), 0, st, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev, snap_dev);
   HIP_CHECK(hipGetLastError());
 }
 void check_on_stream(hipStream_t st, const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
-                     int* conv_itr_dev) {
+                     int* conv_itr_dev, int* snap_dev) {
   ensure_init();
-  hipLaunchKernelGGL(check_k, dim3(1), dim3(1), 0, st, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev);
+  hipLaunchKernelGGL(check_k, dim3(1), dim3(1), 0, st, res_dev, res_normal, eps, itr, hist_dev, flag_dev, conv_itr_dev, snap_dev);
   HIP_CHECK(hipGetLastError());
+}
+// Start of a solve: the arrival ticket of the in-kernel finalisations back to zero.  A launch that was cut short (a lagged pass
+// overtaken by convergence in an older build, an aborted solve) must not leave a count behind for the next solve on this context.
+void reset_ticket() {
+  ensure_init();
+  HIP_CHECK(hipMemsetAsync(ctx.counter, 0, 64, ctx.stream));
 }
 // MAF line solvers: order 0 = colour `sel` in place, 1 = lexicographic in place; xc, yc, zc device arrays
 void pcr_maf_async(REAL* x, const REAL* msk, const REAL* rhs, const int* sz, const int* idx, int g, int pn, int order, int sel,

@@ -5,6 +5,11 @@
 // Multi-GPU: one process per GPU.  Instead of mpirun/MPI_Init (main.cpp:33-35) the ranks are started by any launcher
 // that exports RANK, WORLD_SIZE and LOCAL_RANK (e.g. `python -m torch.distributed.run --no-python ...`); rank 0
 // writes the RCCL unique id to $CZ_COMM_ID_FILE (default /tmp/cz_comm_id.$MASTER_PORT) and the others read it.
+// The file starts with a job key -- $CZ_JOB_ID, or MASTER_ADDR:MASTER_PORT:<pid of the launcher, the ranks' common parent> --
+// and a reader keeps polling until the key is its own: a file left behind by an earlier job on the same port is never
+// joined.  Rank 0 removes any old file first and creates the new one exclusively, mode 0600 (no symlink is followed).
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -46,30 +51,42 @@ int main(int argc, char* argv[]) {
     const int nb = cz_comm_unique_id_bytes();
     std::vector<char> id(nb);
     const std::string path = id_file();
+    char key[256];
+    if (getenv("CZ_JOB_ID")) snprintf(key, sizeof(key), "%s", getenv("CZ_JOB_ID"));
+    else snprintf(key, sizeof(key), "%s:%s:%ld", getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "-", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0", (long)getppid());
+    std::vector<char> rec(sizeof(key) + nb, 0);
+    bool ok = true;
     if (myRank == 0) {
       cz_comm_get_unique_id(id.data());
+      memcpy(rec.data(), key, sizeof(key));
+      memcpy(rec.data() + sizeof(key), id.data(), nb);
       const std::string tmp = path + ".tmp";
-      FILE* f = fopen(tmp.c_str(), "wb");
-      if (!f || fwrite(id.data(), 1, nb, f) != (size_t)nb) {
-        printf("\tcannot write %s\n", tmp.c_str());
-        return -1;
+      unlink(path.c_str());  // a file an earlier job left behind
+      unlink(tmp.c_str());
+      const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+      if (fd < 0 || write(fd, rec.data(), rec.size()) != (ssize_t)rec.size() || close(fd) != 0 || rename(tmp.c_str(), path.c_str()) != 0) {
+        printf("\tcannot write %s\n", path.c_str());
+        ok = false;
       }
-      fclose(f);
-      rename(tmp.c_str(), path.c_str());
     } else {
-      FILE* f = nullptr;
-      for (int tries = 0; tries < 600 && !(f = fopen(path.c_str(), "rb")); tries++) usleep(100000);
-      if (!f || fread(id.data(), 1, nb, f) != (size_t)nb) {
-        printf("\trank %d: cannot read %s\n", myRank, path.c_str());
-        return -1;
+      ok = false;
+      for (int tries = 0; tries < 600 && !ok; tries++) {  // 60 s
+        const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
+        if (fd >= 0) {
+          if (read(fd, rec.data(), rec.size()) == (ssize_t)rec.size() && !strncmp(rec.data(), key, sizeof(key))) ok = true;
+          close(fd);
+        }
+        if (!ok) usleep(100000);
       }
-      fclose(f);
+      if (ok) memcpy(id.data(), rec.data() + sizeof(key), nb);
+      else printf("\trank %d: no communicator id for job %s in %s after 60 s\n", myRank, key, path.c_str());
     }
-    cz_comm_bootstrap(myRank, nproc, id.data());
-    if (myRank == 0) {
-      usleep(2000000);
-      unlink(path.c_str());
+    if (!ok) {
+      czhip_finalize();
+      return -1;
     }
+    cz_comm_bootstrap(myRank, nproc, id.data());  // returns when every rank has joined
+    if (myRank == 0) unlink(path.c_str());
   }
 
   cz_handle* cz = cz_create();
@@ -80,6 +97,9 @@ int main(int argc, char* argv[]) {
   }
   if (0 == cz_evaluate(cz, argc, argv)) {  // main.cpp:45-52
     if (myRank == 0) printf("\n\tSolver error.\n\n");
+    cz_destroy(cz);
+    if (nproc > 1) cz_comm_shutdown();
+    czhip_finalize();
     return -1;
   }
   cz_destroy(cz);

@@ -34,6 +34,7 @@ class CZ:
         lib.cz_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
         lib.cz_kernel_ms.restype = C.c_double
         lib.czhip_timing_read.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+        lib.cz_info.argtypes = [C.c_void_p, C.c_int]
         if lib.czhip_init(int(device)) != 0:
             raise RuntimeError("czhip_init failed")
         self.h = lib.cz_create()
@@ -95,6 +96,11 @@ class CZ:
         loc = (C.c_int * 3)()
         d = self.lib.cz_error_max(self.h, loc)
         return d, tuple(loc)
+
+    def info(self) -> dict:
+        """what a (multi-GPU) run decided (cz_info of include/cz_hip.h)"""
+        keys = ("ranks", "fused_pass", "shell_slabs", "overlap", "lagged_reduce", "rccl_ranks")
+        return {k: self.lib.cz_info(self.h, i) for i, k in enumerate(keys)}
 
     def timing(self, enable: bool):
         self.lib.czhip_timing(1 if enable else 0)

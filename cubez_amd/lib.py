@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_set_pcr_mode", "czhip_use_t2", "czhip_rbsor2_async", "czhip_jacobi2_from_zero_async", "czhip_check2_async", "czhip_pair_split_async", "psor_", "psor_maf_", "pcr_", "pcr_eda_", "pcr_esa_", "pcr_rb_esa_", "pcr_j_esa_", "pcr_rb_maf_", "pcr_rb_esa_maf_", "pcr_maf_", "pcr_eda_maf_", "pcr_esa_maf_",
     "cz_create", "cz_destroy", "cz_evaluate", "cz_setup", "cz_solve", "cz_sweeps", "cz_result_iter", "cz_result_res",
     "cz_history", "cz_field", "cz_local_size", "cz_error_max", "cz_set_quiet", "cz_last_solve_seconds", "cz_kernel_ms",
-    "cz_set_debug", "cz_set_profile", "czhip_timing", "czhip_timing_read",
+    "cz_set_debug", "cz_set_profile", "cz_info", "czhip_timing", "czhip_timing_read",
     "cz_comm_unique_id_bytes", "cz_comm_get_unique_id", "cz_comm_bootstrap", "cz_comm_shutdown", "cz_comm_selftest", "cz_comm_auto_division",
     "cz_comm_decompose", "cz_comm_local_world", "cz_comm_local_world_free", "cz_comm_bootstrap_local",
 ]

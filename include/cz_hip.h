@@ -228,7 +228,9 @@ int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_R
 /* The same bookkeeping for a pair whose two sums were all-reduced first (decomposed runs). */
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);
-int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable); /* 0 / -1 keep; returns 0 if ok */
+/* Shape of the two-stage pass: threads per workgroup (512 | 1024; 0 / -1 keep, -2 = chosen per launch by the balance model), vectors per
+ * thread (2), planes per chunk (0 = chosen per launch, -1 keep), enable (-1 keep).  Returns 0 if ok.  Every shape gives the same bits. */
+int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable);
 /* line-SOR kernels (pcr*_): form 0 = one wave per line with the reference's arithmetic literally (pcr_rb_ only), 1 = coefficient
  * table + right-hand side in LDS, 2 = table + right-hand side in registers (default); variant = waves*10 + lines per wave, 0 = default;
  * negative = keep.  All forms give the same bits. */
@@ -266,6 +268,10 @@ void cz_local_size(const cz_handle*, int* size3, int* head3, int* nID6, int* inn
 double cz_error_max(cz_handle*, int* loc3);   /* debug epilogue, cz_Evaluate.cpp:550-563 (host-side restatement) */
 void cz_set_quiet(cz_handle*, int quiet);     /* suppress stdout / history file (tests, bench) */
 double cz_last_solve_seconds(const cz_handle*);
+/* What a (multi-GPU) run decided: what = 0 ranks, 1 every brick takes the fused pass, 2 shell slabs of this brick, 3 overlapped exchange,
+ * 4 the last stationary solve ran its residual all-reduce + test one pass behind, 5 ranks of the RCCL communicator (ncclCommCount; 0 = LOCAL
+ * test transport or single process). */
+int cz_info(const cz_handle*, int what);
 double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
 
 void cz_set_debug(cz_handle*, int mode);      /* main.cpp:38-42: 1 = run the analytic-error epilogue in cz_evaluate */

@@ -22,10 +22,41 @@ ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--threads", type=int, default=0)
 args = ap.parse_args()
 
-# default: the CPU share of a one-GPU box (16) or what the affinity mask allows, whichever is smaller
-cores = args.threads or min(16, len(os.sched_getaffinity(0)))
+
+
+def usable_cores() -> tuple:
+    """every core this process may run on: the affinity mask, cut by the cgroup's CPU quota where one is set (all host cores,
+    count stated)"""
+    mask = os.sched_getaffinity(0)
+    phys = set()
+    for c in mask:  # one thread per physical core: SMT siblings share a place
+        try:
+            phys.add(open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip())
+        except OSError:
+            phys.add(str(c))
+    aff = len(phys)
+    quota = None
+    try:  # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = max(1, q // per)
+        except (OSError, ValueError):
+            pass
+    return (min(aff, quota) if quota else aff), aff, quota
+
+
+cores, n_affinity, n_quota = usable_cores()
+if args.threads:
+    cores = args.threads
 os.environ["OMP_NUM_THREADS"] = str(cores)
 os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from oracle import cz_oracle as O  # noqa: E402
 
@@ -63,4 +94,5 @@ try:
 except OSError:
     pass
 print(json.dumps({"value": lups / dt / 1e6, "unit": "MLUPS", "cores": cores, "kind": "reference" if kind == "ref" else "port",
-                  "sample": f"{n} {args.solver} sweeps of the {N}^3 {args.prec} grid in {dt:.1f} s, OMP_NUM_THREADS={cores}, {cpu_model}"}))
+                  "sample": f"{n} {args.solver} sweeps of the {N}^3 {args.prec} grid in {dt:.1f} s, OMP_NUM_THREADS={cores} (affinity mask: {n_affinity} physical cores, "
+                            f"cgroup quota {n_quota if n_quota else 'none'}), OMP_PLACES=cores OMP_PROC_BIND=close, {cpu_model}"}))
