@@ -209,6 +209,13 @@ void oracle_blas_triad(REAL* z, const REAL* x, const REAL* y, const REAL* a_p, c
       for (int k = kst; k <= ked; k++) z[IDX(k, i, j)] = a * x[IDX(k, i, j)] + y[IDX(k, i, j)]; /* :297 */
 }
 
+/* Summation order of the two dot products (TEST INFRASTRUCTURE for the BiCGSTAB tolerance, VERDICT r1 "weak" 1): 0 = the reference's
+ * order (j ascending, cz_blas.f90:355-366), 1 = the same products summed with j DEscending.  Nothing else changes, so a solve run with
+ * order 1 shows how far the reference's own Krylov path moves when only the rounding of its REAL-accumulated dots is permuted. */
+static int g_dot_order = 0;
+void oracle_set_dot_order(int order) { g_dot_order = order; }
+int oracle_get_dot_order(void) { return g_dot_order; }
+
 /* ---- blas_dot1 : cz_blas.f90:320-373   r = sum p*p (REAL accumulator, overwritten) */
 void oracle_blas_dot1_w(REAL* r, const REAL* p, const int* sz, const int* idx, const int* gp, double* flop,
                         double* r_wide) {
@@ -217,10 +224,12 @@ void oracle_blas_dot1_w(REAL* r, const REAL* p, const int* sz, const int* idx, c
   REAL acc = (REAL)0.0;
   double accw = 0.0;
   *flop += 2.0 * NPTS;
+  const int rev = g_dot_order;
 #pragma omp parallel for schedule(static) collapse(2) reduction(+ : acc, accw)
-  for (int j = jst; j <= jed; j++)
+  for (int jj = jst; jj <= jed; jj++)
     for (int i = ist; i <= ied; i++)
       for (int k = kst; k <= ked; k++) {
+        const int j = rev ? jst + jed - jj : jj;
         REAL q = p[IDX(k, i, j)];
         REAL t = q * q;
         acc = acc + t; /* :361-362 */
@@ -242,10 +251,12 @@ void oracle_blas_dot2_w(REAL* r, const REAL* p, const REAL* q, const int* sz, co
   REAL acc = (REAL)0.0;
   double accw = 0.0;
   *flop += 2.0 * NPTS;
+  const int rev = g_dot_order;
 #pragma omp parallel for schedule(static) collapse(2) reduction(+ : acc, accw)
-  for (int j = jst; j <= jed; j++)
+  for (int jj = jst; jj <= jed; jj++)
     for (int i = ist; i <= ied; i++)
       for (int k = kst; k <= ked; k++) {
+        const int j = rev ? jst + jed - jj : jj;
         REAL t = p[IDX(k, i, j)] * q[IDX(k, i, j)];
         acc = acc + t; /* :426 */
         accw += (double)t;

@@ -43,12 +43,77 @@ def test_jacobi_512_against_oracle_and_between_paths():
     assert np.allclose(hist_a, [r for _, r in o.history], rtol=1e-11, atol=0)
 
 
-def test_rbsor_512_fused_iteration_equals_two_colour_launches():
+def test_rbsor_512_against_oracle_and_between_paths():
+    """configs[2]: 5 iterations of `cz 512 512 512 sor2sma ... 1.5`: fused red-black pass == two colour launches == oracle, bit for bit
+    (field) and to the double-accumulation tolerance (history)."""
     itr_a, hist_a, P_a = _driver("f32", "sor2sma", 5, 1.5, t2=True)
     itr_b, hist_b, P_b = _driver("f32", "sor2sma", 5, 1.5, t2=False)
     assert itr_a == itr_b == 6
     assert P_a.tobytes() == P_b.tobytes()
     assert np.allclose(hist_a, hist_b, rtol=1e-12, atol=0)
+    o = O.run((N, N, N), "sor2sma", 5, 1.5, kind="oracle", prec="f32", wide=True)
+    assert o.itr == 6
+    assert o.P.tobytes() == P_a.tobytes()
+    assert np.allclose(hist_a, [r for _, r in o.history], rtol=1e-11, atol=0)
+
+
+def _golden_hist(name):
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return [float(ln.split(",")[1]) for ln in open(os.path.join(g, name)).read().splitlines()[1:]]
+
+
+def _large_case(tag):
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return json.load(open(os.path.join(g, "large_cases.json")))[tag]
+
+
+def test_bicgstab_512_fp64_first_iterations_vs_reference():
+    """configs[3] at full size: the first 4 iterations of `cz 512 512 512 pbicgstab ... 0.8 jacobi` (FP64) against the reference's own
+    Fortran kernels run single-threaded in the build container (tests/golden/make_golden_large.py): residuals to 1e-6 (measured: 2e-12),
+    solution to 1e-9."""
+    from cubez_amd import CZ
+    c = _large_case("pbicgstab_jacobi_512x512x512_f64_4it")
+    ref = _golden_hist(c["hist"])
+    cz = CZ("f64", quiet=True)
+    assert cz.setup([N, N, N, "pbicgstab", c["itr_max"], 0.8, "jacobi"]) == 1
+    itr = cz.solve()
+    hist = cz.history()
+    cz.close()
+    assert itr == c["iter"] and len(hist) == len(ref) == 4
+    assert np.allclose(hist, ref, rtol=1e-6, atol=0)
+    assert np.allclose(hist, ref, rtol=1e-10, atol=0)  # what the double-accumulated dots actually give this early in the recurrence
+
+
+def test_bicgstab_256_fp64_to_convergence_vs_reference():
+    """`cz 256 256 256 pbicgstab 1000 0.8 jacobi` (FP64) to eps against the reference (73 iterations, Res 2.220299e-06).  The Krylov
+    recurrence amplifies the rounding of the dot products: the reference's own history, re-run with the SAME dot products summed in
+    another order (hist_*_permuted_dots.txt), leaves the original by 1e-3 at iteration 30 and by O(1) from iteration 40 on, and its
+    residual then idles within a factor 2 of eps for a dozen iterations before it drops.  So: the first 20 iterations to 1e-6 (the stated
+    bar, held while the recurrence is short), afterwards no further from the reference than a small multiple of what the permuted
+    reference is, and convergence inside the window in which the reference's two histories idle next to eps."""
+    from cubez_amd import CZ
+    c = _large_case("pbicgstab_jacobi_256x256x256_f64")
+    ref, perm = np.array(_golden_hist(c["hist"])), np.array(_golden_hist(c["permuted_dots"]["hist"]))
+    cz = CZ("f64", quiet=True)
+    assert cz.setup([256, 256, 256, "pbicgstab", 1000, 0.8, "jacobi"]) == 1
+    itr = cz.solve()
+    hist = np.array(cz.history())
+    res = cz.res
+    cz.close()
+    assert np.allclose(hist[:20], ref[:20], rtol=1e-6, atol=0)
+    m = min(len(hist), len(ref), len(perm))
+    dev_gpu = np.abs(hist[:m] - ref[:m]) / ref[:m]
+    dev_perm = np.abs(perm[:m] - ref[:m]) / ref[:m]
+    run_gpu, run_perm = np.maximum.accumulate(dev_gpu), np.maximum.accumulate(dev_perm)
+    assert np.all(run_gpu <= np.maximum(1e-6, 16.0 * run_perm)), (run_gpu[::8], run_perm[::8])
+    eps = 1.0e-5
+    first_near = 1 + int(np.argmax(np.minimum(ref[:m], perm[:m]) < 2.0 * eps))  # first iteration with a residual within 2x of eps
+    last = max(c["iter"], c["permuted_dots"]["iter"])
+    assert first_near <= itr <= last + (last - first_near), (itr, first_near, last)
+    assert res < eps
 
 
 def test_jacobi_512_fp64_paths_agree():

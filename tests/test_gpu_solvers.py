@@ -78,30 +78,42 @@ def test_stationary_history_vs_wide_oracle(case):
 BICG = [c for c in CASES if c["solver"] in ("pbicgstab", "pbicgstab_maf")]
 
 
+PERM = json.load(open(os.path.join(GOLDEN, "perm_cases.json")))  # the reference re-run with its dot products summed in another order
+DRIFT_FACTOR = 16.0  # |GPU - reference| <= DRIFT_FACTOR x |permuted reference - reference| (measured 0.5x ... 8x; profiles/r02/bicg_drift_*.txt)
+
+
 @pytest.mark.parametrize("case", BICG, ids=[c["tag"] for c in BICG])
 def test_bicgstab_vs_golden(case):
+    """Iteration count, residual history, final residual and analytic error against the reference's own kernels.
+
+    BiCGSTAB's scalar recurrence amplifies rounding differences of the dot products (the GPU accumulates them in double in a fixed tree,
+    the reference in REAL in loop order).  How far that may move a history is MEASURED, not chosen: tests/golden/perm_cases.json holds, for
+    every case, the reference run a second time with the same dot products summed with j descending (oracle_set_dot_order(1); nothing
+    else changes).  The stated bar -- same iteration count, residuals within 1e-6 -- is asserted wherever the reference itself stays
+    within 1e-6/DRIFT_FACTOR of its permuted self; elsewhere the GPU may leave the reference by DRIFT_FACTOR times what the reference
+    leaves itself by (32^3 FP32: 1e-4, 128^3 FP64 Jacobi-preconditioned: 2.4e-3, un-preconditioned: iteration count 41 -> 39)."""
     g = _run_gpu(case)
     ref_hist = [float(l.split(",")[1]) for l in open(os.path.join(GOLDEN, f"hist_{case['tag']}.txt")).read().splitlines()[1:]]
-    if case["prec"] == "f64" and case["precond"] == "none":
-        # Un-preconditioned BiCGSTAB on this grid is rounding-sensitive (erratic, non-monotone residual curve): the
-        # reference's own iteration count moves with the summation order of its dot products.  Same bar as FP32.
-        assert abs(g["itr"] - case["iter"]) <= 3 and g["res"] < 1e-5
-    elif case["prec"] == "f64":
-        # dots differ from the reference only by double summation order: same iteration count, final residual to 1e-6
-        assert g["itr"] == case["iter"]
-        # BiCGSTAB amplifies the 1e-16 summation-order difference of the dot products along the Krylov recurrence:
-        # measured drift of the final residual 7e-12 at 32^3 (9 its), 6e-9 at 64^3 (18), 2e-3 at 128^3 (33 its, jacobi
-        # preconditioner; tools/bicg_drift.py).  The 1e-6 bar is held wherever the recurrence is short enough.
-        tol = 1e-6 if max(case["gsz"]) <= 64 or case["precond"] in ("sor2sma", "sor2sma_maf", "pcr_rb", "psor", "pcr", "pcr_rb_esa", "pcr_rb_maf") else 1e-2
+    p = PERM[case["tag"]]
+    assert len(ref_hist) == len(p["hist_reference_full_precision"])  # the permuted twin belongs to this fixture
+    ref = np.array(p["hist_reference_full_precision"])
+    perm = np.array([float(l.split(",")[1]) for l in open(os.path.join(GOLDEN, p["hist"])).read().splitlines()[1:]])
+    band = abs(p["iter"] - p["iter_reference"])  # how far the reference's own iteration count moves
+    assert abs(g["itr"] - case["iter"]) <= band, (g["itr"], case["iter"], p["iter"])
+    m = min(len(g["hist"]), len(ref), len(perm))
+    hist = np.array(g["hist"][:m])
+    run_gpu = np.maximum.accumulate(np.abs(hist - ref[:m]) / ref[:m])
+    run_perm = np.maximum.accumulate(np.abs(perm[:m] - ref[:m]) / ref[:m])
+    # floor: the stated 1e-6, or -- FP32 -- the error the reference's sequential REAL accumulation of an n-term dot product carries
+    # against the exact sum the GPU rounds once (random-walk estimate sqrt(n) eps, x10): two orderings of the same REAL sum share most of it
+    npts = float(np.prod([n - 2 for n in case["gsz"]]))
+    floor = max(1e-6, 10.0 * np.sqrt(npts) * float(np.finfo(np.float32 if case["prec"] == "f32" else np.float64).eps))
+    assert np.all(run_gpu <= np.maximum(floor, DRIFT_FACTOR * run_perm)), (case["tag"], run_gpu[-1], run_perm[-1])
+    if band == 0:
+        tol = max(floor, DRIFT_FACTOR * abs(p["res"] - p["res_reference"]) / p["res_reference"])
         assert abs(g["res"] - case["res"]) <= tol * case["res"]
-        assert np.allclose(g["hist"], ref_hist, rtol=max(tol, 5e-6), atol=0)  # the file carries 7 digits
-        ref_err = case["errmax"]
-        assert abs(g["err"][0] - ref_err) <= tol * max(ref_err, 1e-12) + 1e-12
-    else:
-        # FP32: the reference's REAL-accumulated dots carry ~1e-4 relative error, so the Krylov path may differ;
-        # the solve must still converge to eps in a comparable number of iterations
-        assert 0 < g["itr"] <= case["iter"] + 3
-        assert g["res"] < 1e-5
+        assert abs(g["err"][0] - case["errmax"]) <= tol * max(case["errmax"], 1e-12) + 1e-12
+    assert g["res"] < 1e-5
 
 
 @pytest.mark.parametrize("case", [c for c in BICG if max(c["gsz"]) <= 64 and c["precond"] != "none"], ids=lambda c: c["tag"])
