@@ -2,7 +2,14 @@
 //
 // One exchange = ONE pack launch, ONE grouped ncclSend/ncclRecv over all neighbours, ONE unpack launch.
 // A message is the box of owned cells next to a face or an edge of the brick; the receiver stores it in the mirror-image
-// ghost box.  Two shapes of exchange:
+// ghost box.  How a box travels follows the K-fastest layout:
+//   J face   whole padded planes are contiguous: sent from / received into the array itself, no pack, no unpack (a plane carries the
+//            i / k guide cells along: +1.6 % bytes; what lands on the receiver's edge cells is overwritten by the edge messages' unpack,
+//            which runs after the group on the same stream)
+//   I face   whole padded k-rows: 16-byte vectors along k, one integer division per ROW; the unpack leaves the k guide cells alone
+//   K face   one or two cells per row: one thread per (i,j) row, 8-byte access where the pair is aligned
+//   edge     a few thousand cells: element by element
+// Two shapes of exchange:
 //   depth 1, faces only          Comm_S(X, 1) of the reference (cz_comm.cpp:23-38): what one sweep reads
 //   depth 2, faces + 12 edges    what a fused pair of sweeps reads: the first sweep is also applied to ghost layer 1, which
 //                                needs ghost layer 2 behind it and the edge cells (ghost in two directions) beside it;
@@ -167,28 +174,93 @@ thread_local Boot boot;
 
 constexpr int MAX_BOX = 18;  // 6 faces + 12 edges
 
+enum BoxKind { BOX_GENERIC = 0, BOX_ROWS = 1 /* I face: whole padded k-rows */, BOX_KPAIR = 2 /* K face */, BOX_DIRECT = 3 /* J face: not packed */ };
+
 struct BoxDesc {
   int i0, j0, k0;   // padded 0-based start
   int ni, nj, nk;   // extent
   long long off;    // element offset in the packed buffer
+  int kind;
 };
 struct BoxTable {
   int n;
   BoxDesc b[MAX_BOX];
 };
 
-// gather the boxes of X into the packed buffer (dir = 0) or scatter the packed buffer into the boxes (dir = 1)
+template <typename T>
+struct Vec16 {
+  typedef T type __attribute__((ext_vector_type(16 / sizeof(T))));
+};
+template <typename T>
+struct Vec8 {
+  typedef T type __attribute__((ext_vector_type(8 / sizeof(T) > 1 ? 8 / sizeof(T) : 2)));  // float2; (unused for double)
+};
+
+// gather the boxes of X into the packed buffer (DIR = 0) or scatter the packed buffer into the boxes (DIR = 1); blockIdx.y = box
 template <typename T, int DIR>
 __global__ void __launch_bounds__(256)
 box_copy_k(T* __restrict__ buf, T* __restrict__ X, BoxTable tab, int nkp, int nip, const int* __restrict__ skip) {
   if (skip && *skip) return;
   const BoxDesc d = tab.b[blockIdx.y];
+  const size_t plane = (size_t)nkp * nip;
+  if (d.kind == BOX_DIRECT) return;
+  if (d.kind == BOX_ROWS) {
+    // packed layout: the ni*nj padded rows of the box one after the other (nkp elements each, 16-byte aligned on both sides)
+    constexpr int VW = 16 / sizeof(T);
+    typedef typename Vec16<T>::type V;
+    const int nv = nkp / VW, nrows = d.ni * d.nj;
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+      const int i = row % d.ni, j = row / d.ni;
+      T* xr = X + (size_t)(d.i0 + i) * nkp + (size_t)(d.j0 + j) * plane;
+      T* br = buf + d.off + (size_t)row * nkp;
+      for (int v = threadIdx.x; v < nv; v += 256) {
+        if (DIR == 0) {
+          reinterpret_cast<V*>(br)[v] = reinterpret_cast<const V*>(xr)[v];
+        } else {
+          const int kk = v * VW;
+          if (kk >= d.k0 && kk + VW <= d.k0 + d.nk) {
+            reinterpret_cast<V*>(xr)[v] = reinterpret_cast<const V*>(br)[v];
+          } else {  // the vectors holding the k guide cells: those cells belong to the edge messages
+#pragma unroll
+            for (int c = 0; c < VW; c++)
+              if (kk + c >= d.k0 && kk + c < d.k0 + d.nk) xr[kk + c] = br[kk + c];
+          }
+        }
+      }
+    }
+    return;
+  }
+  if (d.kind == BOX_KPAIR) {
+    // nk <= 2 cells per (i,j) row; packed layout [j][i][k].  Consecutive lanes take consecutive i: every lane its own 128-byte line of X
+    // (nothing to coalesce on that side), but the packed side is one contiguous run per wave.
+    const int nrows = d.ni * d.nj;
+    for (int row = blockIdx.x * 256 + threadIdx.x; row < nrows; row += gridDim.x * 256) {
+      const int i = row % d.ni, j = row / d.ni;
+      T* xr = X + (size_t)d.k0 + (size_t)(d.i0 + i) * nkp + (size_t)(d.j0 + j) * plane;
+      T* br = buf + d.off + (size_t)row * d.nk;
+      if (sizeof(T) == 4 && d.nk == 2 && (d.k0 & 1) == 0 && (d.off & 1) == 0) {
+        typedef typename Vec8<T>::type V2;
+        if (DIR == 0) *reinterpret_cast<V2*>(br) = *reinterpret_cast<const V2*>(xr);
+        else *reinterpret_cast<V2*>(xr) = *reinterpret_cast<const V2*>(br);
+      } else if (sizeof(T) == 8 && d.nk == 2 && (d.k0 & 1) == 0 && (d.off & 1) == 0) {
+        typedef typename Vec16<T>::type V2;
+        if (DIR == 0) *reinterpret_cast<V2*>(br) = *reinterpret_cast<const V2*>(xr);
+        else *reinterpret_cast<V2*>(xr) = *reinterpret_cast<const V2*>(br);
+      } else {
+        for (int k = 0; k < d.nk; k++) {
+          if (DIR == 0) br[k] = xr[k];
+          else xr[k] = br[k];
+        }
+      }
+    }
+    return;
+  }
   const long long n = (long long)d.ni * d.nj * d.nk;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
     const int k = (int)(e % d.nk);
     const long long r = e / d.nk;
     const int i = (int)(r % d.ni), j = (int)(r / d.ni);
-    const size_t lin = (size_t)(d.k0 + k) + (size_t)(d.i0 + i) * nkp + (size_t)(d.j0 + j) * nkp * nip;
+    const size_t lin = (size_t)(d.k0 + k) + (size_t)(d.i0 + i) * nkp + (size_t)(d.j0 + j) * plane;
     if (DIR == 0) buf[d.off + e] = X[lin];
     else X[lin] = buf[d.off + e];
   }
@@ -202,6 +274,8 @@ struct Pattern {
   int peer[MAX_BOX];
   int dir[MAX_BOX][3];
   size_t count[MAX_BOX], off[MAX_BOX];
+  int direct[MAX_BOX];                                // the message is a run of whole planes of the array (J face): no buffer
+  size_t direct_send[MAX_BOX], direct_recv[MAX_BOX];  // element offsets of those runs in the array
   BoxTable send, recv;
   size_t total = 0;
   void* sendbuf = nullptr;
@@ -219,6 +293,7 @@ struct CommCtx {
   double* h_red = nullptr;
   Pattern shallow, deep;   // depth 1 faces / depth 2 faces + edges
   const Pattern* cur = nullptr;  // LOCAL: pattern being exchanged (published for the neighbours)
+  const void* cur_X = nullptr;   // LOCAL: the array being exchanged (source of the neighbours' direct messages)
   Watch watch;
 };
 
@@ -308,14 +383,32 @@ void build_pattern(CommCtx* c, Pattern& p, int depth, bool edges) {
         sb.i0 = s0[0] + g - 1, sb.j0 = s0[1] + g - 1, sb.k0 = s0[2] + g - 1;
         rb.i0 = r0[0] + g - 1, rb.j0 = r0[1] + g - 1, rb.k0 = r0[2] + g - 1;
         sb.ni = rb.ni = ext[0], sb.nj = rb.nj = ext[1], sb.nk = rb.nk = ext[2];
-        sb.off = rb.off = (long long)p.total;
+        const int nkp = N[2] + 2 * g, nip = N[0] + 2 * g;
+        const bool vec_rows = (nkp * c->eb) % 16 == 0;  // every padded k-row starts 16-byte aligned (hipMalloc'ed arrays)
+        int kind = BOX_GENERIC;
+        size_t cnt = (size_t)ext[0] * ext[1] * ext[2];
+        if (nz == 1 && dj != 0 && !getenv("CZ_COMM_PACK_J")) {
+          kind = BOX_DIRECT;  // dep whole padded planes
+          cnt = (size_t)dep * nkp * nip;
+        } else if (nz == 1 && di != 0 && vec_rows) {
+          kind = BOX_ROWS;  // whole padded rows
+          cnt = (size_t)ext[0] * ext[1] * nkp;
+        } else if (nz == 1 && dk != 0) {
+          kind = BOX_KPAIR;
+        }
+        sb.kind = rb.kind = kind;
         const int m = p.nmsg++;
+        p.direct[m] = (kind == BOX_DIRECT);
+        p.direct_send[m] = (size_t)sb.j0 * nkp * nip;
+        p.direct_recv[m] = (size_t)rb.j0 * nkp * nip;
+        if (kind != BOX_DIRECT && (p.total * c->eb) % 16) p.total += (16 - (p.total * c->eb) % 16) / c->eb;  // 16-byte aligned messages
+        sb.off = rb.off = (long long)p.total;
         p.send.b[m] = sb, p.recv.b[m] = rb;
         p.peer[m] = rc[0] + c->div[0] * (rc[1] + c->div[1] * rc[2]);
         p.dir[m][0] = di, p.dir[m][1] = dj, p.dir[m][2] = dk;
-        p.count[m] = (size_t)ext[0] * ext[1] * ext[2];
+        p.count[m] = cnt;
         p.off[m] = p.total;
-        p.total += p.count[m];
+        if (kind != BOX_DIRECT) p.total += cnt;
       }
   p.send.n = p.recv.n = p.nmsg;
   if (p.total) {
@@ -328,21 +421,34 @@ template <typename T>
 bool exchange(CommCtx* c, const Pattern& p, T* X, const int* skip, hipStream_t st) {
   if (p.nmsg == 0) return true;
   const int nkp = c->size[2] + 2 * c->g, nip = c->size[0] + 2 * c->g;
-  size_t biggest = 0;
-  for (int m = 0; m < p.nmsg; m++) biggest = std::max(biggest, p.count[m]);
-  const dim3 grid((unsigned)std::min<size_t>((biggest + 255) / 256, 2048), (unsigned)p.nmsg);
-  hipLaunchKernelGGL((box_copy_k<T, 0>), grid, dim3(256), 0, st, (T*)p.sendbuf, X, p.send, nkp, nip, skip);
-  HIP_CHECK(hipGetLastError());
+  // grid: enough workgroups for the biggest packed box (rows for the row kind, 256 cells otherwise)
+  size_t most = 0;
+  bool any_packed = false;
+  for (int m = 0; m < p.nmsg; m++) {
+    const BoxDesc& b = p.send.b[m];
+    if (b.kind == BOX_DIRECT) continue;
+    any_packed = true;
+    const size_t rows = (size_t)b.ni * b.nj;
+    most = std::max(most, b.kind == BOX_ROWS ? rows : b.kind == BOX_KPAIR ? (rows + 255) / 256 : (p.count[m] + 255) / 256);
+  }
+  const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(most, 1), 2048), (unsigned)p.nmsg);
+  if (any_packed) {
+    hipLaunchKernelGGL((box_copy_k<T, 0>), grid, dim3(256), 0, st, (T*)p.sendbuf, X, p.send, nkp, nip, skip);
+    HIP_CHECK(hipGetLastError());
+  }
   if (c->tr == T_RCCL) {
     const ncclDataType_t dt = sizeof(T) == 4 ? ncclFloat : ncclDouble;
     NCCL_CHECK(ncclGroupStart());
     for (int m = 0; m < p.nmsg; m++) {
-      NCCL_CHECK(ncclSend((const T*)p.sendbuf + p.off[m], p.count[m], dt, p.peer[m], c->nccl, st));
-      NCCL_CHECK(ncclRecv((T*)p.recvbuf + p.off[m], p.count[m], dt, p.peer[m], c->nccl, st));
+      const T* src = p.direct[m] ? X + p.direct_send[m] : (const T*)p.sendbuf + p.off[m];
+      T* dst = p.direct[m] ? X + p.direct_recv[m] : (T*)p.recvbuf + p.off[m];
+      NCCL_CHECK(ncclSend(src, p.count[m], dt, p.peer[m], c->nccl, st));
+      NCCL_CHECK(ncclRecv(dst, p.count[m], dt, p.peer[m], c->nccl, st));
     }
     NCCL_CHECK(ncclGroupEnd());
   } else {  // LOCAL: every rank has packed; copy what each neighbour packed for me (its message in direction -d)
     c->cur = &p;
+    c->cur_X = X;
     HIP_CHECK(hipStreamSynchronize(st));
     c->world->barrier(c->rank);
     for (int m = 0; m < p.nmsg; m++) {
@@ -351,18 +457,21 @@ bool exchange(CommCtx* c, const Pattern& p, T* X, const int* skip, hipStream_t s
       int mm = -1;
       for (int x = 0; x < q->nmsg; x++)
         if (q->dir[x][0] == -p.dir[m][0] && q->dir[x][1] == -p.dir[m][1] && q->dir[x][2] == -p.dir[m][2]) mm = x;
-      if (mm < 0 || q->count[mm] != p.count[m] || q->peer[mm] != c->rank) {
+      if (mm < 0 || q->count[mm] != p.count[m] || q->peer[mm] != c->rank || q->direct[mm] != p.direct[m]) {
         fprintf(stderr, "czhip: LOCAL transport: rank %d has no matching message from rank %d\n", c->rank, p.peer[m]);
         exit(1);
       }
-      HIP_CHECK(hipMemcpyAsync((T*)p.recvbuf + p.off[m], (const T*)q->sendbuf + q->off[mm], p.count[m] * sizeof(T),
-                               hipMemcpyDeviceToDevice, st));
+      const T* src = q->direct[mm] ? (const T*)nb->cur_X + q->direct_send[mm] : (const T*)q->sendbuf + q->off[mm];
+      T* dst = p.direct[m] ? X + p.direct_recv[m] : (T*)p.recvbuf + p.off[m];
+      HIP_CHECK(hipMemcpyAsync(dst, src, p.count[m] * sizeof(T), hipMemcpyDeviceToDevice, st));
     }
     HIP_CHECK(hipStreamSynchronize(st));
     c->world->barrier(c->rank);  // nobody repacks before everyone has copied
   }
-  hipLaunchKernelGGL((box_copy_k<T, 1>), grid, dim3(256), 0, st, (T*)p.recvbuf, X, p.recv, nkp, nip, skip);
-  HIP_CHECK(hipGetLastError());
+  if (any_packed) {
+    hipLaunchKernelGGL((box_copy_k<T, 1>), grid, dim3(256), 0, st, (T*)p.recvbuf, X, p.recv, nkp, nip, skip);
+    HIP_CHECK(hipGetLastError());
+  }
   c->watch.note(&p == &c->deep ? "halo exchange, two layers + edges" : "halo exchange, one layer", st);
   return true;
 }

@@ -73,6 +73,8 @@ class CZ {
   void skew_wait() const;
   int lag_reduce = 1;            // CZ_LAG_REDUCE=0: residual all-reduce + test on the compute stream after every pass (no lag)
   REAL_TYPE* WRK2 = nullptr;     // third rotation buffer of the lagged mode
+  int wrk_shell_tag = 0;         // whose shell WRK carries: 0 unknown, 1 P's (Dirichlet faces), 2 all zero (sync_wrk_shell)
+  void sync_wrk_shell(const REAL_TYPE* X);
   int overlap = 1;               // CZ_OVERLAP=0 turns it off (exchange after the whole sweep, same results)
   int n_shell = 0;               // shell boxes (cells within two layers of a rank-internal face), 1-based index ranges
   int shell_boxes[36];
