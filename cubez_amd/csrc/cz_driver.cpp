@@ -319,7 +319,7 @@ int CZ::Setup(int argc, char** argv) {
     // Bricks of an uneven division can differ (k-extent multiple of the vector width or not): agree on the weakest.
     int idx1[6];
     for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
-    const double mine = pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE) ? 0.0 : 1.0;
+    const double mine = pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE, cf[6]) ? 0.0 : 1.0;
     pairs_ok = comm_allreduce_max_host(comm, mine) == 0.0;
     if (getenv("CZ_COMM_DEBUG")) {  // one line per rank on stderr: what a multi-GPU run decided
       int dev = -1;
@@ -597,7 +597,7 @@ bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int
   double* rs = res_slot ? res_slot : d_res;
   const int gc = GUIDE;
   hipStream_t st = stream();
-  if (!pair_probe(src, dst, B, size, interior, interior1, gc)) return false;
+  if (!pair_probe(src, dst, B, size, interior, interior1, gc, cf[6])) return false;
   pair_shell_async(src, dst, B, size, idx1, shell_boxes, n_shell, gc, cf, ac1, rb, skip);
   HIP_CHECK(hipEventRecord(ev_shell, st));
   if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, rs, 1, skip)) {

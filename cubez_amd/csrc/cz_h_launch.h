@@ -173,6 +173,7 @@ template <int RB>
 bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
                     const Fin2& fin, int par = 0, int zero_u = 0, bool probe = false) {
   if (!vec_ok(b, {U, B, W})) return false;
+  if (!fastdiv_ok(c.dd)) return false;  // jacobi2p_k divides by dd with the hoisted form (cz_k_fastdiv.h); odd magnitudes take single sweeps
   // the stage-1 box may exceed the output box by at most one layer per side
   if (ba.ii0 < b.ii0 - 1 || ba.ii0 > b.ii0 || ba.ii1 > b.ii1 + 1 || ba.ii1 < b.ii1 || ba.jj0 < b.jj0 - 1 || ba.jj0 > b.jj0 ||
       ba.jj1 > b.jj1 + 1 || ba.jj1 < b.jj1 || ba.kk0 < b.kk0 - 1 || ba.kk0 > b.kk0 || ba.kk1 > b.kk1 + 1 || ba.kk1 < b.kk1)

@@ -276,7 +276,7 @@ psor_tile_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorGeom g
       } else {
         Vec<1> pc, im, ip, pm, pn, bv;
         pc.v[0] = pp, im.v[0] = lp[x - L1], ip.v[0] = lp[x + L1], pm.v[0] = lp[x - L2], pn.v[0] = lp[x + L2], bv.v[0] = bb;
-        lp[x] = relax_vec<1>(pc, im, ip, pm, pn, lp[x - 1], lp[x + 1], bv, c, 1u, 1u, acc).v[0];
+        lp[x] = relax_vec<1>(pc, im, ip, pm, pn, lp[x - 1], lp[x + 1], bv, c, PlainDiv{c.dd}, 1u, 1u, acc).v[0];
       }
     }
     __syncthreads();

@@ -99,6 +99,11 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
   if (jb > g.jj1) jb = g.jj1;
 
   double acc1 = 0.0, acc2 = 0.0;
+#ifdef CZ_P2_PLAIN_DIV  // tools/pair_lab A/B only
+  const PlainDiv dv{c.dd};
+#else
+  const HoistedDiv dv{fastdiv_init(c.dd)};  // exact IEEE quotients, the divisor's share of the work done once (cz_k_fastdiv.h)
+#endif
 
   if (ja <= jb && fb < g.Fend) {
     const long long e1_0 = fb - R;      // first vector of E1
@@ -215,7 +220,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
           const REAL kr = lane_shl1(ehi, pc.v[0]);
           unsigned msk = ka[m];
           if (RB) msk &= colour_bits<V>(pbase[m] + q);  // colour 0 on plane q
-          vc[m] = relax_vec<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], c, msk, count1 ? (own[m] & msk) : 0u, acc1);
+          vc[m] = relax_vec<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], c, dv, msk, count1 ? (own[m] & msk) : 0u, acc1);
         }
       } else {
 #pragma unroll
@@ -241,7 +246,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
             const Vec<V> pm = lds_ld<V>(pV + e);
             unsigned m2 = own[m];
             if (RB) m2 &= colour_bits<V>(pbase[m] + q);  // colour 1 on plane q-1
-            const Vec<V> o = relax_vec<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], c, m2, m2, acc2);
+            const Vec<V> o = relax_vec<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], c, dv, m2, m2, acc2);
             if (own[m] == (1u << V) - 1) {
               st16<V>(Wq, bo[m], o);
             } else {

@@ -36,6 +36,7 @@ constexpr int VW = 4;
 
 namespace {
 #include "cz_k_common.h"
+#include "cz_k_fastdiv.h"
 #include "cz_k_stencil.h"
 #include "cz_k_pair.h"
 #include "cz_k_pair2.h"
@@ -404,7 +405,7 @@ int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const
   ensure_init();
   int boxes[36], in0[6], in1[6];
   const int n = czhip_internal::pair_plan(idx, nID, boxes, in0, in1);
-  if (n == 0 || !czhip_internal::pair_probe(u, w, b, sz, in0, in1, g)) return 0;
+  if (n == 0 || !czhip_internal::pair_probe(u, w, b, sz, in0, in1, g, cf[6])) return 0;
   const int rb = rb_ofst >= 0 ? rb_parity(g, idx, rb_ofst, 0) : -1;
   czhip_internal::pair_shell_async(u, w, b, sz, idx1 ? idx1 : idx, boxes, n, g, cf, omg, rb, nullptr);
   return czhip_internal::pair_box_async(u, w, b, sz, in0, in1, g, cf, omg, rb, res_dev, 1, nullptr);
@@ -423,6 +424,24 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
 }
 
 int czhip_use_t2(void) { return ctx.tune.use_t2; }
+
+// Self-test of the hoisted division of the two-stage pass (cz_k_fastdiv.h): number of numerators (of 2^32: every float / a structured
+// sample of doubles) whose quotient by d differs in any bit from the ordinary IEEE division; -1 when the launchers would not use the
+// hoisted form for this divisor at all.
+long long czhip_selftest_fastdiv(CZ_REAL d) {
+  ensure_init();
+  if (!fastdiv_ok(d)) return -1;
+  unsigned long long* bad = nullptr;
+  HIP_CHECK(hipMalloc(&bad, sizeof(*bad)));
+  HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(*bad), ctx.stream));
+  hipLaunchKernelGGL(fastdiv_check_k, dim3(4096), dim3(256), 0, ctx.stream, d, bad);
+  HIP_CHECK(hipGetLastError());
+  unsigned long long h = 0;
+  HIP_CHECK(hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, ctx.stream));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  HIP_CHECK(hipFree(bad));
+  return (long long)h;
+}
 
 // line-SOR kernel choice: form 0 = pcr_rb_k (the reference's arithmetic literally, pcr_rb only), 1 = table + d in LDS, 2 = table +
 // d in registers (default); variant = waves per workgroup * 10 + lines per wave, 0 = measured default.  Negative: keep.
@@ -987,13 +1006,15 @@ int pair_plan(const int* O, const int* nID, int* boxes, int* interior, int* inte
   return n;
 }
 
-int pair_probe(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g) {
+int pair_probe(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g, REAL dd) {
   ensure_init();
   if (!ctx.tune.fuse_fin || g < 2) return 0;
   const Box bx = make_box(sz, idx, g);
   if (bx.empty) return 0;
   const Box ba = make_box(sz, idx1, g);
-  return launch_jacobi2<0>(u, b, w, Coef(), bx, ba, nullptr, Fin2(), 0, 0, true) ? 1 : 0;
+  Coef c = make_coef_omg((REAL)1);
+  c.dd = dd;  // the divisor decides too: the pass divides with the hoisted form (cz_k_fastdiv.h)
+  return launch_jacobi2<0>(u, b, w, c, bx, ba, nullptr, Fin2(), 0, 0, true) ? 1 : 0;
 }
 
 void pair_shell_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx1_brick, const int* boxes, int n, int g,

@@ -236,6 +236,8 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
  * negative = keep.  All forms give the same bits. */
 int czhip_set_pcr_mode(int form, int variant);
 int czhip_use_t2(void);
+/* self-test: numerators (of 2^32) whose quotient by d in the two-stage pass differs from the IEEE division (expected 0); -1 = divisor not eligible */
+long long czhip_selftest_fastdiv(CZ_REAL d);
 
 /* Convergence bookkeeping on the device (cz_Poisson.cpp:67-77): res = sqrt(res_dev[0]*res_normal);
  * hist_dev[itr] = res; if (res < eps && !*flag) { *flag = 1; conv_itr_dev[0] = itr; }.  No-op when

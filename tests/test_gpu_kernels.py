@@ -643,3 +643,18 @@ def test_pcr_maf_variants_random_boxes_vs_oracle(prec, box):
             assert _beq(dx.get(), x1), (name, it)
             assert _rel(r2, float(w[0])) < 1e-11, (name, r2, w)
             assert h.last_flop == ko.last_flop, name
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_hoisted_division_is_the_ieee_division(prec):
+    """The two-stage pass divides by the diagonal coefficient with the divisor's share of the IEEE expansion done once per thread
+    (cz_k_fastdiv.h).  Every one of the 2^32 float numerators (a structured sample of 2^32 doubles: all sign/exponent patterns x 2^20
+    mantissas) must give the bits of the ordinary `n / d`, for the benchmark's 6.0, the tests' 6.2 / 6.3, a negative and two awkward
+    magnitudes; divisors near the ends of the exponent range are refused (the launchers then take the single-sweep kernels)."""
+    import ctypes as C
+    h = _hip(prec)
+    h.lib.czhip_selftest_fastdiv.restype = C.c_longlong
+    h.lib.czhip_selftest_fastdiv.argtypes = [h.creal]
+    for d in (6.0, 6.2, 6.3, -6.0, 7.3e-4, 1.9e7):
+        assert h.lib.czhip_selftest_fastdiv(d) == 0, d
+    assert h.lib.czhip_selftest_fastdiv(3.0e38 if prec == "f32" else 1e300) == -1

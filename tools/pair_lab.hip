@@ -1,8 +1,8 @@
 // tools/pair_lab.hip -- stand-alone A/B bench of the two-stage pass kernels (jacobi2_k vs jacobi2p_k) on random fields:
 // bitwise comparison of the output field, both residual sums, ms per launch.  Compiles in seconds (the library's translation unit
 // takes minutes), which is what the kernel work of round 2 iterated on.
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -Icubez_amd/csrc -Iinclude tools/pair_lab.hip -o /tmp/pair_lab [-DCZ_REAL_IS_DOUBLE]
-//   /tmp/pair_lab [N=512] [TJ=16] [reps=30] [rb=0] [ni nj nk]
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -Icubez_amd/csrc -Iinclude -Itools tools/pair_lab.hip -o tools/bin/pair_lab [-DCZ_REAL_IS_DOUBLE]
+//   tools/bin/pair_lab N reps rb ni nj nk TBxTJ [TBxTJ ...]      (ni = 0: cube of N; -DCZ_P2_PLAIN_DIV: jacobi2p_k with the ordinary division)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -23,7 +23,9 @@ constexpr int VW = 4;
 
 namespace {
 #include "cz_k_common.h"
+#include "cz_k_fastdiv.h"
 #include "cz_k_pair.h"
+#include "pair_lab_v1.h"
 #include "cz_k_pair2.h"
 
 __global__ void fill_k(REAL* x, size_t n, unsigned seed, REAL scale) {
