@@ -346,21 +346,17 @@ int CZ::Setup(int argc, char** argv) {
 
   ItrMax = atoi(argv[5]);  // :330
 
-  if ((ls_type == LS_PSOR || ls_type == LS_PSOR_MAF || pc_type == LS_PSOR || pc_type == LS_PSOR_MAF) && numProc > 1) {
-    // a lexicographic sweep is one wavefront through the whole grid; this build does not pipeline it across ranks
-    Hostonly_ printf("psor : single-domain runs only in this build\n");
-    return 0;
-  }
   auto is_line = [](int t) {
     return (t >= LS_PCR && t <= LS_PCR_J_ESA) || (t >= LS_PCR_MAF && t <= LS_PCR_RB_ESA_MAF);
   };
   if (is_line(ls_type) || is_line(pc_type)) {
-    // A k-line is solved by one wave: bricks must hold whole lines (no cut along k).  The colour and Jacobi orders exchange
-    // ghost columns after each colour / iteration and reproduce the single-domain run; the lexicographic orders (pcr, pcr_esa)
-    // are one wavefront through the grid and stay single-domain.
-    auto is_lex = [](int t) { return t == LS_PCR || t == LS_PCR_EDA || t == LS_PCR_ESA || t == LS_PCR_MAF || t == LS_PCR_EDA_MAF || t == LS_PCR_ESA_MAF; };
-    if (numProc > 1 && (G_div[2] > 1 || is_lex(ls_type) || is_lex(pc_type))) {
-      Hostonly_ printf("line SOR (pcr*) : decomposed runs need whole k-lines (gdv_z = 1) and the colour or Jacobi order\n");
+    // A k-line is solved by one wave: bricks must hold whole lines (no cut along k).  The colour and Jacobi orders exchange ghost
+    // columns after each colour / iteration and reproduce the single-domain run.  The lexicographic orders (pcr, pcr_eda, pcr_esa and
+    // psor) are one wavefront through the whole grid: decomposed, every brick sweeps its own cells in that order with the ghost values
+    // of the last exchange -- the reference's MPI semantics (one Comm_S per iteration, cz_Poisson.cpp:124,794), block Gauss-Seidel, NOT
+    // the single-domain iterate (tests/test_gpu_decomp.py checks it against the same loop restated with the oracle's kernels).
+    if (numProc > 1 && G_div[2] > 1) {
+      Hostonly_ printf("line SOR (pcr*) : decomposed runs need whole k-lines (gdv_z = 1)\n");
       return 0;
     }
     MSK = czhip_alloc_s3d(size);            // :242
@@ -996,7 +992,9 @@ int CZ::PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double&
   for (itr = 1; itr <= itr_max && !stop; itr++) {
     psor_async(X, B, size, innerFidx, gc, cf, maf ? d_xc : nullptr, d_yc, d_zc, ac1, d_res, 0, skip);  // :108-122
     flop += (maf ? 66.0 : 18.0) * npts();
+    if (!Comm_S(X, skip)) return 0;  // :124 (decomposed: block-local sweeps, ghosts of the last exchange)
     if (converge_check) {
+      if (!Comm_SUM_dev(d_res, 1, skip)) return 0;                                 // :127
       czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);  // :128-141 on the device
       if (itr % POLL_EVERY == 0 && itr < itr_max) {  // lagging, non-blocking view of the flag (as in RBSOR)
         const int slot = npoll % POLL_SLOTS;
@@ -1049,6 +1047,7 @@ int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_
       }
     } else if (order == 1) {
       pcr_variant_async(X, nullptr, MSK, B, size, innerFidx, gc, pn, 1, 0, final4, ac1, d_res, 0);  // :783-786, :966-969
+      if (!Comm_S(X)) return 0;  // :794 (decomposed: block-local, see CZ::Setup)
     } else {
       pcr_variant_async(X, WRK, MSK, B, size, innerFidx, gc, pn, 2, 0, final4, ac1, d_res, 0);  // :1061-1064
       copy_inner_async(X, WRK, size, innerFidx, gc);
@@ -1103,6 +1102,7 @@ int CZ::LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max,
       }
     } else {
       pcr_maf_async(X, MSK, B, size, innerFidx, gc, pn, 1, 0, d_xc, d_yc, d_zc, ac1, d_res, 0);
+      if (!Comm_S(X)) return 0;
     }
     flop += (npts() / n) * ((24.0 + 6.0 + 12.0) + n * 21.0 + (n - 2.0) * 6.0 + n * (double)(pn - 1) * 16.0 + (double)(1 << (pn - 1)) * fin + n * 6.0);
     if (converge_check) {
