@@ -350,15 +350,13 @@ int CZ::Setup(int argc, char** argv) {
     return (t >= LS_PCR && t <= LS_PCR_J_ESA) || (t >= LS_PCR_MAF && t <= LS_PCR_RB_ESA_MAF);
   };
   if (is_line(ls_type) || is_line(pc_type)) {
-    // A k-line is solved by one wave: bricks must hold whole lines (no cut along k).  The colour and Jacobi orders exchange ghost
-    // columns after each colour / iteration and reproduce the single-domain run.  The lexicographic orders (pcr, pcr_eda, pcr_esa and
-    // psor) are one wavefront through the whole grid: decomposed, every brick sweeps its own cells in that order with the ghost values
-    // of the last exchange -- the reference's MPI semantics (one Comm_S per iteration, cz_Poisson.cpp:124,794), block Gauss-Seidel, NOT
-    // the single-domain iterate (tests/test_gpu_decomp.py checks it against the same loop restated with the oracle's kernels).
-    if (numProc > 1 && G_div[2] > 1) {
-      Hostonly_ printf("line SOR (pcr*) : decomposed runs need whole k-lines (gdv_z = 1)\n");
-      return 0;
-    }
+    // Decomposed line SOR.  The colour and Jacobi orders exchange ghost columns after each colour / iteration: with whole k-lines per
+    // brick (gdv_z = 1) they reproduce the single-domain run bit for bit.  What cannot: (a) a cut along k -- every brick then solves ITS
+    // piece of a line with the neighbour's last values beyond its ends, exactly what the reference's MPI path does with CBrick bricks;
+    // (b) the lexicographic orders (pcr, pcr_eda, pcr_esa, and psor), one wavefront through the whole grid -- every brick sweeps its own
+    // cells in that order with the ghost values of the last exchange, one Comm_S per iteration (cz_Poisson.cpp:124, 794).  Both are
+    // block-local iterations, NOT the single-domain iterate; tests/test_gpu_decomp.py pins them against the same loops restated with the
+    // oracle's kernels (tests/blocklocal.py).
     MSK = czhip_alloc_s3d(size);            // :242
     imask_async(MSK, size, innerFidx, gc);  // :389
   }

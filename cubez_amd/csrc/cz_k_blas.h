@@ -164,9 +164,7 @@ dot_k(const REAL* X, const REAL* Y, EGeom g, int nplanes, double* partials, doub
   const int me = blockIdx.y * gridDim.x + blockIdx.x;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&partials[me], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_flag = (ticket == (unsigned)nblk - 1u);
+    last_flag = arrive_and_test_last(counter, nblk);
   }
   __syncthreads();
   if (last_flag) {
@@ -232,9 +230,7 @@ triad_dots_k(REAL* Z, const REAL* X, const REAL* Y, const REAL* W, REAL a, EGeom
   if (threadIdx.x == 0) {
     __hip_atomic_store(&partials[me], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&partials[nblk + me], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_flag = (ticket == (unsigned)nblk - 1u);
+    last_flag = arrive_and_test_last(counter, nblk);
   }
   __syncthreads();
   if (last_flag) {

@@ -95,6 +95,31 @@ __device__ __forceinline__ double block_sum(double x, double* wsum /* TB/64 doub
   return s;  // valid on thread 0
 }
 
+
+// Hand-off of the per-workgroup partial sums to the workgroup that arrives last (in-kernel finalisation; no extra launch per sweep).
+// Why it is sound (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"; cdna_hip_programming.md G16):
+//   producer  lane 0 of every workgroup stores its partials with agent-scope relaxed atomic stores = `global_store ... sc1`: write-through,
+//             the bytes leave the XCD's L2 for memory.  `s_waitcnt vmcnt(0)` (inline asm, so that no compiler pass can drop or move it)
+//             holds the lane until those stores are acknowledged -- on gfx9 stores are counted in vmcnt -- and only then the lane adds to
+//             the agent-scope ticket.  One lane signals for all of its workgroup's handed-off bytes because that lane stored all of them.
+//   consumer  the workgroup whose add returned nblk-1 knows every other add, hence every other drain, came before its own.  Its lane 0
+//             then executes ONE agent-scope acquire (`buffer_inv sc1`: no line of this CU's L1 survives) and waits for it; the
+//             workgroup barrier that follows releases the other waves; all of them read the partials with agent-scope relaxed loads
+//             (`sc1`: served from L2 / memory, never from L1).  The acquire costs about 1.7 us once per launch (one workgroup); a
+//             release fence in every producer instead cost 27 % of a whole sweep (it writes back the XCD's dirty output lines).
+//   The ticket is reset by the finishing workgroup and again at the start of every solve (reset_ticket).
+// Called by lane 0 after its partial stores; returns true in the workgroup that must finalise.
+__device__ __forceinline__ bool arrive_and_test_last(unsigned* counter, int nblk) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool last = (ticket == (unsigned)nblk - 1u);
+  if (last) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  return last;
+}
+
 // MAF flavour (cz_maf.f90, cz_blas.f90:738-1039): the six neighbour weights and the diagonal are
 // recomputed at every point from 1-D coordinate arrays (device copies of xc, yc, zc; X(i) of the Fortran is xc[i+1], which
 // for g = 2 is xc[padded index]).  pvt: row scaling of calc_ax_maf / calc_rk_maf.

@@ -175,9 +175,7 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
   const int nblk = gridDim.x;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *last_flag = (ticket == (unsigned)nblk - 1u);
+    *last_flag = arrive_and_test_last(counter, nblk);
   }
   __syncthreads();
   if (*last_flag) {
@@ -531,9 +529,7 @@ pcr_rb2_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restr
   const int nblk = gridDim.x;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *last_flag = (ticket == (unsigned)nblk - 1u);
+    *last_flag = arrive_and_test_last(counter, nblk);
   }
   __syncthreads();
   if (*last_flag) {
@@ -800,9 +796,7 @@ pcr_line_reg_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __
   const int nblk = gridDim.x;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *last_flag = (ticket == (unsigned)nblk - 1u);
+    *last_flag = arrive_and_test_last(counter, nblk);
   }
   __syncthreads();
   if (*last_flag) {
@@ -984,9 +978,7 @@ pcr_line_reg_maf_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict
   const int nblk = gridDim.x;
   if (threadIdx.x == 0) {
     __hip_atomic_store(&partials[blockIdx.x], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *last_flag = (ticket == (unsigned)nblk - 1u);
+    *last_flag = arrive_and_test_last(counter, nblk);
   }
   __syncthreads();
   if (*last_flag) {

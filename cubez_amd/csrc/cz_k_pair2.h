@@ -287,9 +287,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
   if (t == 0) {
     __hip_atomic_store(&partials[lb], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&partials[nblk + lb], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = __hip_atomic_fetch_add(fin.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *last_flag = (ticket == (unsigned)nblk - 1u);
+    *last_flag = arrive_and_test_last(fin.counter, nblk);
   }
   __syncthreads();
   if (*last_flag) pair_finalize<TB>(partials, nblk, fin, wsum);

@@ -1,7 +1,9 @@
-"""The decomposed loop of the lexicographic solvers (psor, pcr, pcr_eda, pcr_esa) restated with the oracle's kernels: every brick
-sweeps its own cells in lexicographic order with the ghost values of the last exchange, one one-layer exchange per iteration, residual
-summed over the bricks -- the reference's MPI semantics (cz_Poisson.cpp:95-146 PSOR, :745-826 LSOR_PCR: local sweep, Comm_S, Comm_SUM_1),
-on this build's cell-ownership bricks (cubez_amd/decomp.py).  The ranks are emulated one after the other in this process: within an
+"""The decomposed loops that are block-local by nature, restated with the oracle's kernels: the lexicographic solvers (psor, pcr, pcr_eda,
+pcr_esa: every brick sweeps its own cells in lexicographic order with the ghost values of the last exchange, one one-layer exchange per
+iteration) and the colour / Jacobi line solvers under a cut along k (pcr_rb, pcr_rb_esa: global (i+j) colouring, exchange after each
+colour; pcr_j_esa: one exchange per iteration; every brick solves its piece of a k-line) -- the reference's MPI semantics
+(cz_Poisson.cpp:95-146 PSOR, :518-611 LSOR_PCR_RB, :745-826 LSOR_PCR: local sweep, Comm_S, Comm_SUM_1), on this build's cell-ownership
+bricks (cubez_amd/decomp.py).  The ranks are emulated one after the other in this process: within an
 iteration no brick reads what another brick writes, so the order does not matter.  TEST INFRASTRUCTURE."""
 import numpy as np
 
@@ -52,10 +54,26 @@ def run(gsz, div, solver, nit, coef, prec):
             w = np.zeros(1)
             if solver == "psor":
                 k.psor(d["P"], d["size"], d["idx"], cf, coef, d["RHS"], wide=w)
+            elif solver in ("pcr_rb", "pcr_rb_esa"):
+                continue  # colour by colour below
             else:
                 k.pcr_sweep_wide(solver, d["size"], d["idx"], d["pn"], 0, d["P"], d["MSK"], d["RHS"], d["WRK"], coef, w)
+                if solver == "pcr_j_esa":  # all columns from the old field into WRK, then back (cz_Poisson.cpp:1061-1068)
+                    i = d["idx"]
+                    inner = (slice(i[2] + 1, i[3] + 2), slice(i[0] + 1, i[1] + 2), slice(i[4] + 1, i[5] + 2))
+                    d["P"][inner] = d["WRK"][inner]
             tot += float(w[0])
-        halo("P")
+        if solver in ("pcr_rb", "pcr_rb_esa"):
+            name = "pcr_rb_2x2" if solver == "pcr_rb" else "pcr_rb_esa"
+            for color in (0, 1):
+                for d in st:
+                    w = np.zeros(1)
+                    k.pcr_sweep_wide(name, d["size"], d["idx"], d["pn"], (color + d["head"][0] + d["head"][1]) & 1, d["P"], d["MSK"], d["RHS"], None,
+                                     coef, w)
+                    tot += float(w[0])
+                halo("P")
+        else:
+            halo("P")
         hist.append(float(np.sqrt(tot / npts)))
     g = 2
     G = np.zeros((gsz[1] + 4, gsz[0] + 4, gsz[2] + 4), dtype=R)

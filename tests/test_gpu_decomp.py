@@ -217,45 +217,25 @@ def test_decomposed_bicgstab(pc):
     assert np.abs(G[2:-2, 2:-2, 2:-2] - P1[2:-2, 2:-2, 2:-2]).max() < 1e-9
 
 
-def test_line_sor_refuses_a_cut_along_k():
-    """a k-line is solved by one wave: bricks must hold whole lines"""
-    import ctypes as C
-    from cubez_amd import CZ, load
-    lib = load("f32")
-    lib.cz_comm_local_world.restype = C.c_void_p
-    lib.cz_comm_bootstrap_local.argtypes = [C.c_void_p, C.c_int]
-    lib.cz_comm_local_world_free.argtypes = [C.c_void_p]
-    for solver, div in (("pcr_rb", (1, 1, 2)), ("pcr", (1, 1, 2))):
-        world = lib.cz_comm_local_world(2)
-        rets = [None, None]
-
-        def work(r):
-            lib.cz_comm_bootstrap_local(world, r)
-            cz = CZ("f32", quiet=True)
-            rets[r] = cz.setup([32, 32, 32, solver, 4, 1.2] + list(div))
-            cz.close()
-
-        th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
-        [t.start() for t in th]
-        [t.join(timeout=120) for t in th]
-        lib.cz_comm_local_world_free(world)
-        assert rets == [0, 0], (solver, div, rets)
-
-
 BLOCK_LOCAL = [
     ("f32", (40, 36, 44), "psor", 8, 1.2, (2, 1, 1)),
     ("f64", (41, 37, 45), "psor", 6, 1.3, (2, 2, 2)),     # uneven bricks, cuts along all three axes
     ("f32", (40, 39, 32), "pcr", 6, 1.2, (1, 3, 1)),
     ("f64", (36, 40, 32), "pcr_esa", 5, 1.2, (2, 2, 1)),
     ("f32", (40, 36, 64), "pcr_eda", 5, 1.2, (2, 1, 1)),
+    ("f32", (40, 36, 64), "pcr_rb", 6, 1.2, (1, 1, 2)),       # a cut along k: every brick solves its piece of a line
+    ("f64", (41, 37, 70), "pcr_rb_esa", 5, 1.2, (2, 1, 2)),
+    ("f64", (36, 40, 64), "pcr_j_esa", 5, 0.9, (1, 2, 2)),
+    ("f32", (40, 36, 66), "pcr", 4, 1.2, (1, 1, 3)),
 ]
 
 
 @pytest.mark.parametrize("case", BLOCK_LOCAL, ids=[f"{c[2]}_{c[0]}_{'x'.join(map(str, c[5]))}" for c in BLOCK_LOCAL])
-def test_decomposed_lexicographic_solvers_are_block_local_like_the_reference(case):
-    """VERDICT r1 "missing" 5: the reference accepts decomposed runs of its lexicographic solvers and sweeps every brick on its own with
-    the ghost values of the last exchange (cz_Poisson.cpp:124, :794).  Same here; the result is that loop's, not the single-domain
-    iterate: compared bit for bit with the loop restated on the oracle's kernels (tests/blocklocal.py)."""
+def test_block_local_decompositions_like_the_reference(case):
+    """VERDICT r1 "missing" 5: the reference accepts decomposed runs of its lexicographic solvers, and cuts along k for its line solvers,
+    and sweeps every brick on its own with the ghost values of the last exchange (cz_Poisson.cpp:124, :586, :794).  Same here; the result
+    is that loop's, not the single-domain iterate: compared bit for bit with the loop restated on the oracle's kernels
+    (tests/blocklocal.py)."""
     from blocklocal import run as block_local_run
     prec, gsz, solver, nit, coef, div = case
     hist_o, G_o = block_local_run(gsz, div, solver, nit, coef, prec)

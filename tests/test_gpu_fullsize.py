@@ -147,6 +147,48 @@ def test_sweep_is_exactly_linear_under_power_of_two_scaling():
         a.free()
 
 
+def test_residual_handoff_with_tens_of_thousands_of_tiny_workgroups():
+    """The in-kernel finalisation of the residual (cz_k_common.h: arrive_and_test_last) under the load it was NOT tuned for: the two-stage
+    pass cut into one-plane chunks, 44 880 workgroups of three plane steps each, several per CU at very different times, the last arriver
+    with a warm L1.  Launches alternate between a field and its double (every partial then differs by exactly 4x between neighbours in
+    time), so a partial read stale -- from L1, from another XCD's L2, from the previous launch -- cannot hide: every launch must return
+    the bits of its own sums, and those must equal the sums of the ordinary geometry to rounding and the oracle's to 1e-11."""
+    from cubez_amd import CzHip
+    h = CzHip("f32")
+    sz, idx = [N, N, N], [2, N - 1, 2, N - 1, 2, N - 1]
+    rng = np.random.default_rng(7)
+    shape = (N + 4, N + 4, N + 4)
+    p = rng.uniform(-1, 1, shape).astype(np.float32)
+    b = rng.uniform(-1, 1, shape).astype(np.float32)
+    cf = np.array([1.1, 0.9, 1.05, 0.95, 1.2, 0.8, 6.3], dtype=np.float32)
+    dA, bA, dB, bB = h.alloc(sz, p), h.alloc(sz, b), h.alloc(sz, p * np.float32(2)), h.alloc(sz, b * np.float32(2))
+    dw = h.alloc(sz, p)
+    try:
+        assert h.set_tuning2(-2, 2, 0, 1)
+        ok, a1, a2 = h.jacobi2(dA, dw, bA, sz, idx, cf, 0.8)
+        assert ok
+        assert h.set_tuning2(512, 2, 1, 1)  # one plane per chunk
+        seen = []
+        for it in range(24):
+            src, rhs, scale = (dA, bA, 1.0) if it % 2 == 0 else (dB, bB, 4.0)
+            ok, r1, r2 = h.jacobi2(src, dw, rhs, sz, idx, cf, 0.8)
+            assert ok
+            seen.append((r1 / scale, r2 / scale))
+        assert all(v == seen[0] for v in seen), sorted(set(seen))  # bitwise: scaling by 4 is exact
+        assert abs(seen[0][0] - a1) <= 1e-12 * a1 and abs(seen[0][1] - a2) <= 1e-12 * a2
+    finally:
+        h.set_tuning2(-2, 2, 0, 1)
+    k = O.Kernels("oracle", "f32")
+    a, w, r = p.copy(), np.zeros_like(p), []
+    for _ in range(2):
+        wide = np.zeros(1)
+        k.jacobi(a, sz, idx, cf, 0.8, b, w, wide=wide)
+        r.append(wide[0])
+    assert abs(seen[0][0] - r[0]) <= 1e-11 * r[0] and abs(seen[0][1] - r[1]) <= 1e-11 * r[1]
+    for x in (dA, bA, dB, bB, dw):
+        x.free()
+
+
 def test_decomposed_512_equals_single_domain():
     """`cz 512 512 512 jacobi 6 0.8 1 2 1` (two ranks as threads on this GPU, LOCAL transport) == the single-domain run."""
     from cubez_amd import CZ, load
