@@ -649,7 +649,8 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     int first_itr, nsweep, src;
   };
   std::vector<Launch> launches;
-  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2 && !maf && pairs_ok;  // the MAF flavour runs sweep by sweep
+  // (the MAF flavour forms pairs in single-domain runs only: the shell kernel of the overlapped exchange has no MAF form)
+  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2 && pairs_ok && (!maf || numProc == 1);
   int idx1[6];  // index range of the first sweep of a pair: one layer into the ghost cells across rank-internal faces
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
   if (can_pair && numProc > 1) {
@@ -718,8 +719,12 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     }
     if (!done && can_pair && itr + 1 <= itr_max) {
       const bool in_kernel_check = converge_check && numProc == 1;
-      done = 2 * czhip_jacobi2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res, res_normal, eps, itr,
-                                     in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :58 + :67-77, twice
+      if (maf)
+        done = 2 * pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, -1, d_res, res_normal, eps, itr,
+                                  in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :45-53 twice
+      else
+        done = 2 * czhip_jacobi2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res, res_normal, eps, itr,
+                                       in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :58 + :67-77, twice
       if (!done) {
         can_pair = false;
       } else if (numProc > 1) {
@@ -795,7 +800,11 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       if (last->nsweep == 2 && ret == last->first_itr) {
         // the first sweep of a fused pair converged: the pair wrote time n+2 into its destination; its source is
         // untouched, so one plain sweep reproduces the converged iterate (exactly what the sequential loop holds)
-        czhip_jacobi_async(buf[last->src], buf[(last->src + 1) % nbuf], B, size, innerFidx, gc, cf, ac1, d_res + 4, 0, nullptr);  // (never MAF: pairs are not formed there)
+        if (maf)
+          jacobi_maf_async(buf[last->src], buf[(last->src + 1) % nbuf], B, size, innerFidx, gc, d_xc, d_yc, d_zc, ac1, d_res + 4, nullptr, 0, 0.0, 0.0,
+                           0, nullptr, nullptr, nullptr);
+        else
+          czhip_jacobi_async(buf[last->src], buf[(last->src + 1) % nbuf], B, size, innerFidx, gc, cf, ac1, d_res + 4, 0, nullptr);
       }
     }
     final_buf = (last->src + 1) % nbuf;
@@ -834,7 +843,7 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   // Preferred form: the whole iteration (colour 0, then colour 1) in ONE pass over memory, out of place X <-> WRK
   // (czhip_rbsor2_async); decomposed runs then exchange two ghost layers once per iteration.  Fallback: the reference's
   // two in-place colour launches with an exchange after each colour.
-  bool fused = czhip_use_t2() != 0 && !maf && pairs_ok;
+  bool fused = czhip_use_t2() != 0 && pairs_ok && (!maf || numProc == 1);
   int idx1[6];
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
   REAL_TYPE* buf[3] = {X, WRK, nullptr};
@@ -892,9 +901,12 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
     if (fused && !done) {
       REAL_TYPE* src = buf[cur];
       REAL_TYPE* dst = buf[(cur + 1) % nbuf];
-      if (czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
-                             in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip)) {  // :205-209 (+ :218-230)
-        flop += 18.0 * npts();
+      const int launched = maf ? pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, ip, d_res, res_normal, eps, itr,
+                                                in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip)  // :190-200
+                               : czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
+                                                    in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :205-209 (+ :218-230)
+      if (launched) {
+        flop += (maf ? 66.0 : 18.0) * npts();
         if (numProc > 1) {
           if (!Comm_S2(dst, skip)) return 0;  // :215
           if (converge_check) {

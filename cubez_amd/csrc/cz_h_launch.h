@@ -119,9 +119,9 @@ inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, int* tj_out) {
 }
 
 // two fused sweeps (jacobi2p_k); returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
-template <int TB, int MV, int RB, int ZU>
+template <int TB, int MV, int RB, int ZU, int MAF = 0>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
-                         const int* skip, const Fin2& fin_in, int par, bool probe, double* model_cost) {
+                         const int* skip, const Fin2& fin_in, int par, bool probe, double* model_cost, const MafArgs& ma = MafArgs()) {
   constexpr int V = VW;
   Geom2 g;
   g.R = b.nkp / V;
@@ -140,7 +140,8 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   const long long nf = g.Fend - g.F0;
   g.nseg = (int)((nf + g.S - 1) / g.S);
   const int nplanes = b.jj1 - b.jj0 + 1;
-  const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double);
+  const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double) +
+                     (MAF ? (size_t)2 * b.nkp * sizeof(REAL) : 0);  // MAF: the table of the k metric terms
   if (lds > 160 * 1024) return false;
   const int wg_per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / TB));
   int tj = tj_req;
@@ -155,7 +156,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU, MAF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
@@ -163,7 +164,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   fin.counter = ctx.counter;
   {
     ScopedTimer tm(RB ? LBL_RBSOR2 : LBL_JACOBI2);
-    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
+    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU, MAF>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin, ma);
   }
   HIP_CHECK(hipGetLastError());
   return true;
@@ -171,9 +172,10 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
 
 template <int RB>
 bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
-                    const Fin2& fin, int par = 0, int zero_u = 0, bool probe = false) {
+                    const Fin2& fin, int par = 0, int zero_u = 0, bool probe = false, const MafArgs* ma = nullptr) {
   if (!vec_ok(b, {U, B, W})) return false;
-  if (!fastdiv_ok(c.dd)) return false;  // jacobi2p_k divides by dd with the hoisted form (cz_k_fastdiv.h); odd magnitudes take single sweeps
+  if (!ma && !fastdiv_ok(c.dd)) return false;  // jacobi2p_k divides by dd with the hoisted form (cz_k_fastdiv.h); odd magnitudes take single sweeps
+  if (ma && b.g != 2) return false;             // the MAF kernels index the coordinate arrays with the padded index (GUIDE = 2)
   // the stage-1 box may exceed the output box by at most one layer per side
   if (ba.ii0 < b.ii0 - 1 || ba.ii0 > b.ii0 || ba.ii1 > b.ii1 + 1 || ba.ii1 < b.ii1 || ba.jj0 < b.jj0 - 1 || ba.jj0 > b.jj0 ||
       ba.jj1 > b.jj1 + 1 || ba.jj1 < b.jj1 || ba.kk0 < b.kk0 - 1 || ba.kk0 > b.kk0 || ba.kk1 > b.kk1 + 1 || ba.kk1 < b.kk1)
@@ -190,6 +192,10 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
     const bool ok1024 = launch_jacobi2_inst<1024, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, true, &c1024);
     if (!ok512 && !ok1024) return false;
     tb = (ok512 && (!ok1024 || c512 <= c1024)) ? 512 : 1024;
+  }
+  if (ma) {  // MAF flavour (cz_maf.f90): weights recomputed per point from the 1-D grids
+    if (tb == 512 && launch_jacobi2_inst<512, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma)) return true;
+    return launch_jacobi2_inst<1024, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma);
   }
   if (RB == 0 && zero_u) {
     if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);

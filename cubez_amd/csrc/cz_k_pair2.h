@@ -66,11 +66,76 @@ __device__ __forceinline__ double lane_shl1(double edge, double x) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
+// The MAF flavour of the per-point update (cz_maf.f90:193-225, operation for operation as in stencil_k<..., MAF = 1>): the six weights and
+// the diagonal are recomputed at every point from the metric terms of the 1-D grids -- XG, XGG of the row, YE, YEE of the plane, ZT, ZTT of
+// the component.
+template <int V>
+__device__ __forceinline__ Vec<V> relax_vec_maf(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm, const Vec<V>& pn,
+                                                REAL kl, REAL kr, const Vec<V>& bb, REAL XG, REAL XGG, REAL YE, REAL YEE, const Vec<V>& ZT,
+                                                const Vec<V>& ZTT, REAL omg, unsigned mask, unsigned count_mask, double& acc) {
+  Vec<V> o;
+#pragma unroll
+  for (int cc = 0; cc < V; cc++) {
+    const REAL pp = pc.v[cc];
+    const REAL km1 = (cc == 0) ? kl : pc.v[cc > 0 ? cc - 1 : 0];
+    const REAL kp1 = (cc == V - 1) ? kr : pc.v[cc < V - 1 ? cc + 1 : V - 1];
+    const MafW w = maf_weights(XG, XGG, YE, YEE, ZT.v[cc], ZTT.v[cc]);
+    const REAL rp = w.w1 * ip.v[cc] + w.w2 * im.v[cc] + w.w3 * pn.v[cc] + w.w4 * pm.v[cc] + w.w5 * kp1 + w.w6 * km1 + bb.v[cc];  // :219-225
+    const REAL dp = (rp / w.dd - pp) * omg;
+    const REAL d2 = dp * dp;
+    o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;
+    acc += (double)((count_mask & (1u << cc)) ? d2 : (REAL)0);
+  }
+  return o;
+}
+
+// Red-black stage: only every other component of a vector belongs to the colour being updated -- component s, s+2 (FP32) / s (FP64), with
+// s = (k + i + j + parity) & 1 of component 0, a per-lane value.  The operands of those components are selected first and the update is
+// evaluated for V/2 points instead of V (the other colour passes through): same arithmetic on the updated points, hence the same bits,
+// at roughly half the vector instructions of the stage.  `point(pp, ip, im, pn, pm, kp1, km1, bb, zt, ztt)` returns dp.
+template <int V>
+__device__ __forceinline__ typename NatVec<V>::type as_native(const Vec<V>& a) {
+  typename NatVec<V>::type x;
+  __builtin_memcpy(&x, &a, sizeof(x));
+  return x;
+}
+
+template <int V, class F>
+__device__ __forceinline__ Vec<V> relax_vec_rb(const Vec<V>& pc_, const Vec<V>& im_, const Vec<V>& ip_, const Vec<V>& pm_, const Vec<V>& pn_,
+                                               REAL kl, REAL kr, const Vec<V>& bb_, const Vec<V>& zt_, const Vec<V>& ztt_, bool s, unsigned mask,
+                                               unsigned count_mask, double& acc, const F& point) {
+  static_assert(V == 2 || V == 4, "vector of two or four components");
+  // (native vector VALUES: a select between two elements of an in-memory array is turned into an indexed load, which sends the
+  // register arrays of the whole kernel to scratch)
+  const auto pc = as_native<V>(pc_), im = as_native<V>(im_), ip = as_native<V>(ip_), pm = as_native<V>(pm_), pn = as_native<V>(pn_),
+             bb = as_native<V>(bb_), zt = as_native<V>(zt_), ztt = as_native<V>(ztt_);
+  auto o = pc;
+  const unsigned ms = s ? (mask >> 1) : mask, cs = s ? (count_mask >> 1) : count_mask;  // bit 2a: slot a
+#pragma unroll
+  for (int a = 0; a < V / 2; a++) {
+    const int c0 = 2 * a, c1 = 2 * a + 1;  // the slot's component when s = 0 / s = 1
+    const REAL pp = s ? pc[c1] : pc[c0];
+    const REAL km1 = s ? pc[c0] : (c0 == 0 ? kl : pc[c0 > 0 ? c0 - 1 : 0]);
+    const REAL kp1 = s ? (c1 == V - 1 ? kr : pc[c1 < V - 1 ? c1 + 1 : V - 1]) : pc[c1];
+    const REAL dp = point(pp, s ? ip[c1] : ip[c0], s ? im[c1] : im[c0], s ? pn[c1] : pn[c0], s ? pm[c1] : pm[c0], kp1, km1,
+                          s ? bb[c1] : bb[c0], s ? zt[c1] : zt[c0], s ? ztt[c1] : ztt[c0]);
+    const REAL d2 = dp * dp;
+    const REAL nw = (ms & (1u << c0)) ? pp + dp : pp;
+    o[c0] = s ? pc[c0] : nw;
+    o[c1] = s ? nw : pc[c1];
+    acc += (double)((cs & (1u << c0)) ? d2 : (REAL)0);
+  }
+  Vec<V> r;
+  __builtin_memcpy(&r, &o, sizeof(r));
+  return r;
+}
+
 // ZU = 1: the input field is identically zero and is not read (the first pair of a preconditioner solve).
-template <int V, int TB, int MV, int RB, int ZU>
+// MAF = 1: weights from the 1-D coordinate arrays `ma` (device copies; index = padded index for g = 2) instead of c.
+template <int V, int TB, int MV, int RB, int ZU, int MAF = 0>
 __global__ void __launch_bounds__(TB, TB == 512 ? 4 : 1)
 jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
-           const int* __restrict__ skip, Fin2 fin) {
+           const int* __restrict__ skip, Fin2 fin, MafArgs ma) {
   if (skip != nullptr && *skip != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -80,6 +145,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
   Vec<V>* ldsU = reinterpret_cast<Vec<V>*>(smem);                   // 2 buffers of LU vectors
   Vec<V>* ldsV = ldsU + (size_t)2 * LU;                              // 2 buffers of LV vectors
   double* wsum = reinterpret_cast<double*>(ldsV + (size_t)2 * LV);   // 16 doubles + flag
+  REAL* ztab = reinterpret_cast<REAL*>(wsum + 18);                   // MAF: ZT[k], then ZTT[k], k = 0 .. nkp-1
 
   int lb = blockIdx.x;
   const int nblk = gridDim.x;
@@ -132,6 +198,31 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       pbase[m] = kv * V + (int)row + g.par;
       ka[m] = (f >= g.F0a && f < g.Fenda) ? bits1 : 0u;
       own[m] = (e >= R && e < LV - R && f >= g.F0 && f < g.Fend) ? bits2 : 0u;
+    }
+    REAL XG[MAF ? MV : 1], XGG[MAF ? MV : 1];  // MAF: metric terms of the rows of the thread's vectors
+    int kvo[MAF ? MV : 1];                      // MAF: first k of the vector (offset into ztab)
+    if (MAF) {
+      const int nkp = R * V;
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        const long long f = e1_0 + t + m * TB;
+        const long long row = f / R;
+        kvo[m] = (int)(f - row * R) * V;
+        int ii = (int)row;  // padded row index == index into xc for g = 2
+        if (ii < 1) ii = 1;
+        const int nip = (int)(g.PSV / R);
+        if (ii > nip - 2) ii = nip - 2;
+        const REAL xm = ma.xc[ii - 1], x0 = ma.xc[ii], xp = ma.xc[ii + 1];
+        XG[m] = (REAL)0.5 * (xp - xm);
+        XGG[m] = xp - (REAL)2.0 * x0 + xm;
+      }
+      for (int kk = t; kk < nkp; kk += TB) {
+        int kc = kk < 1 ? 1 : kk;
+        if (kc > nkp - 2) kc = nkp - 2;
+        const REAL zm = ma.zc[kc - 1], z0 = ma.zc[kc], zp = ma.zc[kc + 1];
+        ztab[kk] = (REAL)0.5 * (zp - zm);
+        ztab[nkp + kk] = zp - (REAL)2.0 * z0 + zm;
+      }
     }
     // the two outer rows of E2: the first R threads stage the lower one, the last R threads the upper one (2R <= TB)
     const bool has_halo = (t < R) || (t >= TB - R);
@@ -202,6 +293,12 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       const Vec<V>* cV = ldsV + (size_t)cur * LV;        // v(q-1) on E1
       Vec<V>* pV = ldsV + (size_t)(cur ^ 1) * LV;        // v(q-2), own vectors; receives v(q)
       const int w0 = (t & ~63);                          // first lane of the wave
+      REAL YE1 = 0, YEE1 = 0, YE2 = 0, YEE2 = 0;         // MAF: metric terms of plane q (stage 1) and q-1 (stage 2)
+      if (MAF) {
+        const REAL ya = ma.yc[q - 2 > 0 ? q - 2 : 0], yb = ma.yc[q - 1], y0 = ma.yc[q], yp = ma.yc[q + 1];
+        YE1 = (REAL)0.5 * (yp - yb), YEE1 = yp - (REAL)2.0 * y0 + yb;
+        YE2 = (REAL)0.5 * (y0 - ya), YEE2 = y0 - (REAL)2.0 * yb + ya;
+      }
 
       // ---- stage 1: v(q) on E1
       if (plane_inner) {
@@ -218,9 +315,35 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
           const REAL ehi = reinterpret_cast<const REAL*>(cU)[(size_t)(xw + 64) * V];
           const REAL kl = lane_shr1(elo, pc.v[V - 1]);
           const REAL kr = lane_shl1(ehi, pc.v[0]);
-          unsigned msk = ka[m];
-          if (RB) msk &= colour_bits<V>(pbase[m] + q);  // colour 0 on plane q
-          vc[m] = relax_vec<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], c, dv, msk, count1 ? (own[m] & msk) : 0u, acc1);
+          const unsigned msk = ka[m];
+          const unsigned cnt = count1 ? own[m] : 0u;
+          Vec<V> ZT = zerov<V>(), ZTT = zerov<V>();
+          if (MAF) {
+            ZT = lds_ld<V>(reinterpret_cast<const Vec<V>*>(ztab + kvo[m]));
+            ZTT = lds_ld<V>(reinterpret_cast<const Vec<V>*>(ztab + R * V + kvo[m]));
+          }
+          if (RB) {  // colour 0 on plane q: components with (pbase + cc + q) even
+            const bool sc = ((pbase[m] + q) & 1) != 0;
+            if (MAF) {
+              const REAL xg = XG[m], xgg = XGG[m], omg = c.omg;
+              vc[m] = relax_vec_rb<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], ZT, ZTT, sc, msk, cnt & msk, acc1,
+                                      [=](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL z, REAL zz) {
+                                        const MafW w = maf_weights(xg, xgg, YE1, YEE1, z, zz);
+                                        const REAL rp = w.w1 * ipv + w.w2 * imv + w.w3 * pnv + w.w4 * pmv + w.w5 * kp1 + w.w6 * km1 + bv;
+                                        return (rp / w.dd - pp) * omg;
+                                      });
+            } else {
+              vc[m] = relax_vec_rb<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], ZT, ZTT, sc, msk, cnt & msk, acc1,
+                                      [&](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL, REAL) {
+                                        const REAL ss = c.c1 * ipv + c.c2 * imv + c.c3 * pnv + c.c4 * pmv + c.c5 * kp1 + c.c6 * km1;
+                                        return (dv(ss - bv) - pp) * c.omg;
+                                      });
+            }
+          } else if (MAF) {
+            vc[m] = relax_vec_maf<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], XG[m], XGG[m], YE1, YEE1, ZT, ZTT, c.omg, msk, cnt & msk, acc1);
+          } else {
+            vc[m] = relax_vec<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], c, dv, msk, cnt & msk, acc1);
+          }
         }
       } else {
 #pragma unroll
@@ -244,9 +367,35 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
             const Vec<V> im = lds_ld<V>(cV + e - R);
             const Vec<V> ip = lds_ld<V>(cV + e + R);
             const Vec<V> pm = lds_ld<V>(pV + e);
-            unsigned m2 = own[m];
-            if (RB) m2 &= colour_bits<V>(pbase[m] + q);  // colour 1 on plane q-1
-            const Vec<V> o = relax_vec<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], c, dv, m2, m2, acc2);
+            const unsigned m2 = own[m];
+            Vec<V> ZT = zerov<V>(), ZTT = zerov<V>();
+            if (MAF) {
+              ZT = lds_ld<V>(reinterpret_cast<const Vec<V>*>(ztab + kvo[m]));
+              ZTT = lds_ld<V>(reinterpret_cast<const Vec<V>*>(ztab + R * V + kvo[m]));
+            }
+            Vec<V> o;
+            if (RB) {  // colour 1 on plane q-1: components with (pbase + cc + q - 1) odd
+              const bool sc = ((pbase[m] + q) & 1) != 0;
+              if (MAF) {
+                const REAL xg = XG[m], xgg = XGG[m], omg = c.omg;
+                o = relax_vec_rb<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], ZT, ZTT, sc, m2, m2, acc2,
+                                    [=](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL z, REAL zz) {
+                                      const MafW w = maf_weights(xg, xgg, YE2, YEE2, z, zz);
+                                      const REAL rp = w.w1 * ipv + w.w2 * imv + w.w3 * pnv + w.w4 * pmv + w.w5 * kp1 + w.w6 * km1 + bv;
+                                      return (rp / w.dd - pp) * omg;
+                                    });
+              } else {
+                o = relax_vec_rb<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], ZT, ZTT, sc, m2, m2, acc2,
+                                    [&](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL, REAL) {
+                                      const REAL ss = c.c1 * ipv + c.c2 * imv + c.c3 * pnv + c.c4 * pmv + c.c5 * kp1 + c.c6 * km1;
+                                      return (dv(ss - bv) - pp) * c.omg;
+                                    });
+              }
+            } else if (MAF) {
+              o = relax_vec_maf<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], XG[m], XGG[m], YE2, YEE2, ZT, ZTT, c.omg, m2, m2, acc2);
+            } else {
+              o = relax_vec<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], c, dv, m2, m2, acc2);
+            }
             if (own[m] == (1u << V) - 1) {
               st16<V>(Wq, bo[m], o);
             } else {

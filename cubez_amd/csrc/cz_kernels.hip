@@ -411,6 +411,16 @@ int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const
   return czhip_internal::pair_box_async(u, w, b, sz, in0, in1, g, cf, omg, rb, res_dev, 1, nullptr);
 }
 
+// MAF flavour of czhip_jacobi2_async / czhip_rbsor2_async (rb_ofst < 0: two jacobi_maf sweeps, res_dev[0..1]; rb_ofst >= 0: one red-black
+// iteration with that ofst, res_dev[0]).  X, Y, Z are HOST coordinate arrays like those of the drop-in *_maf_ symbols.
+int czhip_pair_maf_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* X,
+                         const CZ_REAL* Y, const CZ_REAL* Z, CZ_REAL omg, int rb_ofst, double* res_dev) {
+  ensure_init();
+  const MafArgs ma = upload_xyz(sz, g, X, Y, Z, nullptr);
+  return czhip_internal::pair_maf_async(u, w, b, sz, idx, idx, g, ma.xc, ma.yc, ma.zc, omg, rb_ofst, res_dev, 0.0, 0.0, 0, nullptr, nullptr,
+                                        nullptr, nullptr);
+}
+
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable) {
   Tuning t = ctx.tune;
   if (threads > 0) t.t2_threads = threads;
@@ -946,6 +956,29 @@ void rbsor_maf_async(REAL* p, const REAL* b, const int* sz, const int* idx, int 
   if (check) ck.enabled = 1, ck.itr = itr, ck.res_normal = res_normal, ck.eps = eps, ck.hist = hist, ck.flag = flag, ck.conv_itr = conv_itr;
   sweep_async<MODE_RB>(p, p, b, bx, make_coef_omg(omg), rb_parity(g, idx, ofst, color), res_dev, accumulate, check ? flag : skip, ck,
                        &ma);
+}
+// MAF flavour of the two-stage pass (cz_maf.f90:131-285 twice / both colours of :287-438): two jacobi_maf sweeps (rb_ofst < 0; res_dev[0..1])
+// or one red-black iteration (rb_ofst = the reference's ofst; res_dev[0]) per pass over memory, u -> w.  Same conventions as
+// czhip_jacobi2_async; returns 0 when the geometry does not suit the kernel (nothing launched).
+int pair_maf_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g, const REAL* xc,
+                   const REAL* yc, const REAL* zc, REAL omg, int rb_ofst, double* res_dev, double res_normal, double eps, int itr,
+                   double* hist_dev, int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev) {
+  ensure_init();
+  if (!ctx.tune.fuse_fin) return 0;
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty || g < 2) return 0;
+  const Box ba = idx1 ? make_box(sz, idx1, g) : bx;
+  MafArgs ma{xc, yc, zc, nullptr};
+  Fin2 fin;
+  fin.dst = res_dev;
+  fin.single = rb_ofst >= 0;
+  if (hist_dev) {
+    fin.do_check = 1, fin.itr = itr, fin.res_normal = res_normal, fin.eps = eps;
+    fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
+  }
+  const int* skip = hist_dev ? flag_dev : skip_flag_dev;
+  if (rb_ofst >= 0) return launch_jacobi2<1>(u, b, w, make_coef_omg(omg), bx, ba, skip, fin, rb_parity(g, idx, rb_ofst, 0), 0, false, &ma) ? 1 : 0;
+  return launch_jacobi2<0>(u, b, w, make_coef_omg(omg), bx, ba, skip, fin, 0, 0, false, &ma) ? 1 : 0;
 }
 // one psor / psor_maf sweep (xc == nullptr: constant coefficients cf), res_dev[0] = or += sum dp^2
 void psor_async(REAL* p, const REAL* b, const int* sz, const int* idx, int g, const REAL* cf, const REAL* xc, const REAL* yc,

@@ -228,6 +228,11 @@ int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_R
 /* The same bookkeeping for a pair whose two sums were all-reduced first (decomposed runs). */
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);
+/* The MAF flavour of the two calls above (cz_maf.f90:131-438): weights recomputed at every point from the host coordinate arrays X, Y, Z
+ * (as in jacobi_maf_ / psor2sma_core_maf_).  rb_ofst < 0: two jacobi_maf sweeps, res_dev[0..1]; rb_ofst >= 0: one red-black iteration with
+ * that ofst, res_dev[0].  Returns 1 if launched. */
+int czhip_pair_maf_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* X,
+                         const CZ_REAL* Y, const CZ_REAL* Z, CZ_REAL omg, int rb_ofst, double* res_dev);
 /* Shape of the two-stage pass: threads per workgroup (512 | 1024; 0 / -1 keep, -2 = chosen per launch by the balance model), vectors per
  * thread (2), planes per chunk (0 = chosen per launch, -1 keep), enable (-1 keep).  Returns 0 if ok.  Every shape gives the same bits. */
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable);
