@@ -10,6 +10,7 @@ struct Tuning {
                                       // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
                                               // the balance model (pair_tj_model, cz_h_launch.h); CZHIP_T2=enable,threads,2,tj fixes them
+  int t2_map = 1;                                 // two-stage pass: equal shares of (segment, chunk) items per XCD (CZHIP_T2_MAP=0: whole-segment bands)
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
 
@@ -34,6 +35,8 @@ struct Ctx {
   double* scal_host = nullptr;  // pinned
   Tuning tune;
   std::map<std::vector<double>, REAL*> bc_tabs;  // key: ix, jx, dh, org0, org1
+  struct PairMap { int* dev = nullptr; long long nblk = 0; };
+  std::map<long long, PairMap> pair_maps;        // workgroup id -> (segment, chunk) tables of the two-stage pass, key nseg << 32 | nchunk
   int num_cu = 256;
   // optional per-launch HIP-event timing of the labelled kernels (bench.py roofline leg)
   bool timing = false;

@@ -102,21 +102,60 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 // the un-overlapped prologue); each XCD serves its band of segments with num_cu/8 * wg_per_cu resident workgroups, so a launch takes
 // ceil(band * nchunk / slots) rounds of that (tools/pair_lab sweeps, profiles/r02/pair_lab_sweep_*.txt: the model ranks the measured
 // times of both shapes and both precisions).  Returns the cost in units of plane steps; *tj_out the best chunk length.
-inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, int* tj_out) {
-  const int band = (nseg + 7) / 8;
+inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, bool balanced, int* tj_out) {
   const int slots = std::max(1, ctx.num_cu / 8) * wg_per_cu;
   double best = 1e300;
   int best_tj = std::min(16, nplanes);
   for (int tj = std::min(12, nplanes); tj <= std::min(nplanes, 128); tj++) {
     const int nchunk = (nplanes + tj - 1) / tj;
     if (tj > 12 && (nplanes + tj - 2) / (tj - 1) == nchunk) continue;  // a shorter chunk gives the same count: not a candidate
-    const long long items = (long long)band * nchunk;
+    // items of the busiest XCD: a band of whole segments, or an eighth of all items with the balanced table (pair_xcd_map)
+    const long long items = balanced ? ((long long)nseg * nchunk + 7) / 8 : (long long)((nseg + 7) / 8) * nchunk;
     const double cost = (double)((items + slots - 1) / slots) * (tj + 3.5);
     if (cost < best) best = cost, best_tj = tj;
   }
   *tj_out = best_tj;
   return best;
 }
+
+// Workgroup id -> (segment, chunk) table with equal shares per XCD.  With whole-segment bands an XCD serves ceil(nseg/8) or floor(nseg/8)
+// segments: 5 against 4 at 512^3 with the 1024-thread shape, i.e. three XCDs idle for a fifth of the launch.  Here the nseg*nchunk items,
+// taken in segment-major order, are cut into eight runs of equal length; an XCD's run covers whole segments except at its two ends, where
+// a segment is shared with the neighbouring XCD by plane range.  Inside its run an XCD walks chunk by chunk (row-adjacent segments are then
+// in the same planes at the same time and share their halo rows in the XCD's L2).  Cached per (nseg, nchunk); 8 bytes per workgroup.
+// Measured (profiles/r02/ab_xcd_map.txt): +6 % at 256^3 and 384^3, where the bands are 3 against 2 segments; -1 % at 512^3 and -4 % at
+// 640^3, where an XCD that finishes early only hands its share of the HBM bandwidth to the others and shared segments cost L2 hits.  So
+// the table is used where the bands would leave more than a tenth of the XCD slots idle (pair_use_map).
+inline const int* pair_xcd_map(int nseg, int nchunk, long long* nblk_out) {
+  const long long key = ((long long)nseg << 32) | (unsigned)nchunk;
+  auto it = ctx.pair_maps.find(key);
+  if (it == ctx.pair_maps.end()) {
+    const long long T = (long long)nseg * nchunk;
+    std::vector<std::vector<std::pair<int, int>>> own(8);  // (chunk, segment) for the sort
+    for (long long e = 0; e < T; e++) own[(size_t)(e * 8 / T)].push_back({(int)(e % nchunk), (int)(e / nchunk)});
+    size_t most = 0;
+    for (auto& v : own) {
+      std::sort(v.begin(), v.end());
+      most = std::max(most, v.size());
+    }
+    std::vector<int> tab(2 * 8 * most);
+    for (size_t r = 0; r < most; r++)
+      for (int x = 0; x < 8; x++) {
+        const bool has = r < own[x].size();
+        tab[2 * (8 * r + x)] = has ? own[x][r].second : nseg;
+        tab[2 * (8 * r + x) + 1] = has ? own[x][r].first : 0;
+      }
+    Ctx::PairMap pm;
+    pm.nblk = (long long)(8 * most);
+    HIP_CHECK(hipMalloc(&pm.dev, tab.size() * sizeof(int)));
+    HIP_CHECK(hipMemcpy(pm.dev, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    it = ctx.pair_maps.emplace(key, pm).first;
+  }
+  *nblk_out = it->second.nblk;
+  return it->second.dev;
+}
+
+inline bool pair_use_map(int nseg) { return ctx.tune.t2_map && nseg >= 8 && 10 * nseg < 9 * 8 * ((nseg + 7) / 8); }
 
 // two fused sweeps (jacobi2p_k); returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
 template <int TB, int MV, int RB, int ZU, int MAF = 0>
@@ -145,14 +184,16 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   if (lds > 160 * 1024) return false;
   const int wg_per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / TB));
   int tj = tj_req;
-  const double cost = pair_tj_model(g.nseg, nplanes, wg_per_cu, tj > 0 ? &g.TJ : &tj);
+  const double cost = pair_tj_model(g.nseg, nplanes, wg_per_cu, pair_use_map(g.nseg), tj > 0 ? &g.TJ : &tj);
   if (model_cost) *model_cost = cost * wg_per_cu * (double)(TB * MV + g.S);  // plane steps x work per CU and step
   if (tj > nplanes) tj = nplanes;
   g.TJ = tj;
   const int nchunk = (nplanes + tj - 1) / tj;
   g.band = 1;
-  const long long nblk = 8LL * ((g.nseg + 7) / 8) * nchunk;
+  g.map = nullptr;
+  long long nblk = 8LL * ((g.nseg + 7) / 8) * nchunk;
   if (probe) return true;
+  if (pair_use_map(g.nseg)) g.map = pair_xcd_map(g.nseg, nchunk, &nblk);
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {

@@ -31,7 +31,8 @@ struct Geom2 {
   int nseg, TJ, S;  // S = TB*MV - 2R
   int par;          // RB: colour 0 = points with (kk + ii + jj + par) even
   int zero_u;       // the input field is identically zero (a freshly cleared preconditioner vector): u is not read
-  int band;         // workgroup id -> (segment, chunk) by XCD bands (see jacobi2_k)
+  int band;         // workgroup id -> (segment, chunk) by XCD bands (see jacobi2p_k)
+  const int* map;   // or by a table: map[2 * id] = segment (nseg: no work), map[2 * id + 1] = chunk (pair_xcd_map, cz_h_launch.h)
 };
 
 struct Fin2 {

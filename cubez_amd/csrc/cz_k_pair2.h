@@ -150,8 +150,14 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
   int lb = blockIdx.x;
   const int nblk = gridDim.x;
   int seg, chunk;
-  {
-    // XCD bands (see jacobi2_k): XCD x owns a contiguous band of segments of every chunk and walks it chunk by chunk
+  if (g.map != nullptr) {
+    // balanced shares: the (segment, chunk) items in segment-major order are cut into eight equal runs, one per XCD (the hardware deals
+    // workgroup ids round-robin over the XCDs), each walked chunk by chunk -- see pair_xcd_map
+    seg = g.map[2 * lb];
+    chunk = g.map[2 * lb + 1];
+  } else {
+    // XCD bands: XCD x owns a contiguous band of whole segments of every chunk (row-adjacent segments share their halo rows in one L2)
+    // and walks it chunk by chunk
     const int x = lb & 7, r = lb >> 3;
     const int base = g.nseg >> 3, rem = g.nseg & 7, bmax = base + (rem ? 1 : 0);
     const int blen = base + (x < rem ? 1 : 0);

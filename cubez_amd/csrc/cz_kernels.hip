@@ -162,6 +162,7 @@ int czhip_init(int device) {
     const int n = sscanf(t2, "%d,%d,%d,%d", &en, &a, &b2, &c2);
     if (n >= 1) czhip_set_tuning2(n >= 2 ? a : 0, n >= 3 ? b2 : 0, n >= 4 ? c2 : -1, en);
   }
+  if (const char* mp = getenv("CZHIP_T2_MAP")) ctx.tune.t2_map = atoi(mp);
   if (const char* pc = getenv("CZHIP_PCR")) {  // "fast[,variant]"
     int f = 1, v = 0;
     sscanf(pc, "%d,%d", &f, &v);
@@ -180,6 +181,8 @@ void czhip_finalize(void) {
   HIP_CHECK(hipStreamSynchronize(ctx.stream));
   for (auto& kv : ctx.bc_tabs) (void)hipFree(kv.second);
   ctx.bc_tabs.clear();
+  for (auto& kv : ctx.pair_maps) (void)hipFree(kv.second.dev);
+  ctx.pair_maps.clear();
   (void)hipFree(ctx.partials);
   (void)hipFree(ctx.shell_partials);
   if (ctx.pcr_tab) (void)hipFree(ctx.pcr_tab);

@@ -75,6 +75,7 @@ bool geom(Lab& L, int tj, int rb) {
   g.TJ = std::min(tj, nplanes);
   const int nchunk = (nplanes + g.TJ - 1) / g.TJ;
   g.band = 1;
+  g.map = nullptr;
   L.nblk = 8 * ((g.nseg + 7) / 8) * nchunk;
   L.lds1 = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double);
   L.lds2 = L.lds1;
