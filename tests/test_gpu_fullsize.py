@@ -228,6 +228,60 @@ def test_decomposed_512_equals_single_domain():
     assert h1.hexdigest() == h2.hexdigest()
 
 
+@pytest.mark.parametrize("solver,coef", [("jacobi", 0.8), ("sor2sma", 1.5)])
+def test_configs4_geometry_1024_cube_2x2x2_bricks_equals_single_domain(solver, coef):
+    """BASELINE configs[4] at full size, as far as one GPU can take it: `cz 1024 1024 1024 <solver> 6 <coef> 2 2 2` -- eight 512^3 bricks,
+    every brick a corner brick with three rank-internal faces, shell slabs + interior, two-layer exchange with edges, lagged residual
+    all-reduce -- with the eight ranks as host threads on this GPU (LOCAL transport: device copies where RCCL would send; same
+    decomposition, kernels, pack/unpack and stream structure) against the single-domain 1024^3 run: same iteration count, history to
+    1e-12, every owned cell bit for bit (compared through sha256 per brick)."""
+    from cubez_amd import CZ, load
+    n = 1024
+    cz = CZ("f32", quiet=True)
+    assert cz.setup([n, n, n, solver, 6, coef]) == 1
+    itr1 = cz.solve()
+    hist1, P1 = cz.history(), cz.field()
+    cz.close()
+    lib = load("f32")
+    lib.cz_comm_local_world.restype = C.c_void_p
+    lib.cz_comm_bootstrap_local.argtypes = [C.c_void_p, C.c_int]
+    lib.cz_comm_local_world_free.argtypes = [C.c_void_p]
+    world = lib.cz_comm_local_world(8)
+    res, errs = [None] * 8, []
+    g = 2
+
+    def work(r):
+        try:
+            lib.cz_comm_bootstrap_local(world, r)
+            c = CZ("f32", quiet=True)
+            assert c.setup([n, n, n, solver, 6, coef, 2, 2, 2]) == 1
+            itr = c.solve()
+            loc, P = c.local(), c.field()
+            (ni, nj, nk) = loc["size"]
+            res[r] = (itr, c.history(), hashlib.sha256(np.ascontiguousarray(P[g:g + nj, g:g + ni, g:g + nk]).tobytes()).hexdigest(), loc, c.info())
+            del P
+            c.close()
+        except BaseException as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(8)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    if any(t.is_alive() for t in th):
+        import os
+        import sys
+        sys.stderr.write("DEADLOCK: the 2x2x2 run did not finish\n")
+        os._exit(3)
+    assert not errs, errs
+    lib.cz_comm_local_world_free(world)
+    for itr, hist, digest, loc, info in res:
+        assert itr == itr1 and np.allclose(hist, hist1, rtol=1e-12, atol=0)
+        assert info["fused_pass"] == 1 and info["shell_slabs"] == 3 and info["lagged_reduce"] == 1, info
+        (ni, nj, nk), (hi, hj, hk) = loc["size"], loc["head"]
+        ref = P1[g + hj - 1:g + hj - 1 + nj, g + hi - 1:g + hi - 1 + ni, g + hk - 1:g + hk - 1 + nk]
+        assert hashlib.sha256(np.ascontiguousarray(ref).tobytes()).hexdigest() == digest, loc
+
+
 def test_psor_512_is_locally_consistent_with_the_sequential_order():
     """One lexicographic SOR sweep at 512^3.  In the order (j, i, k) every update reads the NEW values of its k-1, i-1, j-1
     neighbours and the OLD ones of k+1, i+1, j+1, so the result can be checked point by point (vectorised, exact) without
