@@ -293,12 +293,12 @@ if rank == 0:
         out["multi_gpu"] = {"ranks": devs, "rccl_ranks": info["rccl_ranks"], "fused_pass": bool(info["fused_pass"]), "shell_slabs_rank0": info["shell_slabs"],
                             "overlap": bool(info["overlap"]), "lagged_reduce": bool(info["lagged_reduce"])}
         if nk2 > 0 and not bicg:
-            # exposed (non-overlapped) communication per step = wall time per step minus the rank-0 kernel time per step
-            # (shell slabs + interior of a fused pass cover two steps); the exchange itself runs on a second stream behind the interior
+            # exposed (non-overlapped) communication per step = wall time per step minus the rank-0 interior-kernel time per
+            # step (a fused pass covers two steps); the shell slabs, the exchange and the residual all-reduce run on a second stream beside it
             n_sh, sh_ms = cz_shell
-            per_step_kernel_ms = (kern2_ms + sh_ms) / nk2 / (2.0 if jac_like else 1.0)
+            per_step_kernel_ms = kern2_ms / nk2 / (2.0 if jac_like else 1.0)
             out["multi_gpu"].update({"kernel_ms_per_step_rank0": per_step_kernel_ms, "exposed_ms_per_step": dt / args.steps * 1e3 - per_step_kernel_ms,
-                                     "per_gpu_algorithmic_GBps": achieved})
+                                     "shell_slabs_ms_per_pass_rank0": (sh_ms / n_sh) if n_sh else None, "per_gpu_algorithmic_GBps": achieved})
     if bicg:
         out["config"]["step"] = "one BiCGSTAB iteration: 2 x 8 preconditioner sweeps, 2 SpMV, 5 dots, 4 axpy-type updates (cz_Poisson.cpp:373-500)"
         # 76 words per point and iteration with the Jacobi preconditioner

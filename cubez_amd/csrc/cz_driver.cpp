@@ -98,6 +98,7 @@ CZ::~CZ() {
   (void)hipHostFree(h_flag);
   if (comm) comm_destroy(comm);
   if (ev_shell) (void)hipEventDestroy(ev_shell);
+  if (ev_src) (void)hipEventDestroy(ev_src);
   if (ev_comm) (void)hipEventDestroy(ev_comm);
   if (ev_int) (void)hipEventDestroy(ev_int);
   for (hipEvent_t e : ev_chk)
@@ -573,6 +574,7 @@ void CZ::plan_overlap() {
     HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     HIP_CHECK(hipStreamCreateWithPriority(&comm_stream, hipStreamNonBlocking, prio_greatest));
     HIP_CHECK(hipEventCreateWithFlags(&ev_shell, hipEventDisableTiming));
+    HIP_CHECK(hipEventCreateWithFlags(&ev_src, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_comm, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_int, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&ev_chk[0], hipEventDisableTiming));
@@ -582,8 +584,8 @@ void CZ::plan_overlap() {
 
 // One fused pair of sweeps (rb < 0) or one red-black iteration (rb = colour parity) of a decomposed run, src -> dst, with
 // the two-layer exchange of dst hidden behind the interior:
-//   stream      : shell slabs -> [ev_shell] -> interior ------------------------> wait ev_comm -> (all-reduce, test)
-//   comm_stream :                 wait ev_shell -> pack, send/recv, unpack -> [ev_comm]
+//   stream      : [ev_src] -> interior ------------------------------------------> wait ev_comm -> fold slab sums -> (all-reduce, test)
+//   comm_stream : wait ev_src -> shell slabs -> pack, send/recv, unpack -> [ev_comm]
 // The slabs and the interior write disjoint cells of dst and read only src; the unpack writes ghost cells of dst.
 // Returns false (nothing launched) when the split does not apply; the caller then takes the unsplit path.
 bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot) {
@@ -592,16 +594,20 @@ bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int
   const int gc = GUIDE;
   hipStream_t st = stream();
   if (!pair_probe(src, dst, B, size, interior, interior1, gc, cf[6])) return false;
-  pair_shell_async(src, dst, B, size, idx1, shell_boxes, n_shell, gc, cf, ac1, rb, skip);
-  HIP_CHECK(hipEventRecord(ev_shell, st));
-  if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, rs, 1, skip)) {
+  // The shell slabs and the interior read src and write disjoint cells of dst: they run side by side (round 2; round 1 ran the slabs first
+  // on the compute stream, 49 us per pass of a corner brick during which the GPU was mostly idle).  The slabs go first on the exchange
+  // stream, which has the higher priority, so the exchange starts as early as before.
+  HIP_CHECK(hipEventRecord(ev_src, st));  // src is complete (and nobody reads dst any more) once everything issued so far on st is done
+  HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_src, 0));
+  pair_shell_async(src, dst, B, size, idx1, shell_boxes, n_shell, gc, cf, ac1, rb, skip, comm_stream);
+  if (!comm_halo2(comm, dst, skip, comm_stream)) return false;
+  HIP_CHECK(hipEventRecord(ev_comm, comm_stream));
+  if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, rs, 0, skip)) {
     printf("error : interior launch refused after a successful probe\n");
     exit(1);
   }
-  HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_shell, 0));
-  if (!comm_halo2(comm, dst, skip, comm_stream)) return false;
-  HIP_CHECK(hipEventRecord(ev_comm, comm_stream));
   HIP_CHECK(hipStreamWaitEvent(st, ev_comm, 0));
+  pair_shell_fold_async(rs, rb >= 0 ? 1 : 0, skip, st);  // (behind ev_comm: the slabs have finished)
   return true;
 }
 

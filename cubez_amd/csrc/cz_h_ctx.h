@@ -54,7 +54,8 @@ const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_
 struct ScopedTimer {
   bool on;
   Ctx::Ev ev;
-  explicit ScopedTimer(int label) : on(ctx.timing) {
+  hipStream_t st;
+  explicit ScopedTimer(int label, hipStream_t stream = nullptr) : on(ctx.timing), st(stream ? stream : ctx.stream) {
     if (!on) return;
     if (!ctx.ev_free.empty()) {
       ev = ctx.ev_free.back();
@@ -64,11 +65,11 @@ struct ScopedTimer {
       HIP_CHECK(hipEventCreate(&ev.b));
     }
     ev.label = label;
-    HIP_CHECK(hipEventRecord(ev.a, ctx.stream));
+    HIP_CHECK(hipEventRecord(ev.a, st));
   }
   ~ScopedTimer() {
     if (!on) return;
-    HIP_CHECK(hipEventRecord(ev.b, ctx.stream));
+    HIP_CHECK(hipEventRecord(ev.b, st));
     ctx.ev_used.push_back(ev);
     if (ctx.ev_used.size() >= 4096) fold_events(2048);
   }

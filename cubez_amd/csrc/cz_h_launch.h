@@ -249,7 +249,7 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
 // the shell boxes of a decomposed brick, all in one launch (pair_shell_k); boxes: n x (ist,ied,jst,jed,kst,ked), 1-based
 template <int RB>
 void launch_pair_shell(const REAL* U, const REAL* B, REAL* W, const Coef& c, const int* sz, int g, const Box& ba, const int* boxes, int n,
-                       int par, const int* skip) {
+                       int par, const int* skip, hipStream_t st) {
   ShellTab s;
   s.n = n;
   int most_tiles = 0;
@@ -278,8 +278,8 @@ void launch_pair_shell(const REAL* U, const REAL* B, REAL* W, const Coef& c, con
   s.par = par;
   const unsigned gx = (unsigned)std::min(most_tiles, 2048);
   {
-    ScopedTimer tm(LBL_SHELL);
-    hipLaunchKernelGGL((pair_shell_k<RB>), dim3(gx, (unsigned)n), dim3(256), lds, ctx.stream, U, B, W, c, s, ctx.shell_partials, skip);
+    ScopedTimer tm(LBL_SHELL, st);
+    hipLaunchKernelGGL((pair_shell_k<RB>), dim3(gx, (unsigned)n), dim3(256), lds, st, U, B, W, c, s, ctx.shell_partials, skip);
   }
   HIP_CHECK(hipGetLastError());
   ctx.shell_pending = (int)(gx * n);

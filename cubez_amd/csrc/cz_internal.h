@@ -71,7 +71,8 @@ int rb_par(int g, const int* idx, int ofst);
 int pair_plan(const int* inner_idx, const int* nID, int* boxes, int* interior, int* interior1);
 int pair_probe(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g, CZ_REAL dd);
 void pair_shell_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx1_brick, const int* boxes, int n,
-                      int g, const CZ_REAL* cf, CZ_REAL omg, int rb, const int* skip);
+                      int g, const CZ_REAL* cf, CZ_REAL omg, int rb, const int* skip, hipStream_t st);
+void pair_shell_fold_async(double* res_dev, int single, const int* skip, hipStream_t st);
 // with_shell: res_dev = this launch's sums + those of the pair_shell_async launch before it
 int pair_box_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
                    const CZ_REAL* cf, CZ_REAL omg, int rb, double* res_dev, int with_shell, const int* skip);

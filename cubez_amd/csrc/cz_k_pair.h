@@ -276,3 +276,25 @@ pair_shell_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __res
     partials[nblk + lb] = s2;
   }
 }
+
+// The sums of a pair_shell_k launch added to the sums of the interior launch of the same pass (the driver runs the two concurrently on
+// two streams and folds afterwards): res[0] += first-stage sums, res[1] += second-stage sums (single: both into res[0]).  One
+// workgroup, fixed order.
+__global__ void __launch_bounds__(256)
+shell_fold_k(const double* __restrict__ partials, int n, double* __restrict__ res, int single, const int* __restrict__ skip) {
+  if (skip != nullptr && *skip != 0) return;
+  __shared__ double wsum[8];
+  double x1 = 0.0, x2 = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) x1 += partials[i], x2 += partials[n + i];
+  const double s1 = block_sum<256>(x1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<256>(x2, wsum);
+  if (threadIdx.x == 0) {
+    if (single) {
+      res[0] += s1 + s2;
+    } else {
+      res[0] += s1;
+      res[1] += s2;
+    }
+  }
+}

@@ -410,7 +410,7 @@ int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const
   const int n = czhip_internal::pair_plan(idx, nID, boxes, in0, in1);
   if (n == 0 || !czhip_internal::pair_probe(u, w, b, sz, in0, in1, g, cf[6])) return 0;
   const int rb = rb_ofst >= 0 ? rb_parity(g, idx, rb_ofst, 0) : -1;
-  czhip_internal::pair_shell_async(u, w, b, sz, idx1 ? idx1 : idx, boxes, n, g, cf, omg, rb, nullptr);
+  czhip_internal::pair_shell_async(u, w, b, sz, idx1 ? idx1 : idx, boxes, n, g, cf, omg, rb, nullptr, nullptr);
   return czhip_internal::pair_box_async(u, w, b, sz, in0, in1, g, cf, omg, rb, res_dev, 1, nullptr);
 }
 
@@ -1054,11 +1054,21 @@ int pair_probe(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* 
 }
 
 void pair_shell_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx1_brick, const int* boxes, int n, int g,
-                      const REAL* cf, REAL omg, int rb, const int* skip) {
+                      const REAL* cf, REAL omg, int rb, const int* skip, hipStream_t st) {
   ensure_init();
   const Box ba = make_box(sz, idx1_brick, g);
-  if (rb >= 0) launch_pair_shell<1>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, rb, skip);
-  else launch_pair_shell<0>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, 0, skip);
+  if (!st) st = ctx.stream;
+  if (rb >= 0) launch_pair_shell<1>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, rb, skip, st);
+  else launch_pair_shell<0>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, 0, skip, st);
+}
+
+// res_dev += the sums of the last pair_shell_async launch (which ran on another stream beside the interior launch); stream-ordered on `st`
+void pair_shell_fold_async(double* res_dev, int single, const int* skip, hipStream_t st) {
+  ensure_init();
+  if (ctx.shell_pending <= 0) return;
+  hipLaunchKernelGGL(shell_fold_k, dim3(1), dim3(256), 0, st ? st : ctx.stream, ctx.shell_partials, ctx.shell_pending, res_dev, single, skip);
+  HIP_CHECK(hipGetLastError());
+  ctx.shell_pending = 0;
 }
 
 int pair_box_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g, const REAL* cf,
@@ -1069,8 +1079,10 @@ int pair_box_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const i
   Fin2 fin;
   fin.dst = res_dev;
   fin.single = rb >= 0;
-  if (with_shell) fin.extra = ctx.shell_partials, fin.n_extra = ctx.shell_pending;
-  ctx.shell_pending = 0;
+  if (with_shell) {  // same stream as the shell launch: its sums join this launch's in the finaliser
+    fin.extra = ctx.shell_partials, fin.n_extra = ctx.shell_pending;
+    ctx.shell_pending = 0;
+  }
   if (rb >= 0) return launch_jacobi2<1>(u, b, w, make_coef(cf, omg), bx, ba, skip, fin, rb) ? 1 : 0;
   return launch_jacobi2<0>(u, b, w, make_coef(cf, omg), bx, ba, skip, fin) ? 1 : 0;
 }
