@@ -262,3 +262,38 @@ def test_decomposed_maf_flavour(solver, div):
     assert all(r[0] == itr1 for r in results)
     assert np.allclose(results[0][2], hist1, rtol=1e-9, atol=0)
     assert np.abs(G[2:-2, 2:-2, 2:-2] - P1[2:-2, 2:-2, 2:-2]).max() < 1e-12
+
+
+def test_ranks_out_of_step_end_the_job_with_a_diagnostic_instead_of_hanging():
+    """if ranks ever issue different sequences of collectives the job must end, not hang.  Here one of two ranks never
+    shows up (its thread returns before set-up): the other rank's first collective waits in the LOCAL transport's bounded barrier and the
+    process exits with code 3 and a line naming the rank and the barrier (with RCCL the watchdog of cz_comm.cpp does the same for the
+    stream-ordered collectives).  Run in a child process: the exit is the process's."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, os, sys, threading
+sys.path.insert(0, os.environ["CZ_ROOT"])
+from cubez_amd import CZ, load
+lib = load("f32")
+lib.cz_comm_local_world.restype = C.c_void_p
+lib.cz_comm_bootstrap_local.argtypes = [C.c_void_p, C.c_int]
+world = lib.cz_comm_local_world(2)
+def work(r):
+    lib.cz_comm_bootstrap_local(world, r)
+    if r == 1:
+        return                      # this rank never issues anything
+    cz = CZ("f32", quiet=True)
+    cz.setup([32, 32, 32, "jacobi", 10, 0.8, 1, 2, 1])
+    cz.solve()
+th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+[t.start() for t in th]
+[t.join() for t in th]
+print("finished")                   # must not be reached
+"""
+    env = dict(os.environ, CZ_COMM_TIMEOUT="3", CZ_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 3, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    assert "finished" not in r.stdout
+    assert "cz rank 0" in r.stderr and "barrier" in r.stderr and "ranks arrived" in r.stderr, r.stderr[-500:]
