@@ -6,6 +6,9 @@
 struct Tuning {
   int threads = 512, m = 2, tj = 16 /* 0 = auto */, pf = 0;  // best of tools/tune_jacobi.py at 512^3 FP32
   int fuse_fin = 1;
+  int pcr_pipe = 1;                  // CZHIP_PCR_PIPE: 1 = the lexicographic line SOR (pcr, pcr_esa) in one launch per sweep (pcr_lex_wg_k), 0 = a launch per diagonal
+  int pcr_rows = 0, pcr_q = 1;       // groups of NT threads per workgroup (0: chosen by the launcher), rows per thread (1, 2)
+  long long pipe_spin_ticks = 200000000;  // bound of every wait inside it, in ticks of the 100 MHz wall clock (2 s)
   int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
                                       // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
@@ -22,6 +25,8 @@ struct Ctx {
   REAL* pcr_tab_perm = nullptr; // the same table in the [m][lane] order of pcr_line_reg_k, for pcr_perm_M entries per lane
   int pcr_perm_M = 0;
   size_t pcr_perm_cap = 0;
+  unsigned* pipe_ctl = nullptr;  // pcr_lex_wg_k: strip ticket, error word, one counter per strip (zeroed before every sweep)
+  size_t pipe_ctl_cap = 0;
   REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
   int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
   size_t pcr_tab_cap = 0;

@@ -91,10 +91,9 @@ bool try_pcr_reg_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, con
   return true;
 }
 
-// register form (pcr_line_reg_k): lines of up to 1024 unknowns whose permuted table fits LDS
-template <int FINAL4, int ORDER>
-bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
-                 long long ncol) {
+// the permuted coefficient table of the register form (pcr_line_reg_k): lines of up to 1024 unknowns whose table fits LDS
+template <int FINAL4>
+bool prep_pcr_reg_table(const PcrGeom& g, int* M_out, int* tab_len_out) {
   const int n = g.n, pn = g.pn;
   if (pn < (FINAL4 ? 3 : 2) || n > 1024) return false;
   const int nstage = FINAL4 ? pn - 2 : pn - 1;
@@ -119,6 +118,16 @@ bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Pc
     HIP_CHECK(hipGetLastError());
     ctx.pcr_perm_M = M;
   }
+  *M_out = M, *tab_len_out = tab_len;
+  return true;
+}
+
+// register form (pcr_line_reg_k)
+template <int FINAL4, int ORDER>
+bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
+                 long long ncol) {
+  int M = 0, tab_len = 0;
+  if (!prep_pcr_reg_table<FINAL4>(g, &M, &tab_len)) return false;
   const int v = ctx.tune.pcr_variant;
 #define CZ_PCR_REG(M_)                                                                                                                \
   if (M == M_) {                                                                                                                      \
@@ -134,6 +143,83 @@ bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Pc
   }
   CZ_PCR_REG(2) CZ_PCR_REG(4) CZ_PCR_REG(8) CZ_PCR_REG(16)
 #undef CZ_PCR_REG
+  return false;
+}
+
+// pcr / pcr_esa in one launch per sweep (pcr_lex_wg_k): NT threads per line, R groups of them per workgroup, Q rows per thread.
+// CZHIP_PCR_PIPE=0 turns it off (one launch per diagonal instead).
+template <int FINAL4, int NT, int Q>
+bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate, int nstage, int nfin) {
+  // measured at 512^3 FP32 (profiles/r02/pcr_lex_*): a stage costs in proportion to the waves behind its barrier, so one group of NT
+  // threads per workgroup unless the lines are short
+  int R = std::max(1, std::min(512 / NT, (g.nj + Q - 1) / Q));
+  if (ctx.tune.pcr_rows > 0) R = std::max(1, std::min(1024 / NT, ctx.tune.pcr_rows));
+  const int RS = R * Q;
+  const int nstrips = (g.nj + RS - 1) / RS;
+  const int ntab = 3 * nstage + (FINAL4 ? 7 : 3);
+  const size_t lds = ((size_t)2 * RS * (NT + 2) + (size_t)R * NT + (size_t)ntab * NT) * sizeof(REAL) + 8 * sizeof(int) + 16 + 20 * sizeof(double);
+  if (lds > 160 * 1024) return false;  // (the coefficients of every entry sit in LDS)
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_lex_wg_k<FINAL4, NT, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const size_t ctl_words = (size_t)kPipeCtlStride * (nstrips + 1);
+  if (ctl_words > ctx.pipe_ctl_cap) {
+    if (ctx.pipe_ctl) {
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      HIP_CHECK(hipFree(ctx.pipe_ctl));
+    }
+    HIP_CHECK(hipMalloc(&ctx.pipe_ctl, ctl_words * sizeof(unsigned)));
+    ctx.pipe_ctl_cap = ctl_words;
+  }
+  ensure_partials((size_t)nstrips);
+  // as many workgroups as fit the chip at once (LDS and 2048 threads per CU); the strips beyond are taken by the workgroups that finish first
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)2048 / ((size_t)NT * R)));
+  const unsigned nblk = (unsigned)std::min(nstrips, ctx.num_cu * per_cu);
+  ScopedTimer tm(LBL_PCR);
+  HIP_CHECK(hipMemsetAsync(ctx.pipe_ctl, 0, ctl_words * sizeof(unsigned), ctx.stream));
+  long long* prof = nullptr;
+  static const char* prof_env = getenv("CZHIP_PCR_PIPE_PROF");  // development aid: when each strip started / ended and how long it waited for the one above
+  if (prof_env) {
+    HIP_CHECK(hipMalloc(&prof, (size_t)8 * nstrips * sizeof(long long)));
+    HIP_CHECK(hipMemsetAsync(prof, 0, (size_t)8 * nstrips * sizeof(long long), ctx.stream));
+  }
+  hipLaunchKernelGGL((pcr_lex_wg_k<FINAL4, NT, Q>), dim3(nblk), dim3(NT * R), lds, ctx.stream, x, msk, rhs, g, omg, ctx.pcr_tab, nfin, R, ctx.pipe_ctl,
+                     nstrips, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, prof);
+  HIP_CHECK(hipGetLastError());
+  if (prof) {
+    std::vector<long long> h((size_t)8 * nstrips);
+    HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipFree(prof));
+    const long long t0 = h[0];
+    fprintf(stderr, "pcr_lex_wg_k<%d,%d,%d> n %d ni %d nj %d R %d, %u workgroups: strip: start first_line_ready end | waited (us) in n waits | wg\n", FINAL4, NT, Q, g.n, g.ni, g.nj, R, nblk);
+    const int every = std::max(1, atoi(prof_env));
+    for (int sidx = 0; sidx < nstrips; sidx += every) {
+      const long long* q = &h[(size_t)8 * sidx];
+      fprintf(stderr, "  strip %4d: %9.2f %9.2f %9.2f | %8.2f %5lld | %3lld | phases (us): to first barrier %.1f, stages %.1f, final+relax %.1f, rotation+barrier %.1f\n", sidx,
+              (q[0] - t0) * 0.01, (q[1] - t0) * 0.01, (q[2] - t0) * 0.01, q[3] * 0.01, q[4], q[5], (q[6] >> 32) * 0.01, (q[6] & 0xffffffffLL) * 0.01,
+              (q[7] >> 32) * 0.01, (q[7] & 0xffffffffLL) * 0.01);
+    }
+  }
+  return true;
+}
+
+template <int FINAL4>
+bool try_pcr_lex_wg(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate) {
+  const int n = g.n, pn = g.pn;
+  if (pn < (FINAL4 ? 3 : 2) || n > 1024) return false;
+  const int nstage = FINAL4 ? pn - 2 : pn - 1;
+  if (nstage < 2 || nstage > 10) return false;
+  const int nfin = std::min(1 << nstage, n);
+  ensure_pcr_table(n, pn, FINAL4, nfin, nstage * 3 * n + (FINAL4 ? 7 : 3) * nfin);
+#define CZ_LEX_WG(NT_)                                                                                                               \
+  if (n <= NT_)                                                                                                                     \
+    return ctx.tune.pcr_q == 1 ? try_pcr_lex_wg_inst<FINAL4, NT_, 1>(x, msk, rhs, g, omg, res_dev, accumulate, nstage, nfin)          \
+                               : try_pcr_lex_wg_inst<FINAL4, NT_, 2>(x, msk, rhs, g, omg, res_dev, accumulate, nstage, nfin);
+  CZ_LEX_WG(64) CZ_LEX_WG(128) CZ_LEX_WG(256) CZ_LEX_WG(512) CZ_LEX_WG(1024)
+#undef CZ_LEX_WG
   return false;
 }
 
@@ -198,6 +284,12 @@ void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, c
   bool ok = true;
   if (order == 1) {
     const int ni = b.ii1 - b.ii0 + 1, nj = b.jj1 - b.jj0 + 1;
+    {
+      const PcrGeom g = make_pcr_geom(b, idx, pn, 0);
+      if (ctx.tune.pcr_fast >= 2 && ctx.tune.pcr_pipe != 0 &&
+          (final4 ? try_pcr_lex_wg<1>(x, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_lex_wg<0>(x, msk, rhs, g, omg, res_dev, accumulate)))
+        return;
+    }
     for (int dgn = 0; dgn <= ni + nj - 2 && ok; dgn++) {
       const PcrGeom g = make_pcr_geom(b, idx, pn, dgn);
       ok = final4 ? try_pcr_rb2<1, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0)

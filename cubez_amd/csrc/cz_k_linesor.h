@@ -622,12 +622,86 @@ __device__ __forceinline__ T lane_down(T v, int q, int lane) {  // value of lane
   return (q < 64 && lane + q < 64) ? r : (T)0;
 }
 
+// The reduction stages and the final systems of L lines held in registers (lane = entries k0 .. k0+M-1 of each line): d -> sol.
+// (a function of its own so that other kernels can hold lines in registers the same way)
+template <int M, int L, int FINAL4>
+__device__ __forceinline__ void pcr_reg_solve(REAL (&d)[L][M], REAL (&sol)[L][M], const REAL* T, int nstage, int n, int lane) {
+  constexpr int NE = 64 * M;
+  const int k0 = lane * M;
+  // ---- PCR stages (:572-595), right-hand side only; every index below is a compile-time constant
+#pragma unroll
+  for (int sidx = 0; sidx < 20; sidx++) {
+    if ((1 << sidx) >= NE) break;  // compile time
+    if (sidx < nstage) {
+      const int s = 1 << sidx;
+      const REAL* Tp = T + (size_t)sidx * 3 * NE;
+      REAL nd[L][M];
+#pragma unroll
+      for (int m = 0; m < M; m++) {
+        const REAL e = Tp[m * 64 + lane], ap = Tp[NE + m * 64 + lane], cp = Tp[2 * NE + m * 64 + lane];
+#pragma unroll
+        for (int l = 0; l < L; l++) {
+          REAL dl, dr;
+          if (s < M) {
+            dl = (m - s >= 0) ? d[l][(m - s >= 0) ? m - s : 0] : lane_up(d[l][(m - s + M) % M], 1, lane);
+            dr = (m + s < M) ? d[l][(m + s < M) ? m + s : 0] : lane_down(d[l][(m + s) % M], 1, lane);
+          } else {
+            dl = lane_up(d[l][m], s / M, lane);
+            dr = lane_down(d[l][m], s / M, lane);
+          }
+          nd[l][m] = e * (d[l][m] - ap * dl - cp * dr);
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < L; l++)
+#pragma unroll
+        for (int m = 0; m < M; m++) d[l][m] = (k0 + m < n) ? nd[l][m] : (REAL)0;
+    }
+  }
+  // ---- final stage: every entry solves for itself
+  {
+    const int s = 1 << nstage;
+    const int qf = s / M;  // s >= M always (s >= n/4 > 8M .. see launch_pcr_reg)
+    const REAL* F = T + (size_t)nstage * 3 * NE;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      const int k = k0 + m;
+      const int rr = k >> nstage;  // position of this entry in its 2x2 / 4x4 system (s = 2^nstage)
+      const int x = m * 64 + lane;
+#pragma unroll
+      for (int l = 0; l < L; l++) {
+        const REAL me = d[l][m];
+        if (!FINAL4) {  // (:599-616)
+          const REAL jj2 = F[x], cc1 = F[NE + x], aa2 = F[2 * NE + x];
+          const REAL up = lane_up(me, qf, lane), dn = lane_down(me, qf, lane);
+          const REAL f1 = rr == 0 ? me : up, f2 = rr == 0 ? dn : me;
+          sol[l][m] = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;
+        } else {  // Cramer's rule (:787-842)
+          const REAL inv_detA = F[x], cc1 = F[NE + x], cc2 = F[2 * NE + x], cc3 = F[3 * NE + x];
+          const REAL aa2 = F[4 * NE + x], aa3 = F[5 * NE + x], aa4 = F[6 * NE + x];
+          const REAL u1 = lane_up(me, qf, lane), u2 = lane_up(me, 2 * qf, lane), u3 = lane_up(me, 3 * qf, lane);
+          const REAL w1 = lane_down(me, qf, lane), w2 = lane_down(me, 2 * qf, lane), w3 = lane_down(me, 3 * qf, lane);
+          const REAL dd1 = rr == 0 ? me : rr == 1 ? u1 : rr == 2 ? u2 : u3;
+          const REAL dd2 = rr == 0 ? w1 : rr == 1 ? me : rr == 2 ? u1 : u2;
+          const REAL dd3 = rr == 0 ? w2 : rr == 1 ? w1 : rr == 2 ? me : u1;
+          const REAL dd4 = rr == 0 ? w3 : rr == 1 ? w2 : rr == 2 ? w1 : me;
+          REAL det;
+          if (rr == 0) det = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+          else if (rr == 1) det = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+          else if (rr == 2) det = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+          else det = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+          sol[l][m] = det * inv_detA;
+        }
+      }
+    }
+  }
+}
+
 template <int M, int NW, int L, int FINAL4, int ORDER>
 __global__ void __launch_bounds__(64 * NW)
 pcr_line_reg_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg,
                const REAL* __restrict__ tab, int tab_len, double* partials, double* dst, int accumulate, unsigned* counter) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NE = 64 * M;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = g.n;
   REAL* T = reinterpret_cast<REAL*>(smem);
@@ -703,73 +777,10 @@ pcr_line_reg_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __
         for (int m = 0; m < M; m++) d[l][m] = (REAL)0;
       }
     }
-    // ---- PCR stages (:572-595), right-hand side only; every index below is a compile-time constant
-#pragma unroll
-    for (int sidx = 0; sidx < 20; sidx++) {
-      if ((1 << sidx) >= NE) break;  // compile time
-      if (sidx < nstage) {
-        const int s = 1 << sidx;
-        const REAL* Tp = T + (size_t)sidx * 3 * NE;
-        REAL nd[L][M];
-#pragma unroll
-        for (int m = 0; m < M; m++) {
-          const REAL e = Tp[m * 64 + lane], ap = Tp[NE + m * 64 + lane], cp = Tp[2 * NE + m * 64 + lane];
-#pragma unroll
-          for (int l = 0; l < L; l++) {
-            REAL dl, dr;
-            if (s < M) {
-              dl = (m - s >= 0) ? d[l][(m - s >= 0) ? m - s : 0] : lane_up(d[l][(m - s + M) % M], 1, lane);
-              dr = (m + s < M) ? d[l][(m + s < M) ? m + s : 0] : lane_down(d[l][(m + s) % M], 1, lane);
-            } else {
-              dl = lane_up(d[l][m], s / M, lane);
-              dr = lane_down(d[l][m], s / M, lane);
-            }
-            nd[l][m] = e * (d[l][m] - ap * dl - cp * dr);
-          }
-        }
-#pragma unroll
-        for (int l = 0; l < L; l++)
-#pragma unroll
-          for (int m = 0; m < M; m++) d[l][m] = (k0 + m < n) ? nd[l][m] : (REAL)0;
-      }
-    }
-    // ---- final stage: every entry solves for itself
+    // ---- PCR stages (:572-595) and the final systems, right-hand side only
+    REAL sol[L][M];
+    pcr_reg_solve<M, L, FINAL4>(d, sol, T, nstage, n, lane);
     {
-      const int s = 1 << nstage;
-      const int qf = s / M;  // s >= M always (s >= n/4 > 8M .. see launch_pcr_reg)
-      const REAL* F = T + (size_t)nstage * 3 * NE;
-      REAL sol[L][M];
-#pragma unroll
-      for (int m = 0; m < M; m++) {
-        const int k = k0 + m;
-        const int rr = k >> nstage;  // position of this entry in its 2x2 / 4x4 system (s = 2^nstage)
-        const int x = m * 64 + lane;
-#pragma unroll
-        for (int l = 0; l < L; l++) {
-          const REAL me = d[l][m];
-          if (!FINAL4) {  // (:599-616)
-            const REAL jj2 = F[x], cc1 = F[NE + x], aa2 = F[2 * NE + x];
-            const REAL up = lane_up(me, qf, lane), dn = lane_down(me, qf, lane);
-            const REAL f1 = rr == 0 ? me : up, f2 = rr == 0 ? dn : me;
-            sol[l][m] = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;
-          } else {  // Cramer's rule (:787-842)
-            const REAL inv_detA = F[x], cc1 = F[NE + x], cc2 = F[2 * NE + x], cc3 = F[3 * NE + x];
-            const REAL aa2 = F[4 * NE + x], aa3 = F[5 * NE + x], aa4 = F[6 * NE + x];
-            const REAL u1 = lane_up(me, qf, lane), u2 = lane_up(me, 2 * qf, lane), u3 = lane_up(me, 3 * qf, lane);
-            const REAL w1 = lane_down(me, qf, lane), w2 = lane_down(me, 2 * qf, lane), w3 = lane_down(me, 3 * qf, lane);
-            const REAL dd1 = rr == 0 ? me : rr == 1 ? u1 : rr == 2 ? u2 : u3;
-            const REAL dd2 = rr == 0 ? w1 : rr == 1 ? me : rr == 2 ? u1 : u2;
-            const REAL dd3 = rr == 0 ? w2 : rr == 1 ? w1 : rr == 2 ? me : u1;
-            const REAL dd4 = rr == 0 ? w3 : rr == 1 ? w2 : rr == 2 ? w1 : me;
-            REAL det;
-            if (rr == 0) det = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
-            else if (rr == 1) det = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
-            else if (rr == 2) det = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
-            else det = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
-            sol[l][m] = det * inv_detA;
-          }
-        }
-      }
       // ---- relaxation (:626-633)
 #pragma unroll
       for (int l = 0; l < L; l++) {
@@ -988,6 +999,354 @@ pcr_line_reg_maf_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict
     const double tot = block_sum<64 * NW>(x, wsum);
     if (threadIdx.x == 0) {
       dst[0] = accumulate ? dst[0] + tot : tot;
+      *counter = 0u;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pcr / pcr_esa (cz_solver.f90:666-878, :1036-1250): the lexicographic line SOR in ONE launch per sweep instead of one per diagonal.
+// In the order (j outer, i inner) the line (i,j) sees the new values of (i-1,j) and (i,j-1) and the old ones of (i+1,j) and (i,j+1):
+// the chain (i,j) -> (i+1,j), (i,j) -> (i,j+1) is (ni + nj) line solves long whatever the number of lines in flight, so the sweep is
+// bounded by the LATENCY of one line solve plus the time to hand a line to the row below -- not by throughput.  Hence:
+//   * a line is solved by NT >= n threads, one entry each: the right-hand side ping-pongs between two LDS rows (pcr_rb2_k's arithmetic,
+//     one workgroup barrier per stage that orders LDS only -- the global loads of the next line stay in flight across it), the entry's
+//     coefficients of every stage are read from an LDS copy of pcr_coef_k's table together with the three right-hand sides (one LDS
+//     round trip per stage);
+//   * a group of NT threads owns a row j and walks i = ist..ied, one line per step:
+//       (i-1,j) new   the thread's own previous result, in a register
+//       (i+1,j) old   the row's next line, loaded a step ahead (it is also the centre line `pp` of the next step)
+//       (i,j+1) old   loaded a step ahead -- the owner of row j+1 cannot touch it before this row has published (i,j)
+//       (i,j-1) new   from the row above: inside a workgroup (R groups, Q rows per thread: a strip of R*Q rows in lock step, row rs one
+//                     line behind row rs-1) through LDS or the thread's own registers; between workgroups through memory: the last row of
+//                     a strip stores its line write-through (agent-scope relaxed atomic stores, `sc1`); two stages into the next step
+//                     its waves wait for the acknowledgement (vmcnt) and, behind the barrier, one thread publishes the count of finished
+//                     lines in `ctl`; the strip below polls that count and reads the line with agent-scope loads -- the hand-off of
+//                     arrive_and_test_last, repeated per line.  Measured at 512^3 FP32: a step takes 2.0 us (8 stages x 0.155 us +
+//                     source term, final systems, relaxation), the hand-off adds 2.4 us per strip; with one row per workgroup the sweep
+//                     is (ni + nj) x 2.0 us + nj x 2.4 us (profiles/r02/pcr_lex_*).  More rows per workgroup make every step slower
+//                     by more than the hand-offs they save (a stage costs in proportion to the waves behind its barrier).
+// Progress: strips are handed out by a ticket (`ctl[0]`), so the strip a workgroup waits for was taken earlier by a workgroup that is
+// running or has finished -- no assumption about how many workgroups are resident.  Every wait is bounded (`spin_limit` ticks of the
+// 100 MHz wall clock): on expiry `ctl[1]` is set, all workgroups leave, and the residual is NaN (a lost hand-off must not pass for a result).
+// Same operations on the same operand values as the launch-per-diagonal path (pcr_line_reg_k<ORDER=1>) and the reference => same bits.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kPipeCtlStride = 32;  // one 128-byte line per strip counter; ctl[0] = next strip, ctl[1] = error, counters from ctl[kPipeCtlStride]
+
+// one poll of a bounded wait: true when the wait must be given up (time is up, or another workgroup has given up)
+__device__ __forceinline__ bool pipe_give_up(unsigned& polls, long long& t0, long long limit, unsigned* ctl) {
+  __builtin_amdgcn_s_sleep(1);
+  if ((++polls & 255u) != 0) return false;
+  if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
+  const long long now = (long long)wall_clock64();
+  if (t0 == 0) {
+    t0 = now;
+    return false;
+  }
+  if (now - t0 <= limit) return false;
+  __hip_atomic_store(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
+__device__ __forceinline__ double block_sum_rt(double x, double* wsum, int nwaves) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) wsum[wave] = x;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < nwaves; w++) s += wsum[w];
+  return s;  // valid on thread 0
+}
+
+// workgroup barrier that orders LDS accesses only: __syncthreads() would also wait for every global load and store in flight
+// (vmcnt(0)), i.e. for the operands fetched a step ahead
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template <int FINAL4, int NT, int Q>
+__global__ void __launch_bounds__(1024)
+pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, const REAL* __restrict__ tab, int nfin,
+             int R, unsigned* ctl, int nstrips, long long spin_limit, double* partials, double* dst, int accumulate, unsigned* counter,
+             long long* prof) {
+  // NT threads per line (one entry each), R groups of NT threads, Q rows per group (a thread holds the same entry of Q consecutive rows:
+  // one barrier per stage serves Q line solves, the coefficients are read once for all of them, and row q+1 takes (i,j-1) from the
+  // registers of row q).  A strip = R*Q consecutive rows, row rs one line behind row rs-1.
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MAXST = 10;  // n <= 1024
+  const int t = threadIdx.x;
+  const int rg = __builtin_amdgcn_readfirstlane(t / NT);  // NT is a multiple of 64: a wave belongs to one group (uniform: row addresses stay scalar)
+  const int k = t - rg * NT;
+  const int n = g.n, LD = NT + 2, x = k + 1, RS = R * Q;
+  REAL* D = reinterpret_cast<REAL*>(smem);          // [2][RS][LD]: slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
+  REAL* NLINE = D + (size_t)2 * RS * LD;            // [R][NT]: the line the last row of each group has just finished, for the group below
+  REAL* TAB = NLINE + (size_t)R * NT;               // [3*nstage + NF][NT]: this entry's e | ap | cp of every stage, then the final system's coefficients
+  const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
+  const int ntab = 3 * nstage + (FINAL4 ? 7 : 3);
+  int* sh = reinterpret_cast<int*>(TAB + (size_t)ntab * NT);  // [0] strip, [1] count seen of the strip above, [2] a wait was given up
+  double* wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(sh + 8) + 15) & ~(size_t)15);
+  const int nwaves = (NT * R) >> 6;
+  const bool kin = k < n;
+
+  // ---- the coefficients (pcr_coef_k's table, natural order) into LDS, entry k of every row at [row][k]; zero where the reference has no entry
+  const int sfin = 1 << nstage;
+  const int kb = k & (sfin - 1), rr = k >> nstage;  // base entry and position in the final 2x2 / 4x4 system
+  for (int row = rg; row < ntab; row += R) {
+    REAL v = (REAL)0;
+    if (row < 3 * nstage) {
+      if (kin) v = tab[(size_t)row * n + k];
+    } else if (kin && kb < nfin) {
+      v = tab[(size_t)nstage * 3 * n + (size_t)(row - 3 * nstage) * nfin + kb];
+    }
+    TAB[(size_t)row * NT + k] = v;
+  }
+  const REAL* Tk = TAB + k;
+  const int f1i = kb + 1;
+  const int f2i = (kb + sfin <= n - 1) ? kb + 1 + sfin : n + 1;
+  const int f3i = (kb + 2 * sfin <= n - 1) ? kb + 1 + 2 * sfin : n + 1;
+  const int f4i = (kb + 3 * sfin <= n - 1) ? kb + 1 + 3 * sfin : n + 1;
+  for (int e = t; e < 2 * RS * LD; e += NT * R) D[e] = (REAL)0;
+  if (t == 0) sh[2] = 0;
+
+  const REAL r = (REAL)1.0 / (REAL)6.0;
+  const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
+  const int kc = min(k, n - 1);
+  const bool edge_lo = k == 0, edge_hi = k == n - 1;
+  unsigned polls = 0;
+  long long t0 = 0;
+  bool dead = false;
+
+  for (;;) {
+    __syncthreads();
+    if (t == 0) {
+      sh[0] = (int)__hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sh[1] = 0;
+      if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) sh[2] = 1;
+    }
+    __syncthreads();
+    const int strip = __builtin_amdgcn_readfirstlane(sh[0]);
+    if (strip >= nstrips || sh[2] != 0) break;
+    const int rlast = min(RS, g.nj - strip * RS) - 1;                      // last row of this strip that exists
+    const bool from_mem = strip > 0;                                       // row 0 of the strip reads (i,j-1) from the strip above
+    const bool feeds = strip * RS + rlast + 1 < g.nj;                      // a strip below reads row rlast
+    const bool drains = feeds && rg == rlast / Q;                          // this group stores that row
+    unsigned* my_cnt = ctl + (size_t)kPipeCtlStride * (1 + strip);
+    unsigned* up_cnt = ctl + (size_t)kPipeCtlStride * (strip > 0 ? strip : 1);
+
+    // Every load below is unconditional, from an address clamped into the array (entry kc, a row and a line that exist): a load in a
+    // divergent branch makes the compiler wait for ALL loads in flight at the next use of any of them, and the operands fetched a step
+    // ahead would be waited for at once.  What a clamped load returns for an entry, a row or a line that does not exist is never used.
+    size_t c0[Q];  // element (kst, ist, j) of row q
+    bool rowok[Q];
+    REAL xim[Q], pp[Q], xip[Q], xjp[Q], rh[Q], mk[Q], klo[Q], khi[Q];
+    REAL nxjm = (REAL)0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      const int rs = rg * Q + q;
+      rowok[q] = rs <= rlast;
+      c0[q] = (size_t)g.kk0 + (size_t)g.ii0 * rowlen + (size_t)(g.jj0 + strip * RS + min(rs, rlast)) * plane;
+      const size_t e0 = c0[q] + kc;
+      xim[q] = X[e0 - rowlen], pp[q] = X[e0], xip[q] = X[e0 + rowlen], xjp[q] = X[e0 + plane], rh[q] = RHS[e0], mk[q] = MSK[e0];
+      klo[q] = X[c0[q] - 1], khi[q] = X[c0[q] + n];
+    }
+    if (rg == 0) nxjm = __hip_atomic_load(X + c0[0] + kc - plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used only above strip 0 (the boundary plane)
+    bool have = !from_mem;  // nxjm holds the (i,j-1) entry of the coming line of row 0
+    double acc = 0.0;
+    long long pf_start = 0, pf_first = 0, pf_wait = 0, pf_nwait = 0;  // CZHIP_PCR_PIPE_PROF (thread 0)
+    long long pf_ph[4] = {0, 0, 0, 0}, pf_m = 0;  // ticks up to the first barrier / in the stages / final + relax / rotation + last barrier
+    if (prof && t == 0) pf_start = (long long)wall_clock64();
+    const int nsteps = g.ni + rlast;
+
+    for (int st = 0; st < nsteps; st++) {
+      // ---- (i,j-1) of row 0 when it has not come a step ahead: wait for the strip above (st is row 0's line)
+      if (from_mem && st < g.ni && !have) {
+        if (t == 0) {
+          long long pa = 0;
+          if (prof) pa = (long long)wall_clock64();
+          int seen = sh[1];
+          while (seen < st + 1) {
+            seen = (int)__hip_atomic_load(up_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen < st + 1 && pipe_give_up(polls, t0, spin_limit, ctl)) {
+              sh[2] = 1;
+              break;
+            }
+          }
+          t0 = 0;
+          sh[1] = seen;
+          if (prof) {
+            const long long pb = (long long)wall_clock64();
+            pf_wait += pb - pa, pf_nwait++;
+            if (st == 0) pf_first = pb;
+          }
+        }
+        lds_barrier();
+        if (sh[2]) {
+          dead = true;
+          break;
+        }
+      }
+      if (prof && t == 0) pf_m = (long long)wall_clock64();
+      const int seen_now = sh[1];
+      bool act[Q], on[Q];
+      size_t cl[Q], en[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        const int i = st - (rg * Q + q);
+        act[q] = rowok[q] && i >= 0 && i < g.ni;
+        on[q] = act[q] && kin;
+        const int ic = min(max(i, 0), g.ni - 1);
+        cl[q] = c0[q] + (size_t)ic * rowlen;                       // element (kst, ist+i, j)
+        en[q] = c0[q] + (size_t)min(ic + 1, g.ni - 1) * rowlen;    // element (kst, ist+i+1, j)
+      }
+      // ---- source terms (:558-568)
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        REAL xjm;
+        if (q > 0) {
+          xjm = xim[q - 1];  // what row q-1 finished in the step before: its line i
+        } else if (rg == 0) {
+          xjm = nxjm;
+          if (!have) xjm = __hip_atomic_load(X + cl[0] + kc - plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          xjm = NLINE[(size_t)(rg - 1) * NT + kc];
+        }
+        REAL dv = ((xjm + xjp[q] + xim[q] + xip[q] - rh[q]) * r) * mk[q];
+        if (edge_lo) dv = (dv + klo[q] * r) * mk[q];
+        if (edge_hi) dv = (dv + khi[q] * r) * mk[q];
+        if (on[q]) D[(size_t)(rg * Q + q) * LD + x] = dv;
+      }
+      // ---- operands of the next lines, most of a step ahead of their use: fetched behind the second stage (behind the drain of the
+      // row that feeds the next strip), consumed at the end of the step
+      REAL n_xip[Q], n_xjp[Q], n_rh[Q], n_mk[Q], n_klo[Q], n_khi[Q], n_xjm = (REAL)0;
+      unsigned cnt_async = 0;
+      if (from_mem) have = seen_now >= st + 2;  // (every thread: it decides a barrier of the next step)
+      auto fetch_next = [&]() {
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          n_xip[q] = X[en[q] + rowlen + kc], n_xjp[q] = X[en[q] + plane + kc], n_rh[q] = RHS[en[q] + kc], n_mk[q] = MSK[en[q] + kc];
+          n_klo[q] = X[en[q] - 1], n_khi[q] = X[en[q] + n];
+        }
+        if (rg == 0) {
+          n_xjm = __hip_atomic_load(X + en[0] + kc - plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // valid only if the count allowed it (have)
+          cnt_async = __hip_atomic_load(up_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              // consumed at the end of the step
+        }
+      };
+      lds_barrier();
+      if (prof && t == 0) {
+        const long long nw = (long long)wall_clock64();
+        pf_ph[0] += nw - pf_m, pf_m = nw;
+      }
+      // ---- PCR stages (:572-595), right-hand side only
+#pragma unroll
+      for (int sidx = 0; sidx < MAXST; sidx++) {
+        if (sidx < nstage) {
+          const int s = 1 << sidx;
+          {  // all LDS reads in flight at once (this entry's coefficients of the stage and three right-hand sides per row), one wait
+            const REAL* dc = D + (size_t)((sidx & 1) * RS + rg * Q) * LD;
+            REAL* dn = D + (size_t)(((sidx & 1) ^ 1) * RS + rg * Q) * LD;
+            const int kl = (k - s >= 0) ? x - s : 0;
+            const int kr = (k + s <= n - 1) ? x + s : n + 1;
+            const REAL e = Tk[(3 * sidx) * NT], ap = Tk[(3 * sidx + 1) * NT], cp = Tk[(3 * sidx + 2) * NT];
+            REAL d0[Q], dl[Q], dr[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) d0[q] = dc[q * LD + x], dl[q] = dc[q * LD + kl], dr[q] = dc[q * LD + kr];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+              const REAL nd = e * (d0[q] - ap * dl[q] - cp * dr[q]);
+              if (on[q]) dn[q * LD + x] = nd;
+            }
+          }
+          if (sidx == 1) {  // (nstage >= 2: try_pcr_lex_wg)
+            // the line stored in the step before has had the time of two stages: drain the stores, then (behind the barrier) count it
+            if (drains) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          lds_barrier();
+          if (sidx == 1) {
+            const int idone = st - rlast;  // lines of row rlast that are stored and drained
+            if (drains && k == 0 && idone >= 1 && idone <= g.ni) __hip_atomic_store(my_cnt, (unsigned)idone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fetch_next();
+          }
+        }
+      }
+      if (prof && t == 0) {
+        const long long nw = (long long)wall_clock64();
+        pf_ph[1] += nw - pf_m, pf_m = nw;
+      }
+      // ---- final systems (:599-616 / Cramer's rule :787-842), every entry solves for itself; relaxation (:626-633)
+      REAL out[Q];
+      {
+        const REAL* dc = D + (size_t)((nstage & 1) * RS + rg * Q) * LD;  // (pointer arithmetic, not a select of two pointers: the address space must stay LDS)
+        const REAL* cf = Tk + (size_t)3 * nstage * NT;
+        REAL cfv[FINAL4 ? 7 : 3];
+#pragma unroll
+        for (int v = 0; v < (FINAL4 ? 7 : 3); v++) cfv[v] = cf[(size_t)v * NT];
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+          REAL sol;
+          if (!FINAL4) {
+            const REAL jj2 = cfv[0], cc1 = cfv[1], aa2 = cfv[2];
+            const REAL f1 = dc[q * LD + f1i], f2 = dc[q * LD + f2i];
+            sol = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;
+          } else {
+            const REAL inv_detA = cfv[0], cc1 = cfv[1], cc2 = cfv[2], cc3 = cfv[3], aa2 = cfv[4], aa3 = cfv[5], aa4 = cfv[6];
+            const REAL dd1 = dc[q * LD + f1i], dd2 = dc[q * LD + f2i], dd3 = dc[q * LD + f3i], dd4 = dc[q * LD + f4i];
+            REAL det;
+            if (rr == 0) det = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+            else if (rr == 1) det = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+            else if (rr == 2) det = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+            else det = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+            sol = det * inv_detA;
+          }
+          const REAL dp = (sol - pp[q]) * omg * mk[q];
+          out[q] = pp[q] + dp;
+          const REAL d2 = dp * dp;
+          if (on[q]) {
+            acc += (double)d2;
+            if (feeds && rg * Q + q == rlast) __hip_atomic_store(X + cl[q] + k, out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else X[cl[q] + k] = out[q];
+            if (q == Q - 1) NLINE[(size_t)rg * NT + k] = out[q];
+          }
+        }
+      }
+      if (prof && t == 0) {
+        const long long nw = (long long)wall_clock64();
+        pf_ph[2] += nw - pf_m, pf_m = nw;
+      }
+#pragma unroll
+      for (int q = 0; q < Q; q++)
+        if (act[q]) xim[q] = out[q], pp[q] = xip[q], xip[q] = n_xip[q], xjp[q] = n_xjp[q], rh[q] = n_rh[q], mk[q] = n_mk[q], klo[q] = n_klo[q], khi[q] = n_khi[q];
+      nxjm = n_xjm;
+      if (t == 0 && from_mem) sh[1] = max(seen_now, (int)cnt_async);
+      lds_barrier();
+      if (prof && t == 0) pf_ph[3] += (long long)wall_clock64() - pf_m;
+    }
+    if (drains) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (drains && k == 0 && !dead) __hip_atomic_store(my_cnt, (unsigned)g.ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double sblk = block_sum_rt(acc, wsum, nwaves);
+    if (t == 0) __hip_atomic_store(&partials[strip], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prof && t == 0) {
+      long long* q = prof + (size_t)8 * strip;
+      q[0] = pf_start, q[1] = pf_first, q[2] = (long long)wall_clock64(), q[3] = pf_wait, q[4] = pf_nwait, q[5] = blockIdx.x, q[6] = (pf_ph[0] << 32) | pf_ph[1], q[7] = (pf_ph[2] << 32) | pf_ph[3];
+    }
+  }
+  // ---- residual: the strips' partials in strip order, by the workgroup that arrives last (hand-off as in stencil_k)
+  int* last_flag = sh + 4;
+  const int nblk = gridDim.x;
+  if (t == 0) *last_flag = arrive_and_test_last(counter, nblk);
+  __syncthreads();
+  if (*last_flag) {
+    double xs = 0.0;
+    for (int q = t; q < nstrips; q += NT * R) xs += __hip_atomic_load(&partials[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const double tot = block_sum_rt(xs, wsum, nwaves);
+    if (t == 0) {
+      const bool bad = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      dst[0] = bad ? __builtin_nan("") : (accumulate ? dst[0] + tot : tot);
       *counter = 0u;
     }
   }

@@ -168,6 +168,12 @@ int czhip_init(int device) {
     sscanf(pc, "%d,%d", &f, &v);
     ctx.tune.pcr_fast = f, ctx.tune.pcr_variant = v;
   }
+  if (const char* pp = getenv("CZHIP_PCR_PIPE")) {  // "form[,seconds[,groups[,rows per thread]]]": form as Tuning::pcr_pipe; bound of the waits inside the kernel
+    int w = 1, rows = 0, q = 1;
+    double sec = 2.0;
+    sscanf(pp, "%d,%lf,%d,%d", &w, &sec, &rows, &q);
+    ctx.tune.pcr_pipe = w, ctx.tune.pipe_spin_ticks = (long long)(sec * 1e8), ctx.tune.pcr_rows = rows, ctx.tune.pcr_q = q;
+  }
   const char* tu = getenv("CZHIP_TUNING");  // "threads,m,tj,pf"
   if (tu) {
     int a = 0, b = 0, c = 0, d = -1;
@@ -187,6 +193,8 @@ void czhip_finalize(void) {
   (void)hipFree(ctx.shell_partials);
   if (ctx.pcr_tab) (void)hipFree(ctx.pcr_tab);
   if (ctx.pcr_tab_perm) (void)hipFree(ctx.pcr_tab_perm);
+  if (ctx.pipe_ctl) (void)hipFree(ctx.pipe_ctl);
+  ctx.pipe_ctl = nullptr, ctx.pipe_ctl_cap = 0;
   (void)hipFree(ctx.scal_dev);
   (void)hipHostFree(ctx.scal_host);
   if (ctx.counter) (void)hipFree(ctx.counter);
