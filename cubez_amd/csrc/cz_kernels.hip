@@ -474,6 +474,17 @@ int czhip_set_pcr_mode(int form, int variant) {
   return 0;
 }
 
+// the lexicographic line SOR (pcr_, pcr_esa_, pcr_eda_ and the solvers of those names): one_launch 1 = pcr_lex_wg_k, 0 = a launch per
+// diagonal; groups of threads per workgroup (0 = the launcher's choice); rows per thread (1 | 2).  Negative: keep.  Same bits in every shape.
+int czhip_set_pcr_lex(int one_launch, int groups, int rows_per_thread) {
+  ensure_init();
+  if (rows_per_thread > 2 || rows_per_thread == 0) return 1;
+  if (one_launch >= 0) ctx.tune.pcr_pipe = one_launch ? 1 : 0;
+  if (groups >= 0) ctx.tune.pcr_rows = groups;
+  if (rows_per_thread > 0) ctx.tune.pcr_q = rows_per_thread;
+  return 0;
+}
+
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev) {
   ensure_init();

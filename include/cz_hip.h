@@ -240,6 +240,10 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
  * table + right-hand side in LDS, 2 = table + right-hand side in registers (default); variant = waves*10 + lines per wave, 0 = default;
  * negative = keep.  All forms give the same bits. */
 int czhip_set_pcr_mode(int form, int variant);
+/* the lexicographic line SOR (pcr_, pcr_esa_, pcr_eda_; reference: cz_solver.f90:666-878, one thread walking j, i): one_launch 1 = the whole
+ * sweep in one launch, rows of lines handed from workgroup to workgroup (default), 0 = one launch per diagonal i+j; groups of threads per
+ * workgroup (0 = chosen per launch); rows per thread (1 | 2).  Negative = keep.  Every shape gives the same bits. */
+int czhip_set_pcr_lex(int one_launch, int groups, int rows_per_thread);
 int czhip_use_t2(void);
 /* self-test: numerators (of 2^32) whose quotient by d in the two-stage pass differs from the IEEE division (expected 0); -1 = divisor not eligible */
 long long czhip_selftest_fastdiv(CZ_REAL d);

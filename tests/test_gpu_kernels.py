@@ -607,6 +607,44 @@ def test_pcr_variants_random_boxes_vs_oracle(prec, box):
             assert h.last_flop == ko.last_flop, name
 
 
+LEX_SHAPES = [(0, 0, 1), (1, 0, 1), (1, 2, 1), (1, 0, 2), (1, 2, 2), (1, 3, 2)]  # (one launch?, groups per workgroup, rows per thread)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("lex", LEX_SHAPES, ids=lambda t: "diagonals" if not t[0] else f"one_launch_g{t[1]}_q{t[2]}")
+@pytest.mark.parametrize("box", [(9, 8, 32), (20, 13, 64), (7, 11, 130), (12, 9, 40), (33, 37, 20), (5, 4, 512), (6, 1, 70), (1, 6, 70)],
+                         ids=lambda b: "x".join(map(str, b)))
+def test_lexicographic_line_sor_every_launch_shape_vs_oracle(prec, lex, box):
+    """pcr / pcr_esa / pcr_eda (cz_solver.f90:666-878 and the _esa / _eda forms: lines in the order j outer, i inner, each seeing the new
+    values of (i-1,j) and (i,j-1)) == the oracle bit for bit, whether the sweep runs as one launch per diagonal or as ONE launch with rows
+    of lines handed from workgroup to workgroup (pcr_lex_wg_k) -- one or several groups of threads per workgroup, one or two rows per
+    thread, strips that end in a partial one, a single row, a single line per row."""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    if ni < 3 or nj < 3:  # the inner range must exist: widen the single-row / single-line cases
+        sz = [max(ni, 1) + 2, max(nj, 1) + 2, nk]
+        idx = [2, ni + 1, 2, nj + 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (sz[1] + 4, sz[0] + 4, sz[2] + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    assert h.lib.czhip_set_pcr_lex(*lex) == 0
+    try:
+        for name in ("pcr", "pcr_esa", "pcr_eda"):
+            x1, dx = x0.copy(), h.alloc(sz, x0)
+            for it in range(3):
+                r1, r2 = getattr(ko, name)(sz, idx, pn, x1, msk, rhs, 1.3), getattr(h, name)(sz, idx, pn, dx, dm, dr, 1.3)
+                assert _beq(dx.get(), x1), (name, it)
+                assert r2 == r2 and _rel(r2, r1) < (2e-3 if prec == "f32" else 1e-11), (name, r1, r2)
+    finally:
+        h.lib.czhip_set_pcr_lex(1, 0, 1)
+
+
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("nk", [3, 4, 5, 6, 7, 10])
 def test_line_sor_short_lines(prec, nk):
