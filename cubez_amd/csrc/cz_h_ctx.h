@@ -27,6 +27,9 @@ struct Ctx {
   size_t pcr_perm_cap = 0;
   unsigned* pipe_ctl = nullptr;  // pcr_lex_wg_k: strip ticket, error word, one counter per strip (zeroed before every sweep)
   size_t pipe_ctl_cap = 0;
+  unsigned long long* pipe_hb = nullptr;  // pcr_lex_wg_k: hand-off lines between strips ({sequence number | value} words)
+  size_t pipe_hb_cap = 0;
+  unsigned pipe_seq = 0;         // sequence numbers handed out so far (monotonic: a stale word never matches)
   REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
   int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
   size_t pcr_tab_cap = 0;

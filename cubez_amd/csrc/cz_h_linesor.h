@@ -164,7 +164,7 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_lex_wg_k<FINAL4, NT, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const size_t ctl_words = (size_t)kPipeCtlStride * (nstrips + 1);
+  const size_t ctl_words = (size_t)kPipeCtlStride * (nstrips + 2);
   if (ctl_words > ctx.pipe_ctl_cap) {
     if (ctx.pipe_ctl) {
       HIP_CHECK(hipStreamSynchronize(ctx.stream));
@@ -174,9 +174,36 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
     ctx.pipe_ctl_cap = ctl_words;
   }
   ensure_partials((size_t)nstrips);
-  // as many workgroups as fit the chip at once (LDS and 2048 threads per CU); the strips beyond are taken by the workgroups that finish first
-  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)2048 / ((size_t)NT * R)));
+  // Workgroups: as many as fit the chip at once (measured at 512^3: one per CU steps no faster than two, and the strips beyond the
+  // resident window then wait for a workgroup: 4.21 against 4.08 ms); CZHIP_PCR_WG_PER_CU overrides.
+  const int fit = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)2048 / ((size_t)NT * R)));
+  static const int per_cu_env = getenv("CZHIP_PCR_WG_PER_CU") ? atoi(getenv("CZHIP_PCR_WG_PER_CU")) : 0;
+  const int per_cu = per_cu_env > 0 ? std::min(per_cu_env, fit) : fit;
   const unsigned nblk = (unsigned)std::min(nstrips, ctx.num_cu * per_cu);
+  // Hand-off buffer: per strip `nslots` lines of {sequence number | value} words.  A strip may run at most nslots lines ahead of the strip
+  // below; with nblk workgroups resident the strip at the head of the resident window can then reach line nblk x nslots, which must cover
+  // its whole row so that it ends and frees a workgroup for the first strip that is not resident yet.
+  static const int slots_env = getenv("CZHIP_PCR_SLOTS") ? atoi(getenv("CZHIP_PCR_SLOTS")) : 0;
+  int nslots = slots_env > 0 ? slots_env : 8;  // (what a strip knows of the progress of the strip below is a step or two old: 4 slots make it wait in most steps)
+  while (nslots < (g.ni + (int)nblk - 1) / (int)nblk + 2) nslots *= 2;
+  constexpr size_t HW = sizeof(REAL) == 8 ? 2 : 1;
+  const size_t hb_words = (size_t)nstrips * nslots * NT * HW;
+  if (hb_words > ctx.pipe_hb_cap) {
+    if (ctx.pipe_hb) {
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      HIP_CHECK(hipFree(ctx.pipe_hb));
+    }
+    HIP_CHECK(hipMalloc(&ctx.pipe_hb, hb_words * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemsetAsync(ctx.pipe_hb, 0, hb_words * sizeof(unsigned long long), ctx.stream));
+    ctx.pipe_hb_cap = hb_words;
+    ctx.pipe_seq = 0;
+  }
+  if (ctx.pipe_seq > 0xffffffffu - (unsigned)(g.ni + 2)) {  // the sequence numbers would wrap: start over on a clean buffer
+    HIP_CHECK(hipMemsetAsync(ctx.pipe_hb, 0, ctx.pipe_hb_cap * sizeof(unsigned long long), ctx.stream));
+    ctx.pipe_seq = 0;
+  }
+  const unsigned seq_base = ctx.pipe_seq;  // line i of this sweep carries seq_base + i + 1: larger than anything the buffer holds
+  ctx.pipe_seq += (unsigned)g.ni + 1u;
   ScopedTimer tm(LBL_PCR);
   HIP_CHECK(hipMemsetAsync(ctx.pipe_ctl, 0, ctl_words * sizeof(unsigned), ctx.stream));
   long long* prof = nullptr;
@@ -186,7 +213,7 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
     HIP_CHECK(hipMemsetAsync(prof, 0, (size_t)8 * nstrips * sizeof(long long), ctx.stream));
   }
   hipLaunchKernelGGL((pcr_lex_wg_k<FINAL4, NT, Q>), dim3(nblk), dim3(NT * R), lds, ctx.stream, x, msk, rhs, g, omg, ctx.pcr_tab, nfin, R, ctx.pipe_ctl,
-                     nstrips, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, prof);
+                     ctx.pipe_hb, nslots, seq_base, nstrips, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, prof);
   HIP_CHECK(hipGetLastError());
   if (prof) {
     std::vector<long long> h((size_t)8 * nstrips);

@@ -1018,16 +1018,22 @@ pcr_line_reg_maf_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict
 //       (i+1,j) old   the row's next line, loaded a step ahead (it is also the centre line `pp` of the next step)
 //       (i,j+1) old   loaded a step ahead -- the owner of row j+1 cannot touch it before this row has published (i,j)
 //       (i,j-1) new   from the row above: inside a workgroup (R groups, Q rows per thread: a strip of R*Q rows in lock step, row rs one
-//                     line behind row rs-1) through LDS or the thread's own registers; between workgroups through memory: the last row of
-//                     a strip stores its line write-through (agent-scope relaxed atomic stores, `sc1`); two stages into the next step
-//                     its waves wait for the acknowledgement (vmcnt) and, behind the barrier, one thread publishes the count of finished
-//                     lines in `ctl`; the strip below polls that count and reads the line with agent-scope loads -- the hand-off of
-//                     arrive_and_test_last, repeated per line.  Measured at 512^3 FP32: a step takes 2.0 us (8 stages x 0.155 us +
-//                     source term, final systems, relaxation), the hand-off adds 2.4 us per strip; with one row per workgroup the sweep
-//                     is (ni + nj) x 2.0 us + nj x 2.4 us (profiles/r02/pcr_lex_*).  More rows per workgroup make every step slower
-//                     by more than the hand-offs they save (a stage costs in proportion to the waves behind its barrier).
+//                     line behind row rs-1) through LDS or the thread's own registers; between workgroups through memory, in the manner
+//                     of RCCL's LL protocol: the last row of a strip writes every entry of its line as ONE 64-bit word {sequence number of
+//                     the line | value bits} (FP64: two words, each with half of the bits) into a ring of `nslots` lines, with agent-scope
+//                     relaxed atomic stores (`sc1`, write-through); the thread of the strip below that needs the entry reads the word with
+//                     an agent-scope load -- asked for late in the step before -- and takes the value once the word carries the number it
+//                     expects, reading again until it does.  A 64-bit store is single-copy atomic, so value and number arrive together:
+//                     no drain of the stores, no separate flag, no barrier, one memory round trip.  Sequence numbers grow from sweep to
+//                     sweep (`seq_base`), so a stale word never matches.  The strip below publishes the number of lines it has taken
+//                     (`ctl`, one store per step); the strip above reads that a step ahead and does not overwrite a slot that is not free.
+//                     Measured at 512^3 FP32 (profiles/r02/pcr_lex_*): a step takes 2.1 us (8 stages x 0.13 us + source term and fetches
+//                     0.44 + final systems and relaxation 0.40 + rotation 0.2), a strip starts 2.6-2.8 us behind the one above; the sweep is
+//                     nj x (lag + step').  More rows per workgroup make every step slower by more than the hand-offs they save.
 // Progress: strips are handed out by a ticket (`ctl[0]`), so the strip a workgroup waits for was taken earlier by a workgroup that is
-// running or has finished -- no assumption about how many workgroups are resident.  Every wait is bounded (`spin_limit` ticks of the
+// running or has finished.  The ring adds one condition: a strip may run at most nslots lines ahead of the strip below, so the launcher
+// starts no more workgroups than the chip holds at once and sizes nslots such that the first strip of the resident window can finish
+// (and free its workgroup for the next strip) however far the window's last strip is held back.  Every wait is bounded (`spin_limit` ticks of the
 // 100 MHz wall clock): on expiry `ctl[1]` is set, all workgroups leave, and the residual is NaN (a lost hand-off must not pass for a result).
 // Same operations on the same operand values as the launch-per-diagonal path (pcr_line_reg_k<ORDER=1>) and the reference => same bits.
 // ------------------------------------------------------------------------------------------------------------
@@ -1071,8 +1077,8 @@ __device__ __forceinline__ void lds_barrier() {
 template <int FINAL4, int NT, int Q>
 __global__ void __launch_bounds__(1024)
 pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, const REAL* __restrict__ tab, int nfin,
-             int R, unsigned* ctl, int nstrips, long long spin_limit, double* partials, double* dst, int accumulate, unsigned* counter,
-             long long* prof) {
+             int R, unsigned* ctl, unsigned long long* hb, int nslots, unsigned seq_base, int nstrips, long long spin_limit, double* partials,
+             double* dst, int accumulate, unsigned* counter, long long* prof) {
   // NT threads per line (one entry each), R groups of NT threads, Q rows per group (a thread holds the same entry of Q consecutive rows:
   // one barrier per stage serves Q line solves, the coefficients are read once for all of them, and row q+1 takes (i,j-1) from the
   // registers of row q).  A strip = R*Q consecutive rows, row rs one line behind row rs-1.
@@ -1087,7 +1093,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   REAL* TAB = NLINE + (size_t)R * NT;               // [3*nstage + NF][NT]: this entry's e | ap | cp of every stage, then the final system's coefficients
   const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
   const int ntab = 3 * nstage + (FINAL4 ? 7 : 3);
-  int* sh = reinterpret_cast<int*>(TAB + (size_t)ntab * NT);  // [0] strip, [1] count seen of the strip above, [2] a wait was given up
+  int* sh = reinterpret_cast<int*>(TAB + (size_t)ntab * NT);  // [0] strip, [2] a wait was given up
   double* wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(sh + 8) + 15) & ~(size_t)15);
   const int nwaves = (NT * R) >> 6;
   const bool kin = k < n;
@@ -1118,13 +1124,11 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   const bool edge_lo = k == 0, edge_hi = k == n - 1;
   unsigned polls = 0;
   long long t0 = 0;
-  bool dead = false;
 
   for (;;) {
     __syncthreads();
     if (t == 0) {
       sh[0] = (int)__hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sh[1] = 0;
       if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) sh[2] = 1;
     }
     __syncthreads();
@@ -1133,9 +1137,13 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
     const int rlast = min(RS, g.nj - strip * RS) - 1;                      // last row of this strip that exists
     const bool from_mem = strip > 0;                                       // row 0 of the strip reads (i,j-1) from the strip above
     const bool feeds = strip * RS + rlast + 1 < g.nj;                      // a strip below reads row rlast
-    const bool drains = feeds && rg == rlast / Q;                          // this group stores that row
-    unsigned* my_cnt = ctl + (size_t)kPipeCtlStride * (1 + strip);
-    unsigned* up_cnt = ctl + (size_t)kPipeCtlStride * (strip > 0 ? strip : 1);
+    unsigned* my_prog = ctl + (size_t)kPipeCtlStride * (1 + strip);        // lines of the strip above this strip has taken
+    unsigned* dn_prog = ctl + (size_t)kPipeCtlStride * (2 + strip);        // lines of this strip the strip below has taken
+    // hand-off words of entry kc: {sequence number | value bits}; FP64: two words, each with half of the bits
+    constexpr int HW = sizeof(REAL) == 8 ? 2 : 1;
+    unsigned long long* hb_out = hb + ((size_t)strip * nslots * NT + kc) * HW;
+    const unsigned long long* hb_in = hb + ((size_t)(strip > 0 ? strip - 1 : 0) * nslots * NT + kc) * HW;
+    const int smask = nslots - 1;
 
     // Every load below is unconditional, from an address clamped into the array (entry kc, a row and a line that exist): a load in a
     // divergent branch makes the compiler wait for ALL loads in flight at the next use of any of them, and the operands fetched a step
@@ -1153,8 +1161,18 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       xim[q] = X[e0 - rowlen], pp[q] = X[e0], xip[q] = X[e0 + rowlen], xjp[q] = X[e0 + plane], rh[q] = RHS[e0], mk[q] = MSK[e0];
       klo[q] = X[c0[q] - 1], khi[q] = X[c0[q] + n];
     }
-    if (rg == 0) nxjm = __hip_atomic_load(X + c0[0] + kc - plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used only above strip 0 (the boundary plane)
-    bool have = !from_mem;  // nxjm holds the (i,j-1) entry of the coming line of row 0
+    unsigned long long hw[HW];  // row 0 below another strip: the hand-off words of the coming line, fetched a step ahead
+#pragma unroll
+    for (int w = 0; w < HW; w++) hw[w] = 0ull;
+    if (rg == 0) {
+      if (from_mem) {
+#pragma unroll
+        for (int w = 0; w < HW; w++) hw[w] = __hip_atomic_load(hb_in + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        nxjm = X[c0[0] + kc - plane];  // the boundary plane
+      }
+    }
+    int dn_seen = 0, dn_next = 0;  // lower bounds of dn_prog (the group that hands its row down)
     double acc = 0.0;
     long long pf_start = 0, pf_first = 0, pf_wait = 0, pf_nwait = 0;  // CZHIP_PCR_PIPE_PROF (thread 0)
     long long pf_ph[4] = {0, 0, 0, 0}, pf_m = 0;  // ticks up to the first barrier / in the stages / final + relax / rotation + last barrier
@@ -1162,35 +1180,35 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
     const int nsteps = g.ni + rlast;
 
     for (int st = 0; st < nsteps; st++) {
-      // ---- (i,j-1) of row 0 when it has not come a step ahead: wait for the strip above (st is row 0's line)
-      if (from_mem && st < g.ni && !have) {
-        if (t == 0) {
-          long long pa = 0;
-          if (prof) pa = (long long)wall_clock64();
-          int seen = sh[1];
-          while (seen < st + 1) {
-            seen = (int)__hip_atomic_load(up_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (seen < st + 1 && pipe_give_up(polls, t0, spin_limit, ctl)) {
-              sh[2] = 1;
-              break;
-            }
-          }
-          t0 = 0;
-          sh[1] = seen;
-          if (prof) {
-            const long long pb = (long long)wall_clock64();
-            pf_wait += pb - pa, pf_nwait++;
-            if (st == 0) pf_first = pb;
+      // ---- (i,j-1) of row 0 below another strip: the words fetched a step ahead are the line st once they carry its sequence number;
+      // until then read them again (every thread for itself: no barrier, no separate flag)
+      if (rg == 0 && from_mem && st < g.ni) {
+        const unsigned want = seq_base + (unsigned)st + 1u;
+        long long pa = 0;
+        if (prof && t == 0) pa = (long long)wall_clock64();
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < HW; w++) ok = ok && (unsigned)(hw[w] >> 32) == want;
+        while (!ok) {
+          const unsigned long long* src = hb_in + (size_t)(st & smask) * NT * HW;
+#pragma unroll
+          for (int w = 0; w < HW; w++) hw[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = true;
+#pragma unroll
+          for (int w = 0; w < HW; w++) ok = ok && (unsigned)(hw[w] >> 32) == want;
+          if (!ok && pipe_give_up(polls, t0, spin_limit, ctl)) {
+            sh[2] = 1;
+            break;
           }
         }
-        lds_barrier();
-        if (sh[2]) {
-          dead = true;
-          break;
+        t0 = 0;
+        if (prof && t == 0) {
+          const long long pb = (long long)wall_clock64();
+          pf_wait += pb - pa, pf_nwait += (pb - pa > 20);
+          if (st == 0) pf_first = pb;
         }
       }
       if (prof && t == 0) pf_m = (long long)wall_clock64();
-      const int seen_now = sh[1];
       bool act[Q], on[Q];
       size_t cl[Q], en[Q];
 #pragma unroll
@@ -1209,8 +1227,16 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
         if (q > 0) {
           xjm = xim[q - 1];  // what row q-1 finished in the step before: its line i
         } else if (rg == 0) {
-          xjm = nxjm;
-          if (!have) xjm = __hip_atomic_load(X + cl[0] + kc - plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (from_mem) {
+            if (sizeof(REAL) == 8) {
+              const unsigned long long bits = (hw[0] & 0xffffffffull) | (hw[HW - 1] << 32);
+              xjm = (REAL)__longlong_as_double((long long)bits);
+            } else {
+              xjm = (REAL)__uint_as_float((unsigned)(hw[0] & 0xffffffffull));
+            }
+          } else {
+            xjm = nxjm;
+          }
         } else {
           xjm = NLINE[(size_t)(rg - 1) * NT + kc];
         }
@@ -1221,21 +1247,23 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       }
       // ---- operands of the next lines, most of a step ahead of their use: fetched behind the second stage (behind the drain of the
       // row that feeds the next strip), consumed at the end of the step
-      REAL n_xip[Q], n_xjp[Q], n_rh[Q], n_mk[Q], n_klo[Q], n_khi[Q], n_xjm = (REAL)0;
-      unsigned cnt_async = 0;
-      if (from_mem) have = seen_now >= st + 2;  // (every thread: it decides a barrier of the next step)
+      // (nxjm, hw and dn_next are written in place -- their old values were used at the top of the step -- and never reset: a register
+      // that is zeroed on one path and loaded on another makes the compiler wait for the loads in flight at the zeroing)
+      REAL n_xip[Q], n_xjp[Q], n_rh[Q], n_mk[Q], n_klo[Q], n_khi[Q];
       auto fetch_next = [&]() {
 #pragma unroll
         for (int q = 0; q < Q; q++) {
           n_xip[q] = X[en[q] + rowlen + kc], n_xjp[q] = X[en[q] + plane + kc], n_rh[q] = RHS[en[q] + kc], n_mk[q] = MSK[en[q] + kc];
           n_klo[q] = X[en[q] - 1], n_khi[q] = X[en[q] + n];
         }
-        if (rg == 0) {
-          n_xjm = __hip_atomic_load(X + en[0] + kc - plane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // valid only if the count allowed it (have)
-          cnt_async = __hip_atomic_load(up_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              // consumed at the end of the step
-        }
+        // (no branch here, whatever the group or the strip: a register that is loaded on one path and kept on another is merged by a
+        // copy, and the copy waits for every load in flight.  Groups that need neither of the two read them all the same.)
+        nxjm = X[en[0] + kc - plane];
+        dn_next = (int)__hip_atomic_load(dn_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // used at the end of the next step
       };
+      fetch_next();
       lds_barrier();
+      if (sh[2]) break;  // a wait was given up (by a thread of this workgroup, before the barrier)
       if (prof && t == 0) {
         const long long nw = (long long)wall_clock64();
         pf_ph[0] += nw - pf_m, pf_m = nw;
@@ -1254,27 +1282,26 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
             REAL d0[Q], dl[Q], dr[Q];
 #pragma unroll
             for (int q = 0; q < Q; q++) d0[q] = dc[q * LD + x], dl[q] = dc[q * LD + kl], dr[q] = dc[q * LD + kr];
+            __builtin_amdgcn_sched_barrier(0);  // (all reads issued before the first use: one LDS round trip per stage, not two)
 #pragma unroll
             for (int q = 0; q < Q; q++) {
               const REAL nd = e * (d0[q] - ap * dl[q] - cp * dr[q]);
               if (on[q]) dn[q * LD + x] = nd;
             }
           }
-          if (sidx == 1) {  // (nstage >= 2: try_pcr_lex_wg)
-            // the line stored in the step before has had the time of two stages: drain the stores, then (behind the barrier) count it
-            if (drains) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
           lds_barrier();
-          if (sidx == 1) {
-            const int idone = st - rlast;  // lines of row rlast that are stored and drained
-            if (drains && k == 0 && idone >= 1 && idone <= g.ni) __hip_atomic_store(my_cnt, (unsigned)idone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            fetch_next();
-          }
         }
       }
       if (prof && t == 0) {
         const long long nw = (long long)wall_clock64();
         pf_ph[1] += nw - pf_m, pf_m = nw;
+      }
+      // ---- the hand-off words of the next line: asked for as late as the step allows (the strip above stores them at the end of ITS step),
+      // checked at the top of the next step
+      {
+        const unsigned long long* src = hb_in + (size_t)((st + 1) & smask) * NT * HW;
+#pragma unroll
+        for (int w = 0; w < HW; w++) hw[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // ---- final systems (:599-616 / Cramer's rule :787-842), every entry solves for itself; relaxation (:626-633)
       REAL out[Q];
@@ -1294,6 +1321,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
           } else {
             const REAL inv_detA = cfv[0], cc1 = cfv[1], cc2 = cfv[2], cc3 = cfv[3], aa2 = cfv[4], aa3 = cfv[5], aa4 = cfv[6];
             const REAL dd1 = dc[q * LD + f1i], dd2 = dc[q * LD + f2i], dd3 = dc[q * LD + f3i], dd4 = dc[q * LD + f4i];
+            __builtin_amdgcn_sched_barrier(0);
             REAL det;
             if (rr == 0) det = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
             else if (rr == 1) det = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
@@ -1306,9 +1334,30 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
           const REAL d2 = dp * dp;
           if (on[q]) {
             acc += (double)d2;
-            if (feeds && rg * Q + q == rlast) __hip_atomic_store(X + cl[q] + k, out[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else X[cl[q] + k] = out[q];
+            X[cl[q] + k] = out[q];
             if (q == Q - 1) NLINE[(size_t)rg * NT + k] = out[q];
+            if (feeds && rg * Q + q == rlast) {
+              // hand the line down: slot i mod nslots, free once the strip below has taken line i - nslots
+              const int i = st - rlast;
+              dn_seen = max(dn_seen, dn_next);  // (fetched during the step before)
+              while (dn_seen < i - nslots + 1) {
+                dn_seen = (int)__hip_atomic_load(dn_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dn_seen < i - nslots + 1 && pipe_give_up(polls, t0, spin_limit, ctl)) {
+                  sh[2] = 1;
+                  break;
+                }
+              }
+              t0 = 0;
+              const unsigned long long tag = (unsigned long long)(seq_base + (unsigned)i + 1u) << 32;
+              unsigned long long* dstw = hb_out + (size_t)(i & smask) * NT * HW;
+              if (sizeof(REAL) == 8) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong((double)out[q]);
+                __hip_atomic_store(dstw, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dstw + (HW - 1), tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              } else {
+                __hip_atomic_store(dstw, tag | (unsigned long long)__float_as_uint((float)out[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
           }
         }
       }
@@ -1319,14 +1368,11 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
 #pragma unroll
       for (int q = 0; q < Q; q++)
         if (act[q]) xim[q] = out[q], pp[q] = xip[q], xip[q] = n_xip[q], xjp[q] = n_xjp[q], rh[q] = n_rh[q], mk[q] = n_mk[q], klo[q] = n_klo[q], khi[q] = n_khi[q];
-      nxjm = n_xjm;
-      if (t == 0 && from_mem) sh[1] = max(seen_now, (int)cnt_async);
+      if (t == 0 && from_mem && st < g.ni) __hip_atomic_store(my_prog, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // line st is taken
       lds_barrier();
       if (prof && t == 0) pf_ph[3] += (long long)wall_clock64() - pf_m;
     }
-    if (drains) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (drains && k == 0 && !dead) __hip_atomic_store(my_cnt, (unsigned)g.ni, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double sblk = block_sum_rt(acc, wsum, nwaves);
     if (t == 0) __hip_atomic_store(&partials[strip], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prof && t == 0) {

@@ -195,6 +195,8 @@ void czhip_finalize(void) {
   if (ctx.pcr_tab_perm) (void)hipFree(ctx.pcr_tab_perm);
   if (ctx.pipe_ctl) (void)hipFree(ctx.pipe_ctl);
   ctx.pipe_ctl = nullptr, ctx.pipe_ctl_cap = 0;
+  if (ctx.pipe_hb) (void)hipFree(ctx.pipe_hb);
+  ctx.pipe_hb = nullptr, ctx.pipe_hb_cap = 0, ctx.pipe_seq = 0;
   (void)hipFree(ctx.scal_dev);
   (void)hipHostFree(ctx.scal_host);
   if (ctx.counter) (void)hipFree(ctx.counter);
