@@ -1117,6 +1117,10 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   const int f4i = (kb + 3 * sfin <= n - 1) ? kb + 1 + 3 * sfin : n + 1;
   for (int e = t; e < 2 * RS * LD; e += NT * R) D[e] = (REAL)0;
   if (t == 0) sh[2] = 0;
+  __syncthreads();
+  REAL cfv[FINAL4 ? 7 : 3];  // this entry's coefficients of the final system: the same for every line, kept in registers
+#pragma unroll
+  for (int v = 0; v < (FINAL4 ? 7 : 3); v++) cfv[v] = Tk[(size_t)(3 * nstage + v) * NT];
 
   const REAL r = (REAL)1.0 / (REAL)6.0;
   const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
@@ -1307,10 +1311,6 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       REAL out[Q];
       {
         const REAL* dc = D + (size_t)((nstage & 1) * RS + rg * Q) * LD;  // (pointer arithmetic, not a select of two pointers: the address space must stay LDS)
-        const REAL* cf = Tk + (size_t)3 * nstage * NT;
-        REAL cfv[FINAL4 ? 7 : 3];
-#pragma unroll
-        for (int v = 0; v < (FINAL4 ? 7 : 3); v++) cfv[v] = cf[(size_t)v * NT];
 #pragma unroll
         for (int q = 0; q < Q; q++) {
           REAL sol;

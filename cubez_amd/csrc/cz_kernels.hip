@@ -487,6 +487,14 @@ int czhip_set_pcr_lex(int one_launch, int groups, int rows_per_thread) {
   return 0;
 }
 
+// bound of every wait inside pcr_lex_wg_k, in seconds (default 2; negative: keep).  Returns the bound in force.  When a wait runs out the
+// sweep's residual is NaN: a lost hand-off must not pass for a result.  (0 makes every wait longer than a few hundred polls give up: test aid.)
+double czhip_set_pcr_lex_timeout(double seconds) {
+  ensure_init();
+  if (seconds >= 0.0) ctx.tune.pipe_spin_ticks = (long long)(seconds * 1e8);
+  return (double)ctx.tune.pipe_spin_ticks * 1e-8;
+}
+
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev) {
   ensure_init();

@@ -244,6 +244,9 @@ int czhip_set_pcr_mode(int form, int variant);
  * sweep in one launch, rows of lines handed from workgroup to workgroup (default), 0 = one launch per diagonal i+j; groups of threads per
  * workgroup (0 = chosen per launch); rows per thread (1 | 2).  Negative = keep.  Every shape gives the same bits. */
 int czhip_set_pcr_lex(int one_launch, int groups, int rows_per_thread);
+/* Bound, in seconds, of every wait of one workgroup for another inside the one-launch sweep (default 2; negative = keep); returns the bound in
+ * force.  If a wait runs out, every workgroup leaves and the residual of that sweep is NaN. */
+double czhip_set_pcr_lex_timeout(double seconds);
 int czhip_use_t2(void);
 /* self-test: numerators (of 2^32) whose quotient by d in the two-stage pass differs from the IEEE division (expected 0); -1 = divisor not eligible */
 long long czhip_selftest_fastdiv(CZ_REAL d);

@@ -645,6 +645,45 @@ def test_lexicographic_line_sor_every_launch_shape_vs_oracle(prec, lex, box):
         h.lib.czhip_set_pcr_lex(1, 0, 1)
 
 
+def test_lexicographic_line_sor_gives_up_instead_of_hanging():
+    """Every wait of a workgroup for the row above is bounded: with the bound at zero the rows far from the top give up long before their
+    first line can arrive, every workgroup leaves, the call returns and the residual is NaN -- and the next sweep, with the normal bound,
+    is right again (bit for bit the launch-per-diagonal result)."""
+    import ctypes as C
+    prec = "f32"
+    ni, nj, nk = 300, 300, 66
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(7)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    h.lib.czhip_set_pcr_lex_timeout.restype = C.c_double
+    h.lib.czhip_set_pcr_lex_timeout.argtypes = [C.c_double]
+    before = h.lib.czhip_set_pcr_lex_timeout(-1.0)
+    assert before > 0.1
+    try:
+        assert h.lib.czhip_set_pcr_lex(1, 0, 1) == 0
+        h.lib.czhip_set_pcr_lex_timeout(0.0)
+        r = h.pcr(sz, idx, pn, h.alloc(sz, x0), dm, dr, 1.3)
+        assert r != r, r  # NaN: the sweep is void
+        h.lib.czhip_set_pcr_lex_timeout(before)
+        dx = h.alloc(sz, x0)
+        r2 = h.pcr(sz, idx, pn, dx, dm, dr, 1.3)
+        h.lib.czhip_set_pcr_lex(0, 0, 1)
+        dy = h.alloc(sz, x0)
+        r3 = h.pcr(sz, idx, pn, dy, dm, dr, 1.3)
+        assert r2 == r2 and _beq(dx.get(), dy.get())
+        assert _rel(r2, r3) < 1e-12
+    finally:
+        h.lib.czhip_set_pcr_lex_timeout(before)
+        h.lib.czhip_set_pcr_lex(1, 0, 1)
+
+
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("nk", [3, 4, 5, 6, 7, 10])
 def test_line_sor_short_lines(prec, nk):
