@@ -148,20 +148,21 @@ bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Pc
 
 // pcr / pcr_esa in one launch per sweep (pcr_lex_wg_k): NT threads per line, R groups of them per workgroup, Q rows per thread.
 // CZHIP_PCR_PIPE=0 turns it off (one launch per diagonal instead).
-template <int FINAL4, int NT, int Q>
-bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate, int nstage, int nfin) {
+template <int FINAL4, int NT, int Q, int MAF = 0>
+bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate, int nstage, int nfin,
+                         const MafArgs& ma = MafArgs()) {
   // measured at 512^3 FP32 (profiles/r02/pcr_lex_*): a stage costs in proportion to the waves behind its barrier, so one group of NT
   // threads per workgroup unless the lines are short
   int R = std::max(1, std::min(512 / NT, (g.nj + Q - 1) / Q));
   if (ctx.tune.pcr_rows > 0) R = std::max(1, std::min(1024 / NT, ctx.tune.pcr_rows));
   const int RS = R * Q;
   const int nstrips = (g.nj + RS - 1) / RS;
-  const int ntab = 3 * nstage + (FINAL4 ? 7 : 3);
-  const size_t lds = ((size_t)2 * RS * (NT + 2) + (size_t)R * NT + (size_t)ntab * NT) * sizeof(REAL) + 8 * sizeof(int) + 16 + 20 * sizeof(double);
+  const int ntab = MAF ? 0 : 3 * nstage + (FINAL4 ? 7 : 3);
+  const size_t lds = ((size_t)(MAF ? 6 : 2) * RS * (NT + 2) + (size_t)R * NT + (size_t)ntab * NT) * sizeof(REAL) + 8 * sizeof(int) + 16 + 20 * sizeof(double);
   if (lds > 160 * 1024) return false;  // (the coefficients of every entry sit in LDS)
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_lex_wg_k<FINAL4, NT, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_lex_wg_k<FINAL4, NT, Q, MAF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const size_t ctl_words = (size_t)kPipeCtlStride * (nstrips + 2);
@@ -212,8 +213,8 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
     HIP_CHECK(hipMalloc(&prof, (size_t)8 * nstrips * sizeof(long long)));
     HIP_CHECK(hipMemsetAsync(prof, 0, (size_t)8 * nstrips * sizeof(long long), ctx.stream));
   }
-  hipLaunchKernelGGL((pcr_lex_wg_k<FINAL4, NT, Q>), dim3(nblk), dim3(NT * R), lds, ctx.stream, x, msk, rhs, g, omg, ctx.pcr_tab, nfin, R, ctx.pipe_ctl,
-                     ctx.pipe_hb, nslots, seq_base, nstrips, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, prof);
+  hipLaunchKernelGGL((pcr_lex_wg_k<FINAL4, NT, Q, MAF>), dim3(nblk), dim3(NT * R), lds, ctx.stream, x, msk, rhs, g, omg, ctx.pcr_tab, nfin, R, ctx.pipe_ctl,
+                     ctx.pipe_hb, nslots, seq_base, nstrips, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, prof, ma);
   HIP_CHECK(hipGetLastError());
   if (prof) {
     std::vector<long long> h((size_t)8 * nstrips);
@@ -221,7 +222,7 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
     HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
     HIP_CHECK(hipFree(prof));
     const long long t0 = h[0];
-    fprintf(stderr, "pcr_lex_wg_k<%d,%d,%d> n %d ni %d nj %d R %d, %u workgroups: strip: start first_line_ready end | waited (us) in n waits | wg\n", FINAL4, NT, Q, g.n, g.ni, g.nj, R, nblk);
+    fprintf(stderr, "pcr_lex_wg_k<%d,%d,%d%s> n %d ni %d nj %d R %d, %u workgroups: strip: start first_line_ready end | waited (us) in n waits | wg\n", FINAL4, NT, Q, MAF ? ",maf" : "", g.n, g.ni, g.nj, R, nblk);
     const int every = std::max(1, atoi(prof_env));
     for (int sidx = 0; sidx < nstrips; sidx += every) {
       const long long* q = &h[(size_t)8 * sidx];
@@ -245,6 +246,17 @@ bool try_pcr_lex_wg(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g,
   if (n <= NT_)                                                                                                                     \
     return ctx.tune.pcr_q == 1 ? try_pcr_lex_wg_inst<FINAL4, NT_, 1>(x, msk, rhs, g, omg, res_dev, accumulate, nstage, nfin)          \
                                : try_pcr_lex_wg_inst<FINAL4, NT_, 2>(x, msk, rhs, g, omg, res_dev, accumulate, nstage, nfin);
+  CZ_LEX_WG(64) CZ_LEX_WG(128) CZ_LEX_WG(256) CZ_LEX_WG(512) CZ_LEX_WG(1024)
+#undef CZ_LEX_WG
+  return false;
+}
+
+// the MAF forms of the lexicographic line SOR (pcr_maf, pcr_eda_maf, pcr_esa_maf) in one launch: a, c and d of every line reduced in LDS
+bool try_pcr_lex_wg_maf(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate, const MafArgs& ma) {
+  const int n = g.n, nstage = g.pn - 1;
+  if (ctx.tune.pcr_fast < 2 || ctx.tune.pcr_pipe == 0 || n > 1024 || nstage < 2 || nstage > 10) return false;
+#define CZ_LEX_WG(NT_) \
+  if (n <= NT_) return try_pcr_lex_wg_inst<0, NT_, 1, 1>(x, msk, rhs, g, omg, res_dev, accumulate, nstage, 0, ma);
   CZ_LEX_WG(64) CZ_LEX_WG(128) CZ_LEX_WG(256) CZ_LEX_WG(512) CZ_LEX_WG(1024)
 #undef CZ_LEX_WG
   return false;
@@ -405,6 +417,7 @@ void launch_pcr_maf(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, con
     return try_pcr_rb<1, 1, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma);
   };
   if (order == 1) {
+    if (try_pcr_lex_wg_maf(x, msk, rhs, make_pcr_geom(b, idx, pn, 0), omg, res_dev, accumulate, ma)) return;
     const int ni = b.ii1 - b.ii0 + 1, nj = b.jj1 - b.jj0 + 1;
     for (int dgn = 0; dgn <= ni + nj - 2 && ok; dgn++) ok = one(make_pcr_geom(b, idx, pn, dgn), accumulate || dgn > 0);
   } else {

@@ -1074,11 +1074,14 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int FINAL4, int NT, int Q>
+template <int FINAL4, int NT, int Q, int MAF>
 __global__ void __launch_bounds__(1024)
 pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, const REAL* __restrict__ tab, int nfin,
              int R, unsigned* ctl, unsigned long long* hb, int nslots, unsigned seq_base, int nstrips, long long spin_limit, double* partials,
-             double* dst, int accumulate, unsigned* counter, long long* prof) {
+             double* dst, int accumulate, unsigned* counter, long long* prof, MafArgs ma) {
+  // MAF = 1 (pcr_maf, pcr_eda_maf, pcr_esa_maf; cz_maf.f90:442-1560): the matrix of a line comes from the metrics of the 1-D grids and differs from
+  // line to line, so a and c are reduced together with d (three LDS rows each way instead of one, no table; pcr_rb_k<MAF>'s arithmetic) and the
+  // final systems are the 2x2 ones (FINAL4 = 0).
   // NT threads per line (one entry each), R groups of NT threads, Q rows per group (a thread holds the same entry of Q consecutive rows:
   // one barrier per stage serves Q line solves, the coefficients are read once for all of them, and row q+1 takes (i,j-1) from the
   // registers of row q).  A strip = R*Q consecutive rows, row rs one line behind row rs-1.
@@ -1089,10 +1092,12 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   const int k = t - rg * NT;
   const int n = g.n, LD = NT + 2, x = k + 1, RS = R * Q;
   REAL* D = reinterpret_cast<REAL*>(smem);          // [2][RS][LD]: slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
-  REAL* NLINE = D + (size_t)2 * RS * LD;            // [R][NT]: the line the last row of each group has just finished, for the group below
+  REAL* AA = D + (size_t)2 * RS * LD;               // MAF: the sub- and super-diagonal of every line, laid out like D
+  REAL* CC = AA + (MAF ? (size_t)2 * RS * LD : 0);
+  REAL* NLINE = CC + (MAF ? (size_t)2 * RS * LD : 0);  // [R][NT]: the line the last row of each group has just finished, for the group below
   REAL* TAB = NLINE + (size_t)R * NT;               // [3*nstage + NF][NT]: this entry's e | ap | cp of every stage, then the final system's coefficients
   const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
-  const int ntab = 3 * nstage + (FINAL4 ? 7 : 3);
+  const int ntab = MAF ? 0 : 3 * nstage + (FINAL4 ? 7 : 3);
   int* sh = reinterpret_cast<int*>(TAB + (size_t)ntab * NT);  // [0] strip, [2] a wait was given up
   double* wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(sh + 8) + 15) & ~(size_t)15);
   const int nwaves = (NT * R) >> 6;
@@ -1101,7 +1106,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   // ---- the coefficients (pcr_coef_k's table, natural order) into LDS, entry k of every row at [row][k]; zero where the reference has no entry
   const int sfin = 1 << nstage;
   const int kb = k & (sfin - 1), rr = k >> nstage;  // base entry and position in the final 2x2 / 4x4 system
-  for (int row = rg; row < ntab; row += R) {
+  for (int row = rg; row < ntab; row += R) {  // (MAF: no table)
     REAL v = (REAL)0;
     if (row < 3 * nstage) {
       if (kin) v = tab[(size_t)row * n + k];
@@ -1115,12 +1120,23 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   const int f2i = (kb + sfin <= n - 1) ? kb + 1 + sfin : n + 1;
   const int f3i = (kb + 2 * sfin <= n - 1) ? kb + 1 + 2 * sfin : n + 1;
   const int f4i = (kb + 3 * sfin <= n - 1) ? kb + 1 + 3 * sfin : n + 1;
-  for (int e = t; e < 2 * RS * LD; e += NT * R) D[e] = (REAL)0;
+  for (int e = t; e < (MAF ? 6 : 2) * RS * LD; e += NT * R) D[e] = (REAL)0;  // (AA and CC follow D)
   if (t == 0) sh[2] = 0;
   __syncthreads();
   REAL cfv[FINAL4 ? 7 : 3];  // this entry's coefficients of the final system: the same for every line, kept in registers
 #pragma unroll
-  for (int v = 0; v < (FINAL4 ? 7 : 3); v++) cfv[v] = Tk[(size_t)(3 * nstage + v) * NT];
+  for (int v = 0; v < (FINAL4 ? 7 : 3); v++) cfv[v] = MAF ? (REAL)0 : Tk[(size_t)(3 * nstage + v) * NT];
+  // MAF: what depends on k only (cz_maf.f90:497-512; padded index == index into zc for g = 2, see MafArgs)
+  REAL mz_f3 = 0, mz_lo = 0, mz_hi = 0;  // TZ^2, aw - cw/2, aw + cw/2
+  if (MAF) {
+    const int kk = g.kk0 + min(k, n - 1);
+    const REAL f1 = ma.zc[kk + 1], f2 = ma.zc[kk - 1];
+    const REAL TZ = (REAL)2.0 / (f1 - f2);
+    const REAL ZTT = f1 - (REAL)2.0 * ma.zc[kk] + f2;
+    mz_f3 = TZ * TZ;
+    const REAL cw = -ZTT * mz_f3 * TZ;
+    mz_lo = mz_f3 - (REAL)0.5 * cw, mz_hi = mz_f3 + (REAL)0.5 * cw;
+  }
 
   const REAL r = (REAL)1.0 / (REAL)6.0;
   const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
@@ -1168,6 +1184,18 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
     unsigned long long hw[HW];  // row 0 below another strip: the hand-off words of the coming line, fetched a step ahead
 #pragma unroll
     for (int w = 0; w < HW; w++) hw[w] = 0ull;
+    REAL my_C2[Q], my_cc1[Q], my_cc2[Q];  // MAF: what depends on j only (:489-496)
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      my_C2[q] = my_cc1[q] = my_cc2[q] = (REAL)0;
+      if (MAF) {
+        const int jj = g.jj0 + strip * RS + min(rg * Q + q, rlast);
+        const REAL EY = (REAL)2.0 / (ma.yc[jj + 1] - ma.yc[jj - 1]);
+        const REAL C2 = EY * EY;
+        const REAL C8 = -(ma.yc[jj + 1] - (REAL)2.0 * ma.yc[jj] + ma.yc[jj - 1]) * C2 * EY;
+        my_C2[q] = C2, my_cc1[q] = C2 + (REAL)0.5 * C8, my_cc2[q] = C2 - (REAL)0.5 * C8;
+      }
+    }
     if (rg == 0) {
       if (from_mem) {
 #pragma unroll
@@ -1244,10 +1272,28 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
         } else {
           xjm = NLINE[(size_t)(rg - 1) * NT + kc];
         }
-        REAL dv = ((xjm + xjp[q] + xim[q] + xip[q] - rh[q]) * r) * mk[q];
-        if (edge_lo) dv = (dv + klo[q] * r) * mk[q];
-        if (edge_hi) dv = (dv + khi[q] * r) * mk[q];
-        if (on[q]) D[(size_t)(rg * Q + q) * LD + x] = dv;
+        if (!MAF) {
+          REAL dv = ((xjm + xjp[q] + xim[q] + xip[q] - rh[q]) * r) * mk[q];
+          if (edge_lo) dv = (dv + klo[q] * r) * mk[q];
+          if (edge_hi) dv = (dv + khi[q] * r) * mk[q];
+          if (on[q]) D[(size_t)(rg * Q + q) * LD + x] = dv;
+        } else {  // cz_maf.f90:489-546: the metrics of this line's i, then coefficients and source term of entry k
+          const int ii = g.ii0 + min(max(st - (rg * Q + q), 0), g.ni - 1);
+          const REAL GX = (REAL)2.0 / (ma.xc[ii + 1] - ma.xc[ii - 1]);
+          const REAL C1 = GX * GX;
+          const REAL C7 = -(ma.xc[ii + 1] - (REAL)2.0 * ma.xc[ii] + ma.xc[ii - 1]) * C1 * GX;
+          const REAL dd1 = C1 + (REAL)0.5 * C7, dd2 = C1 - (REAL)0.5 * C7;
+          const REAL dw = (REAL)0.5 / (C1 + my_C2[q] + mz_f3);
+          const REAL av = (edge_lo && n > 1) ? (REAL)0 : -mz_lo * dw;  // (n = 1: :527 overwrites :513)
+          const REAL cv = edge_hi ? (REAL)0 : -mz_hi * dw;
+          REAL dv = (dd1 * xip[q] + dd2 * xim[q] + my_cc1[q] * xjp[q] + my_cc2[q] * xjm - rh[q]) * dw * mk[q];
+          if (edge_lo) dv = (dv + mz_lo * dw * klo[q]) * mk[q];
+          if (edge_hi) dv = (dv + mz_hi * dw * khi[q]) * mk[q];
+          if (on[q]) {
+            const size_t o = (size_t)(rg * Q + q) * LD + x;
+            AA[o] = av, CC[o] = cv, D[o] = dv;
+          }
+        }
       }
       // ---- operands of the next lines, most of a step ahead of their use: fetched behind the second stage (behind the drain of the
       // row that feeds the next strip), consumed at the end of the step
@@ -1277,7 +1323,29 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       for (int sidx = 0; sidx < MAXST; sidx++) {
         if (sidx < nstage) {
           const int s = 1 << sidx;
-          {  // all LDS reads in flight at once (this entry's coefficients of the stage and three right-hand sides per row), one wait
+          if (MAF) {  // a, c and d of every line reduced together (cz_maf.f90:551-574)
+            const size_t oc = (size_t)((sidx & 1) * RS + rg * Q) * LD, on_ = (size_t)(((sidx & 1) ^ 1) * RS + rg * Q) * LD;
+            const int kl = (k - s >= 0) ? x - s : 0;
+            const int kr = (k + s <= n - 1) ? x + s : n + 1;
+            REAL ap[Q], cp[Q], d0[Q], al[Q], cl[Q], dl[Q], ar[Q], cr[Q], dr[Q];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+              const size_t o = oc + (size_t)q * LD;
+              ap[q] = AA[o + x], cp[q] = CC[o + x], d0[q] = D[o + x];
+              al[q] = AA[o + kl], cl[q] = CC[o + kl], dl[q] = D[o + kl];
+              ar[q] = AA[o + kr], cr[q] = CC[o + kr], dr[q] = D[o + kr];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+              const REAL e = (REAL)1.0 / ((REAL)1.0 - ap[q] * cl[q] - cp[q] * ar[q]);
+              const REAL na = -e * ap[q] * al[q], nc = -e * cp[q] * cr[q], nd = e * (d0[q] - ap[q] * dl[q] - cp[q] * dr[q]);
+              if (on[q]) {
+                const size_t o = on_ + (size_t)q * LD + x;
+                AA[o] = na, CC[o] = nc, D[o] = nd;
+              }
+            }
+          } else {  // all LDS reads in flight at once (this entry's coefficients of the stage and three right-hand sides per row), one wait
             const REAL* dc = D + (size_t)((sidx & 1) * RS + rg * Q) * LD;
             REAL* dn = D + (size_t)(((sidx & 1) ^ 1) * RS + rg * Q) * LD;
             const int kl = (k - s >= 0) ? x - s : 0;
@@ -1314,7 +1382,12 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
 #pragma unroll
         for (int q = 0; q < Q; q++) {
           REAL sol;
-          if (!FINAL4) {
+          if (MAF) {  // 2x2 systems with the line's own coefficients (cz_maf.f90:578-596)
+            const size_t o = (size_t)((nstage & 1) * RS + rg * Q + q) * LD;
+            const REAL cc1 = CC[o + f1i], aa2 = AA[o + f2i], f1 = D[o + f1i], f2 = D[o + f2i];
+            const REAL jj2 = (REAL)1.0 / ((REAL)1.0 - aa2 * cc1);
+            sol = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;
+          } else if (!FINAL4) {
             const REAL jj2 = cfv[0], cc1 = cfv[1], aa2 = cfv[2];
             const REAL f1 = dc[q * LD + f1i], f2 = dc[q * LD + f2i];
             sol = rr == 0 ? (f1 - cc1 * f2) * jj2 : (f2 - aa2 * f1) * jj2;

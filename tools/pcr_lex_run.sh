@@ -16,6 +16,12 @@ mkdir -p $O
       done
     done
   done
+  for s in pcr_maf pcr_eda_maf; do
+    for pipe in 1 0; do
+      echo "# CZHIP_PCR_PIPE=$pipe --solver $s --prec f32"
+      CZHIP_PCR_PIPE=$pipe timeout -k 10 300 python3 bench.py --solver $s --steps 4 --warmup 1 --repeats 3 --no-cpu-baseline 2>/dev/null || exit 1
+    done
+  done
 } > $O/bench_pcr_lex_512_on_off.jsonl || { tail -3 $O/bench_pcr_lex_512_on_off.jsonl; exit 1; }
 {
   for cfg in 0,1 2,1 0,2; do
