@@ -771,6 +771,39 @@ def test_pcr_maf_variants_random_boxes_vs_oracle(prec, box):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("lex", [(0, 0, 1), (1, 0, 1), (1, 2, 1)], ids=lambda t: "diagonals" if not t[0] else f"one_launch_g{t[1]}")
+@pytest.mark.parametrize("box", [(9, 8, 32), (20, 13, 70), (33, 37, 20), (5, 4, 512)], ids=lambda b: "x".join(map(str, b)))
+def test_lexicographic_maf_line_sor_every_launch_shape_vs_oracle(prec, lex, box):
+    """pcr_maf / pcr_eda_maf / pcr_esa_maf (cz_maf.f90:1036-1560, lexicographic order) on stretched grids == the oracle bit for bit, with a
+    launch per diagonal and with the whole sweep in one launch (pcr_lex_wg_k<MAF=1>: a, c and d of every line reduced together in LDS)."""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    xc, yc, zc = (np.cumsum(rng.uniform(0.5, 1.5, n + 4)).astype(R) for n in (ni, nj, nk))
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    assert h.lib.czhip_set_pcr_lex(*lex) == 0
+    try:
+        for name in ("pcr_maf", "pcr_eda_maf", "pcr_esa_maf"):
+            x1, dx = x0.copy(), h.alloc(sz, x0)
+            for it in range(3):
+                w = np.zeros(1)
+                ko.pcr_maf(name, sz, idx, pn, 0, x1.copy(), msk, rhs, xc, yc, zc, 1.3, wide=w)
+                ko.pcr_maf(name, sz, idx, pn, 0, x1, msk, rhs, xc, yc, zc, 1.3)
+                r2 = h.pcr_maf(name, sz, idx, pn, 0, dx, dm, dr, xc, yc, zc, 1.3)
+                assert _beq(dx.get(), x1), (name, it)
+                assert r2 == r2 and _rel(r2, float(w[0])) < 1e-11, (name, r2, w)
+    finally:
+        h.lib.czhip_set_pcr_lex(1, 0, 1)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
 def test_hoisted_division_is_the_ieee_division(prec):
     """The two-stage pass divides by the diagonal coefficient with the divisor's share of the IEEE expansion done once per thread
     (cz_k_fastdiv.h).  Every one of the 2^32 float numerators (a structured sample of 2^32 doubles: all sign/exponent patterns x 2^20
