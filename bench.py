@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL; must be set before HIP starts
 
 SOLVERS = ["jacobi", "sor2sma", "pbicgstab", "pcr_rb", "psor", "pcr", "pcr_eda", "pcr_esa", "pcr_rb_esa", "pcr_j_esa", "jacobi_maf", "sor2sma_maf",
-           "psor_maf", "pcr_rb_maf", "pcr_maf"]
+           "psor_maf", "pcr_rb_maf", "pcr_maf", "pcr_eda_maf", "pcr_esa_maf", "pcr_rb_esa_maf"]
 ap = argparse.ArgumentParser()
 ap.add_argument("--gpus", type=int, default=1)
 ap.add_argument("--steps", type=int, default=100)
@@ -238,7 +238,10 @@ if rank == 0:
         # pcr_rb / pcr_rb_esa: two colour launches per iteration, pcr / pcr_esa: one launch per (i+j) diagonal, pcr_j_esa: one
         per_iter = {"pcr_rb": 2, "pcr_rb_esa": 2, "pcr_rb_maf": 2, "pcr_j_esa": 1}.get(args.solver, nk // max(timed_steps, 1))
         alg_bytes_per_launch = my_points * word * 5 // max(per_iter, 1)
-        kernel_name, tkey = f"pcr_rb2_k ({per_iter} launches of k-line solves per iteration)", f"{args.solver}_{n}_{args.prec}"
+        lex = args.solver in ("pcr", "pcr_esa", "pcr_eda", "pcr_maf", "pcr_esa_maf", "pcr_eda_maf")
+        kernel_name = ("pcr_lex_wg_k (the lexicographic sweep in one launch: rows of k-lines handed from workgroup to workgroup)" if lex and per_iter == 1
+                       else f"line-SOR kernels ({per_iter} launches of k-line solves per iteration)")
+        tkey = f"{args.solver}_{n}_{args.prec}"
     if args.solver.startswith("psor"):
         # one sweep (all tile-hyperplane launches together): p read and written in place, b read: 3 words per point
         alg_bytes_per_launch = my_points * word * 3

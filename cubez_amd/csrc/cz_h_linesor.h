@@ -153,8 +153,10 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
                          const MafArgs& ma = MafArgs()) {
   // measured at 512^3 FP32 (profiles/r02/pcr_lex_*): a stage costs in proportion to the waves behind its barrier, so one group of NT
   // threads per workgroup unless the lines are short
+  constexpr int kMaxT = lex_max_threads(MAF);
+  if (NT > kMaxT) return false;
   int R = std::max(1, std::min(512 / NT, (g.nj + Q - 1) / Q));
-  if (ctx.tune.pcr_rows > 0) R = std::max(1, std::min(1024 / NT, ctx.tune.pcr_rows));
+  if (ctx.tune.pcr_rows > 0) R = std::max(1, std::min(kMaxT / NT, ctx.tune.pcr_rows));
   const int RS = R * Q;
   const int nstrips = (g.nj + RS - 1) / RS;
   const int ntab = MAF ? 0 : 3 * nstage + (FINAL4 ? 7 : 3);
@@ -177,16 +179,17 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
   ensure_partials((size_t)nstrips);
   // Workgroups: as many as fit the chip at once (measured at 512^3: one per CU steps no faster than two, and the strips beyond the
   // resident window then wait for a workgroup: 4.21 against 4.08 ms); CZHIP_PCR_WG_PER_CU overrides.
-  const int fit = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)2048 / ((size_t)NT * R)));
+  const int fit = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(kMaxT == 512 ? 512 : 1024) / ((size_t)NT * R)));  // (128 registers per thread: 1 024 threads per CU; 256: 512)
   static const int per_cu_env = getenv("CZHIP_PCR_WG_PER_CU") ? atoi(getenv("CZHIP_PCR_WG_PER_CU")) : 0;
   const int per_cu = per_cu_env > 0 ? std::min(per_cu_env, fit) : fit;
   const unsigned nblk = (unsigned)std::min(nstrips, ctx.num_cu * per_cu);
   // Hand-off buffer: per strip `nslots` lines of {sequence number | value} words.  A strip may run at most nslots lines ahead of the strip
-  // below; with nblk workgroups resident the strip at the head of the resident window can then reach line nblk x nslots, which must cover
-  // its whole row so that it ends and frees a workgroup for the first strip that is not resident yet.
+  // below; with W workgroups resident the strip at the head of the resident window can then reach line W x nslots, which must cover its
+  // whole row so that it ends and frees a workgroup for the first strip that is not resident yet (W >= one per CU, whatever the registers).
   static const int slots_env = getenv("CZHIP_PCR_SLOTS") ? atoi(getenv("CZHIP_PCR_SLOTS")) : 0;
   int nslots = slots_env > 0 ? slots_env : 8;  // (what a strip knows of the progress of the strip below is a step or two old: 4 slots make it wait in most steps)
-  while (nslots < (g.ni + (int)nblk - 1) / (int)nblk + 2) nslots *= 2;
+  const int sure = std::min((int)nblk, ctx.num_cu);  // workgroups that are resident whatever the register count: one per CU
+  while (nslots < (g.ni + sure - 1) / sure + 2) nslots *= 2;
   constexpr size_t HW = sizeof(REAL) == 8 ? 2 : 1;
   const size_t hb_words = (size_t)nstrips * nslots * NT * HW;
   if (hb_words > ctx.pipe_hb_cap) {

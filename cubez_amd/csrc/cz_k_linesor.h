@@ -1074,8 +1074,13 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// (FP64 keeps twice the registers per value: its workgroups are bounded at 512 threads so that the compiler may use 256 registers per thread --
+// with 1 024 it spilled 104 bytes per thread and every reload drained the fetches in flight: 21 400 instead of 26 800 MLUPS)
+// (the MAF form spilled 132 bytes in FP32 as well: same bound)
+constexpr int lex_max_threads(int maf) { return (sizeof(REAL) == 8 || maf) ? 512 : 1024; }
+
 template <int FINAL4, int NT, int Q, int MAF>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(lex_max_threads(MAF))
 pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, const REAL* __restrict__ tab, int nfin,
              int R, unsigned* ctl, unsigned long long* hb, int nslots, unsigned seq_base, int nstrips, long long spin_limit, double* partials,
              double* dst, int accumulate, unsigned* counter, long long* prof, MafArgs ma) {
