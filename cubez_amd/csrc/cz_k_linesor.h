@@ -1025,7 +1025,9 @@ pcr_line_reg_maf_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict
 //                     an agent-scope load -- asked for late in the step before -- and takes the value once the word carries the number it
 //                     expects, reading again until it does.  A 64-bit store is single-copy atomic, so value and number arrive together:
 //                     no drain of the stores, no separate flag, no barrier, one memory round trip.  Sequence numbers grow from sweep to
-//                     sweep (`seq_base`), so a stale word never matches.  The strip below publishes the number of lines it has taken
+//                     sweep (`seq_base`), so a stale word never matches.  (The old line (i,j+1) that row j reads with an ordinary load is
+//                     overwritten by row j+1 only after row j+1 has received the word of (i,j), and that word holds a value computed FROM
+//                     the loaded entry -- the load has returned before the word is stored, so the later store cannot reach it.)  The strip below publishes the number of lines it has taken
 //                     (`ctl`, one store per step); the strip above reads that a step ahead and does not overwrite a slot that is not free.
 //                     Measured at 512^3 FP32 (profiles/r02/pcr_lex_*): a step takes 2.1 us (8 stages x 0.13 us + source term and fetches
 //                     0.44 + final systems and relaxation 0.40 + rotation 0.2), a strip starts 2.6-2.8 us behind the one above; the sweep is
