@@ -160,7 +160,7 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
   const int RS = R * Q;
   const int nstrips = (g.nj + RS - 1) / RS;
   const int ntab = MAF ? 0 : 3 * nstage + (FINAL4 ? 7 : 3);
-  const size_t lds = ((size_t)(MAF ? 6 : 2) * RS * (NT + 2) + (size_t)R * NT + (size_t)ntab * NT) * sizeof(REAL) + 8 * sizeof(int) + 16 + 20 * sizeof(double);
+  const size_t lds = ((size_t)(MAF ? 9 : 3) * RS * (NT + 2) + (size_t)R * NT + (size_t)ntab * NT) * sizeof(REAL) + 8 * sizeof(int) + 16 + 20 * sizeof(double);
   if (lds > 160 * 1024) return false;  // (the coefficients of every entry sit in LDS)
   static bool attr_set = false;
   if (!attr_set) {

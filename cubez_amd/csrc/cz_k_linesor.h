@@ -1098,10 +1098,13 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   const int rg = __builtin_amdgcn_readfirstlane(t / NT);  // NT is a multiple of 64: a wave belongs to one group (uniform: row addresses stay scalar)
   const int k = t - rg * NT;
   const int n = g.n, LD = NT + 2, x = k + 1, RS = R * Q;
-  REAL* D = reinterpret_cast<REAL*>(smem);          // [2][RS][LD]: slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
-  REAL* AA = D + (size_t)2 * RS * LD;               // MAF: the sub- and super-diagonal of every line, laid out like D
-  REAL* CC = AA + (MAF ? (size_t)2 * RS * LD : 0);
-  REAL* NLINE = CC + (MAF ? (size_t)2 * RS * LD : 0);  // [R][NT]: the line the last row of each group has just finished, for the group below
+  // [3][RS][LD]: buffers 0 and 1 ping-pong through the stages, buffer 2 takes the source term -- the first stage reads it -- so that a thread
+  // may start the next line while others still read the final systems of this one (no barrier at the end of a step when R == 1);
+  // slot 0 and slot n+1 of every row are the zero entries k = kst-1 / ked+1
+  REAL* D = reinterpret_cast<REAL*>(smem);
+  REAL* AA = D + (size_t)3 * RS * LD;               // MAF: the sub- and super-diagonal of every line, laid out like D
+  REAL* CC = AA + (MAF ? (size_t)3 * RS * LD : 0);
+  REAL* NLINE = CC + (MAF ? (size_t)3 * RS * LD : 0);  // [R][NT]: the line the last row of each group has just finished, for the group below
   REAL* TAB = NLINE + (size_t)R * NT;               // [3*nstage + NF][NT]: this entry's e | ap | cp of every stage, then the final system's coefficients
   const int nstage = FINAL4 ? g.pn - 2 : g.pn - 1;
   const int ntab = MAF ? 0 : 3 * nstage + (FINAL4 ? 7 : 3);
@@ -1127,7 +1130,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
   const int f2i = (kb + sfin <= n - 1) ? kb + 1 + sfin : n + 1;
   const int f3i = (kb + 2 * sfin <= n - 1) ? kb + 1 + 2 * sfin : n + 1;
   const int f4i = (kb + 3 * sfin <= n - 1) ? kb + 1 + 3 * sfin : n + 1;
-  for (int e = t; e < (MAF ? 6 : 2) * RS * LD; e += NT * R) D[e] = (REAL)0;  // (AA and CC follow D)
+  for (int e = t; e < (MAF ? 9 : 3) * RS * LD; e += NT * R) D[e] = (REAL)0;  // (AA and CC follow D)
   if (t == 0) sh[2] = 0;
   __syncthreads();
   REAL cfv[FINAL4 ? 7 : 3];  // this entry's coefficients of the final system: the same for every line, kept in registers
@@ -1283,7 +1286,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
           REAL dv = ((xjm + xjp[q] + xim[q] + xip[q] - rh[q]) * r) * mk[q];
           if (edge_lo) dv = (dv + klo[q] * r) * mk[q];
           if (edge_hi) dv = (dv + khi[q] * r) * mk[q];
-          if (on[q]) D[(size_t)(rg * Q + q) * LD + x] = dv;
+          if (on[q]) D[(size_t)(2 * RS + rg * Q + q) * LD + x] = dv;
         } else {  // cz_maf.f90:489-546: the metrics of this line's i, then coefficients and source term of entry k
           const int ii = g.ii0 + min(max(st - (rg * Q + q), 0), g.ni - 1);
           const REAL GX = (REAL)2.0 / (ma.xc[ii + 1] - ma.xc[ii - 1]);
@@ -1297,7 +1300,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
           if (edge_lo) dv = (dv + mz_lo * dw * klo[q]) * mk[q];
           if (edge_hi) dv = (dv + mz_hi * dw * khi[q]) * mk[q];
           if (on[q]) {
-            const size_t o = (size_t)(rg * Q + q) * LD + x;
+            const size_t o = (size_t)(2 * RS + rg * Q + q) * LD + x;
             AA[o] = av, CC[o] = cv, D[o] = dv;
           }
         }
@@ -1320,7 +1323,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       };
       fetch_next();
       lds_barrier();
-      if (sh[2]) break;  // a wait was given up (by a thread of this workgroup, before the barrier)
+      int gave_up = 0;
       if (prof && t == 0) {
         const long long nw = (long long)wall_clock64();
         pf_ph[0] += nw - pf_m, pf_m = nw;
@@ -1331,7 +1334,8 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
         if (sidx < nstage) {
           const int s = 1 << sidx;
           if (MAF) {  // a, c and d of every line reduced together (cz_maf.f90:551-574)
-            const size_t oc = (size_t)((sidx & 1) * RS + rg * Q) * LD, on_ = (size_t)(((sidx & 1) ^ 1) * RS + rg * Q) * LD;
+            const size_t oc = (size_t)((sidx == 0 ? 2 : (sidx & 1)) * RS + rg * Q) * LD, on_ = (size_t)(((sidx & 1) ^ 1) * RS + rg * Q) * LD;
+            if (sidx == 0) gave_up = sh[2];  // (read with the operands of the first stage: nobody writes it between the two barriers around)
             const int kl = (k - s >= 0) ? x - s : 0;
             const int kr = (k + s <= n - 1) ? x + s : n + 1;
             REAL ap[Q], cp[Q], d0[Q], al[Q], cl[Q], dl[Q], ar[Q], cr[Q], dr[Q];
@@ -1353,8 +1357,9 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
               }
             }
           } else {  // all LDS reads in flight at once (this entry's coefficients of the stage and three right-hand sides per row), one wait
-            const REAL* dc = D + (size_t)((sidx & 1) * RS + rg * Q) * LD;
+            const REAL* dc = D + (size_t)((sidx == 0 ? 2 : (sidx & 1)) * RS + rg * Q) * LD;
             REAL* dn = D + (size_t)(((sidx & 1) ^ 1) * RS + rg * Q) * LD;
+            if (sidx == 0) gave_up = sh[2];  // (read with the operands of the first stage: nobody writes it between the two barriers around)
             const int kl = (k - s >= 0) ? x - s : 0;
             const int kr = (k + s <= n - 1) ? x + s : n + 1;
             const REAL e = Tk[(3 * sidx) * NT], ap = Tk[(3 * sidx + 1) * NT], cp = Tk[(3 * sidx + 2) * NT];
@@ -1369,8 +1374,10 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
             }
           }
           lds_barrier();
+          if (sidx == 0 && gave_up) break;  // a wait was given up by a thread of this workgroup (every thread read the same value)
         }
       }
+      if (gave_up) break;
       if (prof && t == 0) {
         const long long nw = (long long)wall_clock64();
         pf_ph[1] += nw - pf_m, pf_m = nw;
@@ -1449,7 +1456,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       for (int q = 0; q < Q; q++)
         if (act[q]) xim[q] = out[q], pp[q] = xip[q], xip[q] = n_xip[q], xjp[q] = n_xjp[q], rh[q] = n_rh[q], mk[q] = n_mk[q], klo[q] = n_klo[q], khi[q] = n_khi[q];
       if (t == 0 && from_mem && st < g.ni) __hip_atomic_store(my_prog, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // line st is taken
-      lds_barrier();
+      if (R > 1) lds_barrier();  // (the group below reads NLINE at the top of the next step)
       if (prof && t == 0) pf_ph[3] += (long long)wall_clock64() - pf_m;
     }
     __syncthreads();
