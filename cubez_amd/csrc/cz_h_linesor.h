@@ -9,9 +9,10 @@ int num_stage(int n) {  // cz.h:293-300
   return -1;
 }
 
-template <int NW, int ORDER = 0, int MAF = 0>
+template <int NW, int ORDER = 0, int MAF = 0, int FINAL4 = 0>
 bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, double* res_dev, int accumulate, size_t lds_cap,
                 const MafArgs& ma = MafArgs()) {
+  if (FINAL4 && g.pn < 2) return false;  // (a line of one unknown has no 4x4 form)
   const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj
                                       : (long long)(std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1);
   const unsigned nblk = (unsigned)((ncol + NW - 1) / NW);
@@ -20,11 +21,11 @@ bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, 
   ensure_partials(nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW, ORDER, MAF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW, ORDER, MAF, FINAL4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   ScopedTimer tm(LBL_PCR);
-  hipLaunchKernelGGL((pcr_rb_k<NW, ORDER, MAF>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.partials, res_dev,
+  hipLaunchKernelGGL((pcr_rb_k<NW, ORDER, MAF, FINAL4>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.partials, res_dev,
                      accumulate, ctx.counter, ma);
   HIP_CHECK(hipGetLastError());
   return true;
@@ -323,10 +324,22 @@ void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, c
     if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
     return;
   }
+  // the literal per-line kernel (a, c and d of every line reduced in LDS, no table): lines too long for the table forms, or czhip_set_pcr_mode(0, .)
+  auto literal = [&](const PcrGeom& g, int acc) -> bool {
+    if (order == 2) return false;  // (pcr_j_esa reads the old field and writes another array: table forms only)
+    if (order == 0) {
+      if (final4) return try_pcr_rb<4, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) || try_pcr_rb<2, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) ||
+                         try_pcr_rb<1, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024);
+      return try_pcr_rb<4, 0, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) || try_pcr_rb<2, 0, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) ||
+             try_pcr_rb<1, 0, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024);
+    }
+    return final4 ? try_pcr_rb<1, 1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024) : try_pcr_rb<1, 1, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024);
+  };
+  const bool table_forms = ctx.tune.pcr_fast > 0 || order == 2;
   bool ok = true;
   if (order == 1) {
     const int ni = b.ii1 - b.ii0 + 1, nj = b.jj1 - b.jj0 + 1;
-    {
+    if (table_forms) {
       const PcrGeom g = make_pcr_geom(b, idx, pn, 0);
       if (ctx.tune.pcr_fast >= 2 && ctx.tune.pcr_pipe != 0 &&
           (final4 ? try_pcr_lex_wg<1>(x, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_lex_wg<0>(x, msk, rhs, g, omg, res_dev, accumulate)))
@@ -334,16 +347,21 @@ void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, c
     }
     for (int dgn = 0; dgn <= ni + nj - 2 && ok; dgn++) {
       const PcrGeom g = make_pcr_geom(b, idx, pn, dgn);
-      ok = final4 ? try_pcr_rb2<1, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0)
-                  : try_pcr_rb2<0, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0);
+      ok = table_forms && (final4 ? try_pcr_rb2<1, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0)
+                                  : try_pcr_rb2<0, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate || dgn > 0));
+      if (!ok) ok = literal(g, accumulate || dgn > 0);
     }
   } else {
     const PcrGeom g = make_pcr_geom(b, idx, pn, sel);
-    if (order == 0) ok = final4 ? try_pcr_rb2<1, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
-    else ok = final4 ? try_pcr_rb2<1, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
+    ok = false;
+    if (table_forms) {
+      if (order == 0) ok = final4 ? try_pcr_rb2<1, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 0>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
+      else ok = final4 ? try_pcr_rb2<1, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate) : try_pcr_rb2<0, 2>(x, wout, msk, rhs, g, omg, res_dev, accumulate);
+    }
+    if (!ok) ok = literal(g, accumulate);
   }
   if (!ok) {
-    fprintf(stderr, "czhip: line SOR (4x4 / ordered variants): the coefficient table of a k-line of %d unknowns does not fit the 160 KiB of LDS\n",
+    fprintf(stderr, "czhip: line SOR: a k-line of %d unknowns fits the 160 KiB of LDS in no form (coefficient table, or a, c and d of one line)\n",
             b.kk1 - b.kk0 + 1);
     exit(1);
   }

@@ -27,7 +27,7 @@ struct PcrGeom {
 // ORDER 0: one colour; ORDER 1: the columns of one diagonal (i-ist)+(j-jst) = g.color of the lexicographic order (see pcr_rb2_k).
 // MAF = 1: the matrix comes from the metrics of the 1-D grids (cz_maf.f90:442-1560: pcr_rb_maf, pcr_maf and their _eda/_esa
 // forms): it differs from line to line, so this literal form is the only one that applies.
-template <int NW, int ORDER, int MAF>
+template <int NW, int ORDER, int MAF, int FINAL4 = 0>
 __global__ void __launch_bounds__(64 * NW)
 pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, double* partials,
          double* dst, int accumulate, unsigned* counter, MafArgs ma) {
@@ -112,7 +112,7 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
   wave_lds_sync();  // a line never leaves its wave: no workgroup barrier between the stages
   // ---- PCR stages (:572-595)
   int cur = 0;
-  for (int p = 1; p <= g.pn - 1; p++) {
+  for (int p = 1; p <= (FINAL4 ? g.pn - 2 : g.pn - 1); p++) {
     const int s = 1 << (p - 1);
     if (active) {
       const REAL* a = A[cur];
@@ -135,8 +135,33 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
     wave_lds_sync();
     cur ^= 1;
   }
-  // ---- 2x2 systems of the last stage (:599-616), result into the d slot of the other buffer
-  {
+  // ---- 4x4 systems of the last stage by Cramer's rule (pcr :787-842, pcr_esa, pcr_rb_esa; the coefficients pcr_coef_k tabulates are taken
+  // from this line's own a and c: same operations, same values), result into the d slot of the other buffer
+  if (FINAL4) {
+    const int s = 1 << (g.pn - 2);
+    if (active) {
+      const REAL* a = A[cur];
+      const REAL* c = a + LD;
+      const REAL* d = c + LD;
+      REAL* d1 = A[cur ^ 1] + 2 * LD;
+      for (int k = lane; k < s && k < n; k += 64) {
+        const int x = k + 1;
+        const int kl = (k + s <= n - 1) ? x + s : n + 1, km = (k + 2 * s <= n - 1) ? x + 2 * s : n + 1, kr = (k + 3 * s <= n - 1) ? x + 3 * s : n + 1;
+        const REAL cc1 = c[x], cc2 = c[kl], cc3 = c[km], aa2 = a[kl], aa3 = a[km], aa4 = a[kr];
+        const REAL inv_detA = (REAL)1.0 / ((REAL)1.0 - aa4 * cc3 - aa3 * cc2 - aa2 * cc1 * ((REAL)1.0 - cc3 * aa4));
+        const REAL dd1 = d[x], dd2 = d[kl], dd3 = d[km], dd4 = d[kr];
+        const REAL detA1 = -cc3 * (aa4 * dd1 + cc1 * cc2 * dd4 - aa4 * cc1 * dd2) + dd1 + cc1 * cc2 * dd3 - aa3 * cc2 * dd1 - cc1 * dd2;
+        const REAL detA2 = dd2 + cc2 * cc3 * dd4 - aa4 * cc3 * dd2 - cc2 * dd3 - aa2 * (dd1 - aa4 * cc3 * dd1);
+        const REAL detA3 = dd3 - cc3 * dd4 - aa3 * dd2 - aa2 * (cc1 * dd3 - cc1 * cc3 * dd4 - aa3 * dd1);
+        const REAL detA4 = dd4 + aa3 * aa4 * dd2 - aa4 * dd3 - aa3 * cc2 * dd4 - aa2 * (cc1 * dd4 + aa3 * aa4 * dd1 - aa4 * cc1 * dd3);
+        d1[x] = detA1 * inv_detA;
+        if (kl <= n) d1[kl] = detA2 * inv_detA;
+        if (km <= n) d1[km] = detA3 * inv_detA;
+        if (kr <= n) d1[kr] = detA4 * inv_detA;
+      }
+    }
+    wave_lds_sync();
+  } else {  // ---- 2x2 systems of the last stage (:599-616), result into the d slot of the other buffer
     const int s = 1 << (g.pn - 1);
     if (active) {
       const REAL* a = A[cur];

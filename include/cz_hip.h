@@ -236,7 +236,8 @@ int czhip_pair_maf_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const i
 /* Shape of the two-stage pass: threads per workgroup (512 | 1024; 0 / -1 keep, -2 = chosen per launch by the balance model), vectors per
  * thread (2), planes per chunk (0 = chosen per launch, -1 keep), enable (-1 keep).  Returns 0 if ok.  Every shape gives the same bits. */
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable);
-/* line-SOR kernels (pcr*_): form 0 = one wave per line with the reference's arithmetic literally (pcr_rb_ only), 1 = coefficient
+/* line-SOR kernels (pcr*_): form 0 = one wave per line with the reference's arithmetic literally (a, c and d of the line reduced in LDS; every
+ * variant but pcr_j_esa_; also the fall-back for lines whose coefficient table does not fit LDS), 1 = coefficient
  * table + right-hand side in LDS, 2 = table + right-hand side in registers (default); variant = waves*10 + lines per wave, 0 = default;
  * negative = keep.  All forms give the same bits. */
 int czhip_set_pcr_mode(int form, int variant);

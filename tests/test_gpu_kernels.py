@@ -685,6 +685,41 @@ def test_lexicographic_line_sor_gives_up_instead_of_hanging():
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", [(9, 8, 32), (12, 9, 40), (7, 11, 130), (5, 4, 700)], ids=lambda b: "x".join(map(str, b)))
+def test_line_sor_literal_form_every_variant_vs_oracle(prec, box):
+    """czhip_set_pcr_mode(0, .): every line-SOR variant through the literal per-line kernel (a, c and d of a line reduced in LDS, 2x2 or 4x4
+    final systems from the line's own coefficients) -- the form that takes over when the coefficient table of a long line does not fit
+    LDS (FP64 lines beyond ~640 unknowns with the 4x4 final stage) -- == the oracle, bit for bit."""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    assert h.lib.czhip_set_pcr_mode(0, 0) == 0
+    try:
+        for name in ("pcr", "pcr_esa", "pcr_eda", "pcr_rb_esa", "pcr_rb"):
+            x1, dx = x0.copy(), h.alloc(sz, x0)
+            for it in range(2):
+                if name.startswith("pcr_rb"):
+                    r1 = r2 = 0.0
+                    for color in (0, 1):
+                        r1 = getattr(ko, name)(sz, idx, pn, 0, color, x1, msk, rhs, 1.3, res=r1)
+                        r2 = getattr(h, name)(sz, idx, pn, 0, color, dx, dm, dr, 1.3, res=r2)
+                else:
+                    r1, r2 = getattr(ko, name)(sz, idx, pn, x1, msk, rhs, 1.3), getattr(h, name)(sz, idx, pn, dx, dm, dr, 1.3)
+                assert _beq(dx.get(), x1), (name, it)
+                assert _rel(r2, r1) < (2e-3 if prec == "f32" else 1e-11), (name, r1, r2)
+    finally:
+        h.lib.czhip_set_pcr_mode(2, 0)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("nk", [3, 4, 5, 6, 7, 10])
 def test_line_sor_short_lines(prec, nk):
     """k-lines of 1..8 unknowns (pn = 1..4): fewer reduction stages than the kernels are tuned for, none at all for n <= 3."""
