@@ -212,7 +212,7 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
   ScopedTimer tm(LBL_PCR);
   HIP_CHECK(hipMemsetAsync(ctx.pipe_ctl, 0, ctl_words * sizeof(unsigned), ctx.stream));
   long long* prof = nullptr;
-  static const char* prof_env = getenv("CZHIP_PCR_PIPE_PROF");  // development aid: when each strip started / ended and how long it waited for the one above
+  static const char* prof_env = kLexProf ? getenv("CZHIP_PCR_PIPE_PROF") : nullptr;  // development aid (build with -DCZ_LEX_PROF): when each strip started / ended and how long it waited
   if (prof_env) {
     HIP_CHECK(hipMalloc(&prof, (size_t)8 * nstrips * sizeof(long long)));
     HIP_CHECK(hipMemsetAsync(prof, 0, (size_t)8 * nstrips * sizeof(long long), ctx.stream));

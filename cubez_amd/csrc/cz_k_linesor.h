@@ -1106,6 +1106,14 @@ __device__ __forceinline__ void lds_barrier() {
 // (the MAF form spilled 132 bytes in FP32 as well: same bound)
 constexpr int lex_max_threads(int maf) { return (sizeof(REAL) == 8 || maf) ? 512 : 1024; }
 
+// The per-strip time stamps (CZHIP_PCR_PIPE_PROF) cost eighteen registers: compiled in only with -DCZ_LEX_PROF (how the strip profiles under
+// profiles/r02 were taken); without them the MAF form gained 15 % (27 100 -> 31 300 MLUPS).
+#ifdef CZ_LEX_PROF
+constexpr bool kLexProf = true;
+#else
+constexpr bool kLexProf = false;
+#endif
+
 template <int FINAL4, int NT, int Q, int MAF>
 __global__ void __launch_bounds__(lex_max_threads(MAF))
 pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, const REAL* __restrict__ tab, int nfin,
@@ -1243,7 +1251,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
     double acc = 0.0;
     long long pf_start = 0, pf_first = 0, pf_wait = 0, pf_nwait = 0;  // CZHIP_PCR_PIPE_PROF (thread 0)
     long long pf_ph[4] = {0, 0, 0, 0}, pf_m = 0;  // ticks up to the first barrier / in the stages / final + relax / rotation + last barrier
-    if (prof && t == 0) pf_start = (long long)wall_clock64();
+    if (kLexProf && prof && t == 0) pf_start = (long long)wall_clock64();
     const int nsteps = g.ni + rlast;
 
     for (int st = 0; st < nsteps; st++) {
@@ -1252,7 +1260,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       if (rg == 0 && from_mem && st < g.ni) {
         const unsigned want = seq_base + (unsigned)st + 1u;
         long long pa = 0;
-        if (prof && t == 0) pa = (long long)wall_clock64();
+        if (kLexProf && prof && t == 0) pa = (long long)wall_clock64();
         bool ok = true;
 #pragma unroll
         for (int w = 0; w < HW; w++) ok = ok && (unsigned)(hw[w] >> 32) == want;
@@ -1269,13 +1277,13 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
           }
         }
         t0 = 0;
-        if (prof && t == 0) {
+        if (kLexProf && prof && t == 0) {
           const long long pb = (long long)wall_clock64();
           pf_wait += pb - pa, pf_nwait += (pb - pa > 20);
           if (st == 0) pf_first = pb;
         }
       }
-      if (prof && t == 0) pf_m = (long long)wall_clock64();
+      if (kLexProf && prof && t == 0) pf_m = (long long)wall_clock64();
       bool act[Q], on[Q];
       size_t cl[Q], en[Q];
 #pragma unroll
@@ -1349,7 +1357,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
       fetch_next();
       lds_barrier();
       int gave_up = 0;
-      if (prof && t == 0) {
+      if (kLexProf && prof && t == 0) {
         const long long nw = (long long)wall_clock64();
         pf_ph[0] += nw - pf_m, pf_m = nw;
       }
@@ -1403,7 +1411,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
         }
       }
       if (gave_up) break;
-      if (prof && t == 0) {
+      if (kLexProf && prof && t == 0) {
         const long long nw = (long long)wall_clock64();
         pf_ph[1] += nw - pf_m, pf_m = nw;
       }
@@ -1473,7 +1481,7 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
           }
         }
       }
-      if (prof && t == 0) {
+      if (kLexProf && prof && t == 0) {
         const long long nw = (long long)wall_clock64();
         pf_ph[2] += nw - pf_m, pf_m = nw;
       }
@@ -1482,12 +1490,12 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
         if (act[q]) xim[q] = out[q], pp[q] = xip[q], xip[q] = n_xip[q], xjp[q] = n_xjp[q], rh[q] = n_rh[q], mk[q] = n_mk[q], klo[q] = n_klo[q], khi[q] = n_khi[q];
       if (t == 0 && from_mem && st < g.ni) __hip_atomic_store(my_prog, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // line st is taken
       if (R > 1) lds_barrier();  // (the group below reads NLINE at the top of the next step)
-      if (prof && t == 0) pf_ph[3] += (long long)wall_clock64() - pf_m;
+      if (kLexProf && prof && t == 0) pf_ph[3] += (long long)wall_clock64() - pf_m;
     }
     __syncthreads();
     const double sblk = block_sum_rt(acc, wsum, nwaves);
     if (t == 0) __hip_atomic_store(&partials[strip], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prof && t == 0) {
+    if (kLexProf && prof && t == 0) {
       long long* q = prof + (size_t)8 * strip;
       q[0] = pf_start, q[1] = pf_first, q[2] = (long long)wall_clock64(), q[3] = pf_wait, q[4] = pf_nwait, q[5] = blockIdx.x, q[6] = (pf_ph[0] << 32) | pf_ph[1], q[7] = (pf_ph[2] << 32) | pf_ph[3];
     }

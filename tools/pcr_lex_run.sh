@@ -1,7 +1,7 @@
 #!/bin/bash
 # Evidence for the one-launch lexicographic line SOR (pcr_lex_wg_k), 512^3: bench lines with the kernel on / off (launch per diagonal) on the
 # same box, the strip profile (CZHIP_PCR_PIPE_PROF) of the shapes that were compared, and the kernel trace.
-# usage (GPU box, repo root): tools/pcr_lex_run.sh
+# usage (GPU box, repo root): tools/pcr_lex_run.sh      (the strip profile needs a library built with -DCZ_LEX_PROF: make CXXFLAGS_EXTRA=-DCZ_LEX_PROF)
 set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
