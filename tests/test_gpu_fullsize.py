@@ -333,6 +333,28 @@ def test_line_sor_512_three_kernel_forms_agree():
     assert np.allclose(outs[0][1], outs[2][1], rtol=1e-12, atol=0) and np.allclose(outs[1][1], outs[2][1], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("solver,prec", [("pcr", "f32"), ("pcr_eda", "f64"), ("pcr_maf", "f32")])
+def test_lexicographic_line_sor_512_one_launch_equals_diagonals(solver, prec):
+    """pcr / pcr_eda / pcr_maf at 512^3: the whole sweep in one launch (rows of k-lines handed from workgroup to workgroup, 510 strips
+    in flight) gives the field of the launch-per-diagonal form, bit for bit, after two iterations -- and neither residual is NaN."""
+    from cubez_amd import CZ
+    outs = []
+    for one_launch in (1, 0):
+        cz = CZ(prec, quiet=True)
+        assert cz.lib.czhip_set_pcr_lex(one_launch, 0, 1) == 0
+        try:
+            assert cz.setup([N, N, N, solver, 2, 1.2]) == 1
+            cz.solve()
+            h = cz.history()
+            assert all(v == v for v in h), h
+            outs.append((hashlib.sha256(cz.field().tobytes()).hexdigest(), h))
+        finally:
+            cz.lib.czhip_set_pcr_lex(1, 0, 1)
+            cz.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-12, atol=0)
+
+
 def test_arrays_beyond_2_to_31_elements():
     """maximum sizes: 1300^3 cells = 2.2e9 elements (8.9 GB) per FP32 array -- every linear index needs 64 bits.  The fused-pair path and
     the single-sweep path agree bit for bit, the Dirichlet data sit where the 64-bit index says."""
