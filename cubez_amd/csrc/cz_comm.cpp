@@ -50,7 +50,7 @@ namespace {
 double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // Seconds a collective may stay incomplete before the job is ended with a diagnostic: CZ_COMM_TIMEOUT, default 300 when CZ_COMM_DEBUG
-// is set (bench.py sets it for N > 1), 0 = wait for ever (RCCL) / 120 (LOCAL test transport, whose waits are host-side).
+// is set (bench.py sets it for N > 1) and 120 for the LOCAL test transport, whose waits are host-side; 0 (or less) = wait for ever.
 double comm_timeout_s(bool local) {
   if (const char* t = getenv("CZ_COMM_TIMEOUT")) return atof(t);
   if (local) return 120.0;
@@ -77,7 +77,9 @@ struct LocalWorld {
       cv.notify_all();
     } else {
       const double lim = comm_timeout_s(true);
-      if (!cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return generation != gen; })) {
+      if (lim <= 0.0) {  // CZ_COMM_TIMEOUT=0: no bound
+        cv.wait(lk, [&] { return generation != gen; });
+      } else if (!cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return generation != gen; })) {
         fprintf(stderr, "cz rank %d: LOCAL barrier #%ld: only %d of %d ranks arrived within %.0f s -- the ranks issue different collectives\n", rank,
                 gen, arrived, n, lim);
         fflush(stderr);
@@ -167,6 +169,7 @@ struct Boot {
   Transport tr = T_NONE;
   int rank = 0, nproc = 1;
   ncclComm_t nccl = nullptr;
+  ncclComm_t nccl_red = nullptr;  // a second communicator over the same ranks for the all-reduces (see cz_comm_bootstrap)
   LocalWorld* world = nullptr;
 };
 thread_local Boot boot;
@@ -238,11 +241,12 @@ box_copy_k(T* __restrict__ buf, T* __restrict__ X, BoxTable tab, int nkp, int ni
       const int i = row % d.ni, j = row / d.ni;
       T* xr = X + (size_t)d.k0 + (size_t)(d.i0 + i) * nkp + (size_t)(d.j0 + j) * plane;
       T* br = buf + d.off + (size_t)row * d.nk;
-      if (sizeof(T) == 4 && d.nk == 2 && (d.k0 & 1) == 0 && (d.off & 1) == 0) {
+      // (8- / 16-byte accesses need every row start aligned: k0 even AND an even row length -- with nkp odd every second row is not)
+      if (sizeof(T) == 4 && d.nk == 2 && (d.k0 & 1) == 0 && (d.off & 1) == 0 && (nkp & 1) == 0) {
         typedef typename Vec8<T>::type V2;
         if (DIR == 0) *reinterpret_cast<V2*>(br) = *reinterpret_cast<const V2*>(xr);
         else *reinterpret_cast<V2*>(xr) = *reinterpret_cast<const V2*>(br);
-      } else if (sizeof(T) == 8 && d.nk == 2 && (d.k0 & 1) == 0 && (d.off & 1) == 0) {
+      } else if (sizeof(T) == 8 && d.nk == 2 && (d.k0 & 1) == 0 && (d.off & 1) == 0 && (nkp & 1) == 0) {
         typedef typename Vec16<T>::type V2;
         if (DIR == 0) *reinterpret_cast<V2*>(br) = *reinterpret_cast<const V2*>(xr);
         else *reinterpret_cast<V2*>(xr) = *reinterpret_cast<const V2*>(br);
@@ -288,7 +292,8 @@ struct CommCtx {
   int size[3], nID[6];
   int coord[3], div[3];
   int g = 2;
-  ncclComm_t nccl = nullptr;
+  ncclComm_t nccl = nullptr;      // halo exchanges
+  ncclComm_t nccl_red = nullptr;  // all-reduces (== nccl when the job asked for one communicator)
   LocalWorld* world = nullptr;
   double* h_red = nullptr;
   Pattern shallow, deep;   // depth 1 faces / depth 2 faces + edges
@@ -417,6 +422,11 @@ void build_pattern(CommCtx* c, Pattern& p, int depth, bool edges) {
   }
 }
 
+// `skip` (a device flag: the solve has converged) turns the pack and unpack launches into no-ops; the messages themselves are ALWAYS sent --
+// collectives must never depend on device state the host has not read (rank lock step).  Packed messages then carry stale
+// buffer contents that nobody unpacks.  Direct messages (J faces, received into the array itself) do write the ghost planes after
+// convergence: what they write are the sender's owned cells of the converged iterate, which the skipped sweeps no longer change -- the
+// same values the last exchange before convergence left there for every array the solver still reads.
 template <typename T>
 bool exchange(CommCtx* c, const Pattern& p, T* X, const int* skip, hipStream_t st) {
   if (p.nmsg == 0) return true;
@@ -484,7 +494,7 @@ CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], i
   }
   CommCtx* c = new CommCtx();
   c->tr = boot.tr, c->rank = rank, c->nproc = nproc, c->eb = elem_bytes;
-  c->nccl = boot.nccl, c->world = boot.world;
+  c->nccl = boot.nccl, c->nccl_red = boot.nccl_red ? boot.nccl_red : boot.nccl, c->world = boot.world;
   for (int a = 0; a < 3; a++) c->size[a] = size[a], c->div[a] = div[a];
   for (int f = 0; f < 6; f++) c->nID[f] = nID[f];
   c->coord[0] = rank % div[0], c->coord[1] = (rank / div[0]) % div[1], c->coord[2] = rank / (div[0] * div[1]);
@@ -524,7 +534,7 @@ bool comm_halo2(CommCtx* c, void* X, const int* skip, hipStream_t st) {
 bool comm_allreduce_sum(CommCtx* c, double* d_val, int count, hipStream_t st) {
   if (!c) return true;
   if (c->tr == T_RCCL) {
-    NCCL_CHECK(ncclAllReduce(d_val, d_val, count, ncclDouble, ncclSum, c->nccl, st));
+    NCCL_CHECK(ncclAllReduce(d_val, d_val, count, ncclDouble, ncclSum, c->nccl_red, st));
     c->watch.note("all-reduce (sum)", st);
     return true;
   }
@@ -550,7 +560,7 @@ double comm_allreduce_max_host(CommCtx* c, double v) {
     double* d = nullptr;
     HIP_CHECK(hipMalloc(&d, sizeof(double)));
     HIP_CHECK(hipMemcpy(d, &v, sizeof(double), hipMemcpyHostToDevice));
-    NCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclMax, c->nccl, czhip_internal::stream()));
+    NCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclMax, c->nccl_red, czhip_internal::stream()));
     c->watch.note("all-reduce (max)", czhip_internal::stream());
     HIP_CHECK(hipStreamSynchronize(czhip_internal::stream()));
     HIP_CHECK(hipMemcpy(&v, d, sizeof(double), hipMemcpyDeviceToHost));
@@ -598,11 +608,24 @@ int cz_comm_bootstrap(int rank, int nranks, const char* id_bytes) {
   memcpy(&id, id_bytes, sizeof(id));
   ncclComm_t comm;
   NCCL_CHECK(ncclCommInitRank(&comm, nranks, id, rank));
-  boot.tr = T_RCCL, boot.rank = rank, boot.nproc = nranks, boot.nccl = comm, boot.world = nullptr;
+  boot.tr = T_RCCL, boot.rank = rank, boot.nproc = nranks, boot.nccl = comm, boot.nccl_red = nullptr, boot.world = nullptr;
+  // The halo exchanges run on the exchange stream, the all-reduces of the non-lagged paths and of BiCGSTAB on the compute stream.  RCCL
+  // orders the operations of ONE communicator across the streams they are issued on (it makes the later stream wait for the earlier
+  // operation); the driver already orders them with events the way the algorithm needs, and a second communicator over the same ranks
+  // keeps RCCL from adding an order of its own between an exchange and an all-reduce that have nothing to do with each other.  Every rank
+  // issues the operations of both communicators in the same program order (CZ::JACOBI / RBSOR / PBiCGSTAB), which is what concurrent
+  // communicators need.  CZ_COMM_ONE_COMM=1 keeps everything on one communicator.
+  const char* one = getenv("CZ_COMM_ONE_COMM");
+  if (!(one && atoi(one) != 0)) {
+    ncclComm_t red = nullptr;
+    NCCL_CHECK(ncclCommSplit(comm, 0, rank, &red, nullptr));
+    boot.nccl_red = red;
+  }
   return 0;
 }
 
 void cz_comm_shutdown(void) {
+  if (boot.tr == T_RCCL && boot.nccl_red) NCCL_CHECK(ncclCommDestroy(boot.nccl_red));
   if (boot.tr == T_RCCL && boot.nccl) NCCL_CHECK(ncclCommDestroy(boot.nccl));
   boot = Boot();
 }

@@ -327,9 +327,9 @@ int CZ::Setup(int argc, char** argv) {
       (void)hipGetDevice(&dev);
       fprintf(stderr,
               "cz rank %d/%d device %d: div %dx%dx%d size %dx%dx%d head %d,%d,%d nID %d %d %d %d %d %d fused_pass=%d shell_slabs=%d overlap=%d "
-              "lagged_reduce=%d\n",
+              "lagged_reduce=%d comm_cus_per_xcd=%d\n",
               myRank, numProc, dev, G_div[0], G_div[1], G_div[2], size[0], size[1], size[2], head[0], head[1], head[2], nID[0], nID[1], nID[2],
-              nID[3], nID[4], nID[5], (int)pairs_ok, n_shell, overlap, lag_reduce);
+              nID[3], nID[4], nID[5], (int)pairs_ok, n_shell, overlap, lag_reduce, comm_cus);
     }
   }
   const bool bicg = ls_type == LS_BICGSTAB || ls_type == LS_BICGSTAB_MAF;
@@ -564,8 +564,18 @@ void CZ::skew_wait() const {
 // Split of the inner box for overlapped exchanges (pair_plan, cz_kernels.hip); n_shell = 0 when there is nothing to overlap.
 void CZ::plan_overlap() {
   n_shell = 0;
-  if (numProc == 1 || !overlap) return;
-  n_shell = pair_plan(innerFidx, nID, shell_boxes, interior, interior1);
+  comm_cus = 0;
+  if (numProc > 1 && overlap) n_shell = pair_plan(innerFidx, nID, shell_boxes, interior, interior1);
+  // CUs per XCD the sweeps leave to the exchange stream while an interior launch fills the chip (RCCL's send/recv kernels need CUs of their
+  // own for as long as a message is in flight; reserve_comm_cus, cz_kernels.hip).  CZ_COMM_CUS, default 2: at 512^3 the interior launch
+  // of the two-stage pass uses 30 of an XCD's 32 CUs anyway (profiles/r03/cu_reserve_cost.txt).  Every rank reserves alike (argv and
+  // environment are the job's), also a brick without a rank-internal face: the launch geometry of a pass depends on the CU count.
+  if (numProc > 1 && overlap) {
+    const char* cc = getenv("CZ_COMM_CUS");
+    comm_cus = reserve_comm_cus(cc ? atoi(cc) : 2);
+  } else {
+    reserve_comm_cus(0);
+  }
   if (n_shell == 0) return;
   if (!comm_stream) {
     // highest priority: pack / send-recv / unpack must get workgroup slots while the interior sweep (thousands of queued
@@ -629,6 +639,18 @@ int CZ::finish_stationary(int itr_max, int first_itr, bool converge_check, doubl
     res = history.back();
   }
   return conv ? n_exec : itr_max + 1;
+}
+
+// d_res[0] of the sweep(s) just issued, read back behind them: NaN = the sweep gave up a wait between its workgroups (pcr_lex_wg_k)
+bool CZ::sweep_failed(const char* solver) {
+  HIP_CHECK(hipMemcpyAsync(h_scal + 9, d_res, sizeof(double), hipMemcpyDeviceToHost, stream()));
+  HIP_CHECK(hipStreamSynchronize(stream()));
+  if (!std::isnan(h_scal[9])) return false;
+  fprintf(stderr, "cz rank %d: %s: the residual of a sweep is NaN -- a hand-off between the workgroups of the one-launch lexicographic sweep did "
+                  "not arrive within its bound (czhip_set_pcr_lex_timeout), or the data hold NaN.  The iterate is void.  CZHIP_PCR_PIPE=0 selects "
+                  "the launch-per-diagonal form.\n", myRank, solver);
+  line_error = true;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1075,7 +1097,7 @@ int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_
       if (!Comm_SUM_dev(d_res, 1)) return 0;
       czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
+      if (sweep_failed(printMethod(s_type))) return 0;  // (synchronises)
       if (h_flag[0]) break;
     }
   }
@@ -1086,7 +1108,7 @@ int CZ::LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_
     HIP_CHECK(hipMemcpy(history.data() + base, d_hist + 1, (size_t)n_exec * sizeof(double), hipMemcpyDeviceToHost));
     res = history.back();
   } else {
-    czhip_sync();
+    if (sweep_failed(printMethod(s_type))) return 0;  // (synchronises)
   }
   return itr;
 }
@@ -1125,7 +1147,7 @@ int CZ::LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max,
       if (!Comm_SUM_dev(d_res, 1)) return 0;
       czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
+      if (sweep_failed(printMethod(s_type))) return 0;  // (synchronises)
       if (h_flag[0]) break;
     }
   }
@@ -1136,7 +1158,7 @@ int CZ::LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max,
     HIP_CHECK(hipMemcpy(history.data() + base, d_hist + 1, (size_t)n_exec * sizeof(double), hipMemcpyDeviceToHost));
     res = history.back();
   } else {
-    czhip_sync();
+    if (sweep_failed(printMethod(s_type))) return 0;  // (synchronises)
   }
   return itr;
 }
@@ -1144,7 +1166,6 @@ int CZ::LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max,
 // cz_Poisson.cpp:518-611.  Line SOR: every (i,j) column of one checkerboard colour is solved along k by parallel cyclic
 // reduction (pcr_rb_k), colour 0 then colour 1, in place.  Single-domain.
 int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
-  (void)s_type;
   const int gc = GUIDE;
   hipStream_t st = stream();
   reset_ticket();
@@ -1173,7 +1194,7 @@ int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, 
       if (!Comm_SUM_dev(d_res, 1)) return 0;
       czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
+      if (sweep_failed(printMethod(s_type))) return 0;  // (synchronises)
       if (h_flag[0]) break;
     }
   }
@@ -1184,7 +1205,7 @@ int CZ::LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, 
     HIP_CHECK(hipMemcpy(history.data() + base, d_hist + 1, (size_t)n_exec * sizeof(double), hipMemcpyDeviceToHost));
     res = history.back();
   } else {
-    czhip_sync();
+    if (sweep_failed(printMethod(s_type))) return 0;  // (synchronises)
   }
   return itr;
 }
@@ -1315,6 +1336,7 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     flop_count = 0.0;                                // :405 blas_clear_(pcg_p_) happens inside Preconditioner
     Preconditioner(pcg_p_, pcg_p, flop_count, pc_type);  // :409
     flop += flop_count;
+    if (line_error) return 0;
 
     // :417/:421 q = A p_  and  :427 q.r0
     calc_ax_dots_async(pcg_q, pcg_p_, pcg_r0, size, innerFidx, gc, cf, maf ? &mp : nullptr, d_res + 2);
@@ -1331,6 +1353,7 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     flop_count = 0.0;  // :441 blas_clear_(pcg_s_) happens inside Preconditioner
     Preconditioner(pcg_s_, pcg_s, flop_count, pc_type);  // :445
     flop += flop_count;
+    if (line_error) return 0;
 
     // :453/:457 t_ = A s_  and  :464 t_.s, t_.t_
     calc_ax_dots_async(pcg_t_, pcg_s_, pcg_s, size, innerFidx, gc, cf, maf ? &mp : nullptr, d_res + 4);
@@ -1599,6 +1622,7 @@ int cz_info(const cz_handle* h, int what) {
     case 3: return c.overlap;
     case 4: return c.last_lag;
     case 5: return comm_transport_ranks(c.comm);
+    case 6: return c.comm_cus;
     default: return -1;
   }
 }

@@ -76,6 +76,7 @@ class CZ {
   int wrk_shell_tag = 0;         // whose shell WRK carries: 0 unknown, 1 P's (Dirichlet faces), 2 all zero (sync_wrk_shell)
   void sync_wrk_shell(const REAL_TYPE* X);
   int overlap = 1;               // CZ_OVERLAP=0 turns it off (exchange after the whole sweep, same results)
+  int comm_cus = 0;              // CUs per XCD the sweeps leave to the exchange stream (CZ_COMM_CUS; 0 in single-domain runs)
   int n_shell = 0;               // shell boxes (cells within two layers of a rank-internal face), 1-based index ranges
   int shell_boxes[36];
   int interior[6], interior1[6]; // the rest of the inner box / its first-sweep range
@@ -131,6 +132,10 @@ class CZ {
   bool Comm_SUM_1(double* host_val);
 
   int finish_stationary(int itr_max, int first_itr, bool converge_check, double& res);
+  // line solvers: the one-launch lexicographic sweep reports a lost hand-off between its workgroups as a NaN residual (every wait inside
+  // it is bounded); the iterate is then void and the solve ends with "Solver error" instead of sweeping on (true = failed; message printed)
+  bool sweep_failed(const char* solver);
+  bool line_error = false;       // set by sweep_failed; PBiCGSTAB gives up when a line-solver preconditioner set it
   double npts() const;
 };
 

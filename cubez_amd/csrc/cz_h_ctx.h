@@ -9,6 +9,8 @@ struct Tuning {
   int pcr_pipe = 1;                  // CZHIP_PCR_PIPE: 1 = the lexicographic line SOR (pcr, pcr_esa) in one launch per sweep (pcr_lex_wg_k), 0 = a launch per diagonal
   int pcr_rows = 0, pcr_q = 1;       // groups of NT threads per workgroup (0: chosen by the launcher), rows per thread (1, 2)
   long long pipe_spin_ticks = 200000000;  // bound of every wait inside it, in ticks of the 100 MHz wall clock (2 s)
+  int pcr_wg_per_cu = 0, pcr_max_wg = 0, pcr_slots = 0;  // pcr_lex_wg_k: workgroups per CU / in all, lines per hand-off ring (0: the launcher's choice);
+                                                         // CZHIP_PCR_WG_PER_CU, CZHIP_PCR_MAX_WG, CZHIP_PCR_SLOTS, czhip_set_pcr_lex_limits
   int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
                                       // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
@@ -33,6 +35,8 @@ struct Ctx {
   REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
   int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
   size_t pcr_tab_cap = 0;
+  REAL* pcr_scratch = nullptr;  // pcr_rb_k<GS = 1>: a, c, d of the lines in flight (lines too long for LDS)
+  size_t pcr_scratch_cap = 0;
   double* shell_partials = nullptr;  // per-workgroup sums of the last pair_shell_k launch, folded in by the interior launch
   int shell_pending = 0;
   size_t partials_cap = 0;
@@ -45,7 +49,9 @@ struct Ctx {
   std::map<std::vector<double>, REAL*> bc_tabs;  // key: ix, jx, dh, org0, org1
   struct PairMap { int* dev = nullptr; long long nblk = 0; };
   std::map<long long, PairMap> pair_maps;        // workgroup id -> (segment, chunk) tables of the two-stage pass, key nseg << 32 | nchunk
-  int num_cu = 256;
+  int num_cu = 256;             // CUs the compute stream may use (= num_cu_total - 8 * cu_reserved)
+  int num_cu_total = 256;
+  int cu_reserved = 0;          // CUs per XCD the compute stream leaves to the exchange stream (decomposed runs; reserve_comm_cus)
   // optional per-launch HIP-event timing of the labelled kernels (bench.py roofline leg)
   bool timing = false;
   struct Ev { hipEvent_t a, b; int label; };

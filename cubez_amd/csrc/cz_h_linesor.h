@@ -9,32 +9,48 @@ int num_stage(int n) {  // cz.h:293-300
   return -1;
 }
 
-template <int NW, int ORDER = 0, int MAF = 0, int FINAL4 = 0>
+// the literal per-line kernel; wout: ORDER 2 only.  GS = 1: work arrays in global scratch, any line length (persistent workgroups).
+template <int NW, int ORDER = 0, int MAF = 0, int FINAL4 = 0, int GS = 0>
 bool try_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, PcrGeom g, REAL omg, double* res_dev, int accumulate, size_t lds_cap,
-                const MafArgs& ma = MafArgs()) {
+                const MafArgs& ma = MafArgs(), REAL* wout = nullptr) {
   if (FINAL4 && g.pn < 2) return false;  // (a line of one unknown has no 4x4 form)
   const long long ncol = (ORDER == 0) ? (long long)g.nhalf * g.nj
-                                      : (long long)(std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1);
-  const unsigned nblk = (unsigned)((ncol + NW - 1) / NW);
-  const size_t lds = (size_t)NW * 6 * (g.n + 2) * sizeof(REAL) + 64 + 16 * sizeof(double);
-  if (lds > lds_cap) return false;
+                         : (ORDER == 1) ? (long long)(std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1)
+                                        : (long long)g.ni * g.nj;
+  unsigned nblk = (unsigned)((ncol + NW - 1) / NW);
+  size_t lds = (size_t)NW * 6 * (g.n + 2) * sizeof(REAL) + 64 + 16 * sizeof(double);
+  if (GS) {
+    lds = 64 + 16 * sizeof(double);
+    nblk = (unsigned)std::min<long long>(nblk, (long long)ctx.num_cu * (16 / NW));  // 16 waves per CU: latency-bound either way
+    const size_t need = (size_t)nblk * NW * 6 * (g.n + 2);
+    if (need > ctx.pcr_scratch_cap) {
+      if (ctx.pcr_scratch) {
+        HIP_CHECK(hipStreamSynchronize(ctx.stream));
+        HIP_CHECK(hipFree(ctx.pcr_scratch));
+      }
+      HIP_CHECK(hipMalloc(&ctx.pcr_scratch, need * sizeof(REAL)));
+      ctx.pcr_scratch_cap = need;
+    }
+  } else if (lds > lds_cap) {
+    return false;
+  }
   ensure_partials(nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW, ORDER, MAF, FINAL4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb_k<NW, ORDER, MAF, FINAL4, GS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   ScopedTimer tm(LBL_PCR);
-  hipLaunchKernelGGL((pcr_rb_k<NW, ORDER, MAF, FINAL4>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, msk, rhs, g, omg, ctx.partials, res_dev,
-                     accumulate, ctx.counter, ma);
+  hipLaunchKernelGGL((pcr_rb_k<NW, ORDER, MAF, FINAL4, GS>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, wout, msk, rhs, g, omg, ctx.partials, res_dev,
+                     accumulate, ctx.counter, ma, ctx.pcr_scratch, ncol);
   HIP_CHECK(hipGetLastError());
   return true;
 }
 
-template <int NW, int L, int FINAL4, int ORDER>
+template <int NW, int L, int FINAL4, int ORDER, int TG = 0>
 bool try_pcr_rb2_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const PcrGeom& g, REAL omg, double* res_dev, int accumulate,
                       int tab_len, int nfin, long long ncol) {
-  const size_t lds = ((size_t)tab_len + (size_t)NW * 2 * L * (g.n + 2) + 8) * sizeof(REAL) + 32 * sizeof(double);
+  const size_t lds = ((size_t)(TG ? 0 : tab_len) + (size_t)NW * 2 * L * (g.n + 2) + 8) * sizeof(REAL) + 32 * sizeof(double);
   if (lds > 160 * 1024) return false;
   const long long ngroups = (ncol + L - 1) / L;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(32 / NW)));
@@ -42,20 +58,28 @@ bool try_pcr_rb2_inst(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, con
   ensure_partials(nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb2_k<NW, L, FINAL4, ORDER>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_rb2_k<NW, L, FINAL4, ORDER, TG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
   ScopedTimer tm(LBL_PCR);
-  hipLaunchKernelGGL((pcr_rb2_k<NW, L, FINAL4, ORDER>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, wout, msk, rhs, g, omg, ctx.pcr_tab,
+  hipLaunchKernelGGL((pcr_rb2_k<NW, L, FINAL4, ORDER, TG>), dim3(nblk), dim3(64 * NW), lds, ctx.stream, x, wout, msk, rhs, g, omg, ctx.pcr_tab,
                      tab_len, nfin, ctx.partials, res_dev, accumulate, ctx.counter);
   HIP_CHECK(hipGetLastError());
   return true;
 }
 
 // the line-independent coefficients of a line of n unknowns (pcr_coef_k), computed once per (n, pn, variant)
-void ensure_pcr_table(int n, int pn, int final4, int nfin, int tab_len) {
-  if (ctx.pcr_tab_n == n && ctx.pcr_tab_pn == pn && ctx.pcr_tab_final4 == final4) return;
+// (pcr_coef_k reduces a and c of one line in LDS: 4 (n + 2) words -- lines of up to ~10 000 FP32 / ~5 000 FP64 unknowns; false beyond)
+bool ensure_pcr_table(int n, int pn, int final4, int nfin, int tab_len) {
+  if (ctx.pcr_tab_n == n && ctx.pcr_tab_pn == pn && ctx.pcr_tab_final4 == final4) return true;
+  const size_t coef_lds = (size_t)4 * (n + 2) * sizeof(REAL);
+  if (coef_lds > 160 * 1024) return false;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&pcr_coef_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
   if ((size_t)tab_len > ctx.pcr_tab_cap) {
     if (ctx.pcr_tab) {
       HIP_CHECK(hipStreamSynchronize(ctx.stream));
@@ -64,10 +88,11 @@ void ensure_pcr_table(int n, int pn, int final4, int nfin, int tab_len) {
     HIP_CHECK(hipMalloc(&ctx.pcr_tab, (size_t)tab_len * sizeof(REAL)));
     ctx.pcr_tab_cap = tab_len;
   }
-  hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), (size_t)4 * (n + 2) * sizeof(REAL), ctx.stream, ctx.pcr_tab, n, pn, nfin, final4);
+  hipLaunchKernelGGL(pcr_coef_k, dim3(1), dim3(256), coef_lds, ctx.stream, ctx.pcr_tab, n, pn, nfin, final4);
   HIP_CHECK(hipGetLastError());
   ctx.pcr_tab_n = n, ctx.pcr_tab_pn = pn, ctx.pcr_tab_final4 = final4;
   ctx.pcr_perm_M = 0;  // the permuted copy is stale
+  return true;
 }
 
 template <int M, int NW, int L, int FINAL4, int ORDER>
@@ -181,16 +206,24 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
   // Workgroups: as many as fit the chip at once (measured at 512^3: one per CU steps no faster than two, and the strips beyond the
   // resident window then wait for a workgroup: 4.21 against 4.08 ms); CZHIP_PCR_WG_PER_CU overrides.
   const int fit = (int)std::max<size_t>(1, std::min<size_t>((size_t)160 * 1024 / lds, (size_t)(kMaxT == 512 ? 512 : 1024) / ((size_t)NT * R)));  // (128 registers per thread: 1 024 threads per CU; 256: 512)
-  static const int per_cu_env = getenv("CZHIP_PCR_WG_PER_CU") ? atoi(getenv("CZHIP_PCR_WG_PER_CU")) : 0;
-  const int per_cu = per_cu_env > 0 ? std::min(per_cu_env, fit) : fit;
-  const unsigned nblk = (unsigned)std::min(nstrips, ctx.num_cu * per_cu);
+  const int per_cu = ctx.tune.pcr_wg_per_cu > 0 ? std::min(ctx.tune.pcr_wg_per_cu, fit) : fit;
+  unsigned nblk = (unsigned)std::min(nstrips, ctx.num_cu * per_cu);
+  if (ctx.tune.pcr_max_wg > 0) nblk = std::min(nblk, (unsigned)ctx.tune.pcr_max_wg);
   // Hand-off buffer: per strip `nslots` lines of {sequence number | value} words.  A strip may run at most nslots lines ahead of the strip
   // below; with W workgroups resident the strip at the head of the resident window can then reach line W x nslots, which must cover its
-  // whole row so that it ends and frees a workgroup for the first strip that is not resident yet (W >= one per CU, whatever the registers).
-  static const int slots_env = getenv("CZHIP_PCR_SLOTS") ? atoi(getenv("CZHIP_PCR_SLOTS")) : 0;
-  int nslots = slots_env > 0 ? slots_env : 8;  // (what a strip knows of the progress of the strip below is a step or two old: 4 slots make it wait in most steps)
-  const int sure = std::min((int)nblk, ctx.num_cu);  // workgroups that are resident whatever the register count: one per CU
-  while (nslots < (g.ni + sure - 1) / sure + 2) nslots *= 2;
+  // whole row so that it ends and frees a workgroup for the first strip that is not resident yet.  How many workgroups ARE resident is not
+  // the launcher's to know: other queues of this process (rank threads of the LOCAL transport), other processes on the device or a CU mask
+  // can hold most of the chip.  The ring therefore counts on an EIGHTH of the workgroups that one per CU would give (and on one when fewer
+  // than eight are launched): 32 lines per ring at 512^3, 64 MB in all.  Should even that fail, every wait inside the kernel is bounded
+  // and the sweep ends with a NaN residual, which the solver loops treat as a hard error (CZ::lex_failed, cz_driver.cpp).
+  int nslots = 8;  // (what a strip knows of the progress of the strip below is a step or two old: 4 slots make it wait in most steps)
+  if (ctx.tune.pcr_slots > 0) {
+    while (nslots < ctx.tune.pcr_slots) nslots *= 2;  // a power of two (the kernel masks the line number)
+    if (ctx.tune.pcr_slots < 8) nslots = ctx.tune.pcr_slots >= 4 ? 4 : 2;
+  } else {
+    const int sure = std::max(1, std::min((int)nblk, ctx.num_cu) / 8);
+    while (nslots < (g.ni + sure - 1) / sure + 2) nslots *= 2;
+  }
   constexpr size_t HW = sizeof(REAL) == 8 ? 2 : 1;
   const size_t hb_words = (size_t)nstrips * nslots * NT * HW;
   if (hb_words > ctx.pipe_hb_cap) {
@@ -283,12 +316,22 @@ bool try_pcr_rb2(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Pc
   const int tab_len = nstage * 3 * n + (FINAL4 ? 7 : 3) * nfin;
   const size_t fixed = ((size_t)tab_len + 8) * sizeof(REAL) + 32 * sizeof(double);
   const size_t per_line = (size_t)2 * (n + 2) * sizeof(REAL);
-  if (fixed + 4 * per_line > 160 * 1024) return false;  // table + four lines must fit
-  ensure_pcr_table(n, pn, FINAL4, nfin, tab_len);
   long long ncol;
   if (ORDER == 0) ncol = (long long)g.nhalf * g.nj;
   else if (ORDER == 1) ncol = std::min(g.ni - 1, g.color) - std::max(0, g.color - (g.nj - 1)) + 1;
   else ncol = (long long)g.ni * g.nj;
+  if (fixed + 4 * per_line > 160 * 1024) {
+    // the table and four lines do not fit LDS together: keep the table in global memory (one copy, read by every workgroup through the caches),
+    // the right-hand sides in LDS -- as many waves per workgroup as still give two workgroups per CU, down to one line per workgroup
+    if (!ensure_pcr_table(n, pn, FINAL4, nfin, tab_len)) return false;
+    if (ORDER != 1) {  // (a diagonal holds few lines: small workgroups there)
+      if (8 * per_line <= 72 * 1024 && try_pcr_rb2_inst<8, 1, FINAL4, ORDER, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+    }
+    if ((4 * per_line <= 72 * 1024 || ORDER == 1) && try_pcr_rb2_inst<4, 1, FINAL4, ORDER, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+    if (try_pcr_rb2_inst<2, 1, FINAL4, ORDER, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
+    return try_pcr_rb2_inst<1, 1, FINAL4, ORDER, 1>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol);
+  }
+  if (!ensure_pcr_table(n, pn, FINAL4, nfin, tab_len)) return false;
   if (ORDER == 1) {  // a diagonal holds few lines: small workgroups spread them over the chip
     if (try_pcr_rb2_inst<4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, nfin, ncol)) return true;
     return false;
@@ -317,23 +360,30 @@ PcrGeom make_pcr_geom(const Box& b, const int* idx, int pn, int sel) {
 
 // The line-SOR variants that end in 4x4 systems or visit the columns in another order (pcr, pcr_esa, pcr_rb_esa, pcr_j_esa).
 // order 0: colour `sel` in place; 1: lexicographic in place = one launch per diagonal; 2: all columns, x -> wout.
-// They exist in the table form only: a line whose table does not fit LDS is refused.
+// Forms, in the order they are tried: coefficient table + right-hand sides in registers / in LDS; table in global memory + right-hand sides in
+// LDS; a, c, d of the line in LDS; a, c, d in global scratch -- every line length the reference accepts runs in one of them.
 void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Box& b, const int* idx, int pn, int order, int sel,
                         int final4, REAL omg, double* res_dev, int accumulate) {
   if (b.empty) {
     if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
     return;
   }
-  // the literal per-line kernel (a, c and d of every line reduced in LDS, no table): lines too long for the table forms, or czhip_set_pcr_mode(0, .)
+  // the literal per-line kernel (a, c and d of every line reduced in LDS, no table): lines too long for the table forms, or czhip_set_pcr_mode(0, .);
+  // beyond the ~6 800 FP32 / ~3 400 FP64 unknowns whose six work rows fill LDS, the same kernel on global scratch (no limit)
   auto literal = [&](const PcrGeom& g, int acc) -> bool {
-    if (order == 2) return false;  // (pcr_j_esa reads the old field and writes another array: table forms only)
+    const MafArgs no = MafArgs();
+    if (order == 2) {  // pcr_j_esa: 2x2 final systems, old field in, wout out
+      return try_pcr_rb<4, 2, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, no, wout) || try_pcr_rb<2, 2, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, no, wout) ||
+             try_pcr_rb<1, 2, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, no, wout) || try_pcr_rb<4, 2, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 0, no, wout);
+    }
     if (order == 0) {
       if (final4) return try_pcr_rb<4, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) || try_pcr_rb<2, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) ||
-                         try_pcr_rb<1, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024);
+                         try_pcr_rb<1, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024) || try_pcr_rb<4, 0, 0, 1, 1>(x, msk, rhs, g, omg, res_dev, acc, 0);
       return try_pcr_rb<4, 0, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) || try_pcr_rb<2, 0, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024) ||
-             try_pcr_rb<1, 0, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024);
+             try_pcr_rb<1, 0, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024) || try_pcr_rb<4, 0, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 0);
     }
-    return final4 ? try_pcr_rb<1, 1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024) : try_pcr_rb<1, 1, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024);
+    return final4 ? (try_pcr_rb<1, 1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024) || try_pcr_rb<4, 1, 0, 1, 1>(x, msk, rhs, g, omg, res_dev, acc, 0))
+                  : (try_pcr_rb<1, 1, 0, 0>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024) || try_pcr_rb<4, 1, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 0));
   };
   const bool table_forms = ctx.tune.pcr_fast > 0 || order == 2;
   bool ok = true;
@@ -361,8 +411,7 @@ void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, c
     if (!ok) ok = literal(g, accumulate);
   }
   if (!ok) {
-    fprintf(stderr, "czhip: line SOR: a k-line of %d unknowns fits the 160 KiB of LDS in no form (coefficient table, or a, c and d of one line)\n",
-            b.kk1 - b.kk0 + 1);
+    fprintf(stderr, "czhip: line SOR: no kernel form took a k-line of %d unknowns (pn = %d)\n", b.kk1 - b.kk0 + 1, pn);
     exit(1);
   }
 }
@@ -386,7 +435,8 @@ void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, cons
   if (try_pcr_rb<4>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
   if (try_pcr_rb<2>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
   if (try_pcr_rb<1>(x, msk, rhs, g, omg, res_dev, accumulate, 160 * 1024)) return;
-  fprintf(stderr, "czhip: pcr_rb: a k-line of %d unknowns does not fit the 160 KiB of LDS\n", g.n);
+  if (try_pcr_rb<4, 0, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, accumulate, 0)) return;  // work arrays in global scratch: any length
+  fprintf(stderr, "czhip: pcr_rb: no kernel form took a k-line of %d unknowns\n", g.n);
   exit(1);
 }
 
@@ -433,9 +483,9 @@ void launch_pcr_maf(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, con
     if (reg(g, acc)) return true;
     if (order == 0) {
       return try_pcr_rb<4, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, ma) || try_pcr_rb<2, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 80 * 1024, ma) ||
-             try_pcr_rb<1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma);
+             try_pcr_rb<1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma) || try_pcr_rb<4, 0, 1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 0, ma);
     }
-    return try_pcr_rb<1, 1, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma);
+    return try_pcr_rb<1, 1, 1>(x, msk, rhs, g, omg, res_dev, acc, 160 * 1024, ma) || try_pcr_rb<4, 1, 1, 0, 1>(x, msk, rhs, g, omg, res_dev, acc, 0, ma);
   };
   if (order == 1) {
     if (try_pcr_lex_wg_maf(x, msk, rhs, make_pcr_geom(b, idx, pn, 0), omg, res_dev, accumulate, ma)) return;

@@ -22,6 +22,9 @@
 
 namespace czhip_internal {
 hipStream_t stream();
+// decomposed runs: the compute stream leaves k CUs per XCD to the exchange stream (CU mask); returns the reservation in force
+int reserve_comm_cus(int k);
+int comm_cus_reserved();
 void triad_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, const int* sz, const int* idx, int g);
 void bicg1_async(CZ_REAL* p, const CZ_REAL* r, const CZ_REAL* q, CZ_REAL beta, CZ_REAL omg, const int* sz, const int* idx, int g);
 void bicg2_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, CZ_REAL b, const int* sz, const int* idx, int g);

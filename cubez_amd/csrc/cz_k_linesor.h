@@ -24,22 +24,28 @@ struct PcrGeom {
   int nhalf;                    // columns of one colour per j row (upper bound)
 };
 
-// ORDER 0: one colour; ORDER 1: the columns of one diagonal (i-ist)+(j-jst) = g.color of the lexicographic order (see pcr_rb2_k).
+// ORDER 0: one colour; ORDER 1: the columns of one diagonal (i-ist)+(j-jst) = g.color of the lexicographic order; ORDER 2: all columns from
+// the old field, results into WOUT (pcr_j_esa; see pcr_rb2_k).
 // MAF = 1: the matrix comes from the metrics of the 1-D grids (cz_maf.f90:442-1560: pcr_rb_maf, pcr_maf and their _eda/_esa
 // forms): it differs from line to line, so this literal form is the only one that applies.
-template <int NW, int ORDER, int MAF, int FINAL4 = 0>
+// GS = 1: a, c, d and their successors live in a per-wave piece of GLOBAL scratch instead of LDS -- the form without a limit on the line
+// length (the reference allocates its work arrays by kx, cz_Evaluate.cpp:257-262, and has none).  A line still never leaves its wave, and
+// a wave's own stores are visible to its later loads (one CU, one L1; program order), so the wave-scope synchronisation is the same.  The
+// workgroups are persistent there (`ncol` columns dealt round-robin), the scratch is the launch's workgroups x NW lines.
+template <int NW, int ORDER, int MAF, int FINAL4 = 0, int GS = 0>
 __global__ void __launch_bounds__(64 * NW)
-pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, double* partials,
-         double* dst, int accumulate, unsigned* counter, MafArgs ma) {
+pcr_rb_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg, double* partials,
+         double* dst, int accumulate, unsigned* counter, MafArgs ma, REAL* scratch, long long ncol) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
-  REAL* base = reinterpret_cast<REAL*>(smem) + (size_t)wave * 6 * LD;
+  REAL* base = GS ? scratch + ((size_t)blockIdx.x * NW + wave) * 6 * LD : reinterpret_cast<REAL*>(smem) + (size_t)wave * 6 * LD;
   REAL* A[2] = {base, base + 3 * LD};          // [buf][a | c | d]
-  double* wsum = reinterpret_cast<double*>(reinterpret_cast<REAL*>(smem) + (size_t)NW * 6 * LD + 4);
+  double* wsum = reinterpret_cast<double*>(reinterpret_cast<REAL*>(smem) + (GS ? 0 : (size_t)NW * 6 * LD) + 4);
   wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
+  double acc = 0.0;
 
-  const long long col = (long long)blockIdx.x * NW + wave;  // column ordinal among the launch's columns
+  for (long long col = (long long)blockIdx.x * NW + wave; col < ncol; col += (long long)gridDim.x * NW) {  // (GS = 0: one column per wave)
   bool active;
   int ii = 0, jj = 0;
   if (ORDER == 0) {
@@ -53,17 +59,19 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
       ii = g.ii0 + (i1 - g.ist1);
       jj = g.jj0 + jrow;
     }
-  } else {
+  } else if (ORDER == 1) {
     const int dlo = max(0, g.color - (g.nj - 1));
     active = col < (long long)(min(g.ni - 1, g.color) - dlo + 1);
     const int io = dlo + (int)col;
     ii = g.ii0 + io, jj = g.jj0 + (g.color - io);
+  } else {
+    active = col < (long long)g.ni * g.nj;
+    ii = g.ii0 + (int)(col % g.ni), jj = g.jj0 + (int)(col / g.ni);
   }
   if (!active) ii = g.ii0, jj = g.jj0;
   const REAL r = (REAL)1.0 / (REAL)6.0;
   const size_t rowlen = (size_t)g.nkp, plane = (size_t)g.nkp * g.nip;
   const size_t c0 = (size_t)g.kk0 + (size_t)ii * rowlen + (size_t)jj * plane;  // element (kst, i, j)
-  double acc = 0.0;
 
   // ---- set-up: coefficients and source term (:545-568)
   if (active) {
@@ -188,11 +196,14 @@ pcr_rb_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, Pc
       const size_t e = c0 + k;
       const REAL pp = X[e];
       const REAL dp = (d1[k + 1] - pp) * omg * MSK[e];
-      X[e] = pp + dp;
+      if (ORDER == 2) WOUT[e] = pp + dp;
+      else X[e] = pp + dp;
       const REAL d2 = dp * dp;
       acc += (double)d2;
     }
   }
+  wave_lds_sync();  // (the next column's set-up overwrites the buffers)
+  }  // columns of this wave
   // ---- residual: partial per workgroup, fixed-order sum by the last one (write-through hand-off as in stencil_k)
   __syncthreads();
   const double sblk = block_sum<64 * NW>(acc, wsum);
@@ -394,19 +405,25 @@ pcr_coef_k(REAL* __restrict__ tab, int n, int pn, int nfin, int final4) {
 //   1  one diagonal (i-ist)+(j-jst) = g.color of the lexicographic order, in place: a column of pcr (:718-719) / pcr_esa sees
 //      the new values of its i-1 and j-1 neighbours, which lie on the diagonal before => diagonals in sequence, columns of one in parallel
 //   2  all columns from the old field, result into WOUT (pcr_j_esa :1553-1632; the caller copies back, :1655-1663)
-template <int NW, int L, int FINAL4, int ORDER>
+//   TG = 1: the table stays in global memory (read through L1 / L2: it is the same for every line, a few hundred KB at most) and LDS holds the
+//   right-hand sides only -- lines whose table does not fit LDS beside them (FP64 beyond ~640 unknowns, FP32 beyond ~1 290), up to the
+//   ~10 000 / 20 000 unknowns whose two right-hand-side buffers fill the 160 KiB.  Same operations on the same values => same bits.
+template <int NW, int L, int FINAL4, int ORDER, int TG = 0>
 __global__ void __launch_bounds__(64 * NW)
 pcr_rb2_k(REAL* X, REAL* WOUT, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS, PcrGeom g, REAL omg,
           const REAL* __restrict__ tab, int tab_len, int nfin, double* partials, double* dst, int accumulate, unsigned* counter) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = g.n, LD = n + 2;  // slot 0 and slot n+1 are the zero entries k = kst-1 / ked+1
-  REAL* T = reinterpret_cast<REAL*>(smem);
-  REAL* D = T + tab_len + (size_t)wave * 2 * L * LD;  // [buf][line][LD]
-  double* wsum = reinterpret_cast<double*>(T + tab_len + (size_t)NW * 2 * L * LD + 4);
+  REAL* Tl = reinterpret_cast<REAL*>(smem);
+  const size_t tl = TG ? 0 : (size_t)tab_len;           // words of LDS in front of the right-hand sides
+  const REAL* T = TG ? tab : Tl;                        // (TG is a compile-time constant: the address space of T is known per instantiation)
+  REAL* D = Tl + tl + (size_t)wave * 2 * L * LD;        // [buf][line][LD]
+  double* wsum = reinterpret_cast<double*>(Tl + tl + (size_t)NW * 2 * L * LD + 4);
   wsum = reinterpret_cast<double*>((reinterpret_cast<size_t>(wsum) + 15) & ~(size_t)15);
 
-  for (int i = threadIdx.x; i < tab_len; i += 64 * NW) T[i] = tab[i];
+  if (!TG)
+    for (int i = threadIdx.x; i < tab_len; i += 64 * NW) Tl[i] = tab[i];
   if (lane < 2 * L) D[lane * LD] = (REAL)0, D[lane * LD + n + 1] = (REAL)0;
   __syncthreads();
 
@@ -1460,17 +1477,20 @@ pcr_lex_wg_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict__ RHS
               // hand the line down: slot i mod nslots, free once the strip below has taken line i - nslots
               const int i = st - rlast;
               dn_seen = max(dn_seen, dn_next);  // (fetched during the step before)
+              bool slot_free = true;
               while (dn_seen < i - nslots + 1) {
                 dn_seen = (int)__hip_atomic_load(dn_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (dn_seen < i - nslots + 1 && pipe_give_up(polls, t0, spin_limit, ctl)) {
                   sh[2] = 1;
+                  slot_free = false;  // the wait was given up: the slot still holds a line the strip below has not taken -- leave it alone
                   break;
                 }
               }
               t0 = 0;
               const unsigned long long tag = (unsigned long long)(seq_base + (unsigned)i + 1u) << 32;
               unsigned long long* dstw = hb_out + (size_t)(i & smask) * NT * HW;
-              if (sizeof(REAL) == 8) {
+              if (!slot_free) {
+              } else if (sizeof(REAL) == 8) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong((double)out[q]);
                 __hip_atomic_store(dstw, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(dstw + (HW - 1), tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -71,6 +71,9 @@ __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, 
                                             const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c, const DIV& dv,
                                             unsigned mask, unsigned count_mask, double& acc) {
   Vec<V> o;
+#if defined(CZ_P2_RES_GROUP)  // tools/pair_lab A/B only: the vector's dp^2 summed in REAL, one conversion and one double add per vector
+  REAL grp = (REAL)0;
+#endif
 #pragma unroll
   for (int cc = 0; cc < V; cc++) {
     const REAL pp = pc.v[cc];
@@ -80,8 +83,17 @@ __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, 
     const REAL dp = (dv(ss - bb.v[cc]) - pp) * c.omg;
     const REAL d2 = dp * dp;
     o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;
+#if defined(CZ_P2_NO_RES)  // tools/pair_lab A/B only: no residual at all (what the accumulation costs at most)
+    (void)d2, (void)count_mask, (void)acc;
+#elif defined(CZ_P2_RES_GROUP)
+    grp += (count_mask & (1u << cc)) ? d2 : (REAL)0;
+#else
     acc += (double)((count_mask & (1u << cc)) ? d2 : (REAL)0);  // (+0.0 leaves the sum as it is)
+#endif
   }
+#if defined(CZ_P2_RES_GROUP)
+  acc += (double)grp;
+#endif
   return o;
 }
 

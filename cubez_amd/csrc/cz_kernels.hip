@@ -122,6 +122,25 @@ namespace {
 #include "cz_h_linesor.h"
 }  // namespace
 
+namespace {
+// which CU a workgroup runs on: XCC id | HW_ID (gfx9: cu_id [11:8], sh_id [12], se_id [15:13]); spins a little so that every CU gets one
+__global__ void where_k(unsigned* out, long long spin_ticks) {
+  if (threadIdx.x == 0) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    out[blockIdx.x] = ((xcc & 0xf) << 16) | (hw & 0xff00);
+  }
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < spin_ticks) {
+  }
+}
+}  // namespace
+
+namespace czhip_internal {
+int reserve_comm_cus(int k);
+}
+
 // ============================================================================================================
 // Part 2: runtime
 // ============================================================================================================
@@ -146,7 +165,8 @@ int czhip_init(int device) {
   ctx.device = device;
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
-  ctx.num_cu = prop.multiProcessorCount;
+  ctx.num_cu = ctx.num_cu_total = prop.multiProcessorCount;
+  ctx.cu_reserved = 0;
   HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
   HIP_CHECK(hipMalloc(&ctx.scal_dev, 16 * sizeof(double)));
   HIP_CHECK(hipMemset(ctx.scal_dev, 0, 16 * sizeof(double)));
@@ -174,6 +194,9 @@ int czhip_init(int device) {
     sscanf(pp, "%d,%lf,%d,%d", &w, &sec, &rows, &q);
     ctx.tune.pcr_pipe = w, ctx.tune.pipe_spin_ticks = (long long)(sec * 1e8), ctx.tune.pcr_rows = rows, ctx.tune.pcr_q = q;
   }
+  if (const char* v = getenv("CZHIP_PCR_WG_PER_CU")) ctx.tune.pcr_wg_per_cu = atoi(v);
+  if (const char* v = getenv("CZHIP_PCR_MAX_WG")) ctx.tune.pcr_max_wg = atoi(v);
+  if (const char* v = getenv("CZHIP_PCR_SLOTS")) ctx.tune.pcr_slots = atoi(v);
   const char* tu = getenv("CZHIP_TUNING");  // "threads,m,tj,pf"
   if (tu) {
     int a = 0, b = 0, c = 0, d = -1;
@@ -193,6 +216,7 @@ void czhip_finalize(void) {
   (void)hipFree(ctx.shell_partials);
   if (ctx.pcr_tab) (void)hipFree(ctx.pcr_tab);
   if (ctx.pcr_tab_perm) (void)hipFree(ctx.pcr_tab_perm);
+  if (ctx.pcr_scratch) (void)hipFree(ctx.pcr_scratch);
   if (ctx.pipe_ctl) (void)hipFree(ctx.pipe_ctl);
   ctx.pipe_ctl = nullptr, ctx.pipe_ctl_cap = 0;
   if (ctx.pipe_hb) (void)hipFree(ctx.pipe_hb);
@@ -466,6 +490,31 @@ long long czhip_selftest_fastdiv(CZ_REAL d) {
   return (long long)h;
 }
 
+// Self-test of the CU reservation of decomposed runs (reserve_comm_cus): with k CUs per XCD set aside, where do the workgroups of a launch on
+// the library's compute stream run?  per_xcd[x] receives the number of distinct CUs of XCD x that ran one; returns their total.  The
+// reservation is undone before returning.
+int czhip_selftest_cu_reserve(int k, int* per_xcd) {
+  ensure_init();
+  const int before = ctx.cu_reserved;
+  czhip_internal::reserve_comm_cus(k);
+  const int nwg = 8192;
+  unsigned* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, nwg * sizeof(unsigned)));
+  hipLaunchKernelGGL(where_k, dim3(nwg), dim3(64), 0, ctx.stream, d, 2000LL);  // 20 us each
+  HIP_CHECK(hipGetLastError());
+  std::vector<unsigned> h(nwg);
+  HIP_CHECK(hipMemcpyAsync(h.data(), d, nwg * sizeof(unsigned), hipMemcpyDeviceToHost, ctx.stream));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  HIP_CHECK(hipFree(d));
+  std::sort(h.begin(), h.end());
+  h.erase(std::unique(h.begin(), h.end()), h.end());
+  for (int x = 0; x < 8; x++) per_xcd[x] = 0;
+  for (unsigned key : h)
+    if ((key >> 16) < 8) per_xcd[key >> 16]++;
+  czhip_internal::reserve_comm_cus(before);
+  return (int)h.size();
+}
+
 // line-SOR kernel choice: form 0 = pcr_rb_k (the reference's arithmetic literally, pcr_rb only), 1 = table + d in LDS, 2 = table +
 // d in registers (default); variant = waves per workgroup * 10 + lines per wave, 0 = measured default.  Negative: keep.
 int czhip_set_pcr_mode(int form, int variant) {
@@ -493,6 +542,17 @@ double czhip_set_pcr_lex_timeout(double seconds) {
   ensure_init();
   if (seconds >= 0.0) ctx.tune.pipe_spin_ticks = (long long)(seconds * 1e8);
   return (double)ctx.tune.pipe_spin_ticks * 1e-8;
+}
+
+// pcr_lex_wg_k launch limits (test aid; negative: keep, 0: the launcher's choice): workgroups per CU, workgroups in all, lines per hand-off
+// ring (rounded up to a power of two).  The launcher's own choice of the ring always lets the sweep finish; a forced small ring with few
+// workgroups does not -- the waits inside the kernel then run out and the sweep reports a NaN residual (tests/test_gpu_kernels.py).
+int czhip_set_pcr_lex_limits(int wg_per_cu, int max_wg, int slots) {
+  ensure_init();
+  if (wg_per_cu >= 0) ctx.tune.pcr_wg_per_cu = wg_per_cu;
+  if (max_wg >= 0) ctx.tune.pcr_max_wg = max_wg;
+  if (slots >= 0) ctx.tune.pcr_slots = slots;
+  return 0;
 }
 
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
@@ -861,6 +921,36 @@ hipStream_t stream() {
   ensure_init();
   return ctx.stream;
 }
+
+// Decomposed runs: the compute stream gives up k CUs of every XCD, so that what the exchange stream launches while an interior sweep
+// fills the chip -- shell slabs, pack / unpack and above all RCCL's send/recv kernels, which need CUs of their own for as long as a
+// message is in flight -- never waits for a workgroup slot.  The interior launch of the two-stage pass is sized to fill its slots in ONE
+// round with workgroups that live as long as the launch (pair_tj_model), so a stream priority alone frees nothing before the end.
+// Mechanism: the stream's queue gets a CU mask (hipExtStreamCreateWithCUMask).  Bit i of the mask is CU i / 8 of XCD i % 8 on this part
+// (tools/cumask_lab.hip `reserve`: the masked stream runs on 32 - k CUs of every XCD and never on the others; czhip_selftest_cu_reserve
+// checks it on the box it runs on).  Everything sized from the CU count (chunk lengths of the sweeps, resident workgroups of the line
+// solvers) follows ctx.num_cu.  Returns the reservation in force.
+int reserve_comm_cus(int k) {
+  ensure_init();
+  const int per_xcd = ctx.num_cu_total / 8;
+  if (ctx.num_cu_total % 8 != 0 || per_xcd < 4) k = 0;  // not the 8-XCD part this was measured on
+  k = std::max(0, std::min(k, per_xcd / 2));
+  if (k == ctx.cu_reserved) return k;
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  HIP_CHECK(hipStreamDestroy(ctx.stream));
+  if (k == 0) {
+    HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+  } else {
+    std::vector<uint32_t> mask((size_t)(ctx.num_cu_total + 31) / 32, 0u);
+    for (int i = 0; i < ctx.num_cu_total; i++)
+      if (i / 8 < per_xcd - k) mask[(size_t)i / 32] |= 1u << (i % 32);
+    HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx.stream, (uint32_t)mask.size(), mask.data()));
+  }
+  ctx.cu_reserved = k;
+  ctx.num_cu = ctx.num_cu_total - 8 * k;
+  return k;
+}
+int comm_cus_reserved() { return ctx.cu_reserved; }
 void triad_async(REAL* z, const REAL* x, const REAL* y, REAL a, const int* sz, const int* idx, int g) {
   launch_ewise<OP_TRIAD>(z, x, y, a, (REAL)0, make_box(sz, idx, g));
 }

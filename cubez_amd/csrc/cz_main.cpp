@@ -5,9 +5,9 @@
 // Multi-GPU: one process per GPU.  Instead of mpirun/MPI_Init (main.cpp:33-35) the ranks are started by any launcher
 // that exports RANK, WORLD_SIZE and LOCAL_RANK (e.g. `python -m torch.distributed.run --no-python ...`); rank 0
 // writes the RCCL unique id to $CZ_COMM_ID_FILE (default /tmp/cz_comm_id.$MASTER_PORT) and the others read it.
-// The file starts with a job key -- $CZ_JOB_ID, or MASTER_ADDR:MASTER_PORT:<pid of the launcher, the ranks' common parent> --
-// and a reader keeps polling until the key is its own: a file left behind by an earlier job on the same port is never
-// joined.  Rank 0 removes any old file first and creates the new one exclusively, mode 0600 (no symlink is followed).
+// The file starts with a job key -- $CZ_JOB_ID, or MASTER_ADDR:MASTER_PORT -- and the time rank 0 wrote it; a reader keeps polling until
+// the key is its own and the record is not older than the reader itself (less a minute): a file left behind by an earlier job on the same
+// port is not joined.  Rank 0 removes any old file first and creates the new one exclusively, mode 0600 (no symlink is followed).
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -51,15 +52,22 @@ int main(int argc, char* argv[]) {
     const int nb = cz_comm_unique_id_bytes();
     std::vector<char> id(nb);
     const std::string path = id_file();
+    // The record: job key, creation time, id.  Job key: $CZ_JOB_ID, else MASTER_ADDR:MASTER_PORT -- values every rank of a job shares
+    // whatever started it (one launcher, a wrapper script per rank, several nodes with the file on a shared file system).  A file a dead job
+    // left behind on the same address and port is told apart by its age: rank 0 stamps the record, a reader takes a record only when the
+    // stamp is not older than its own start minus a minute (ranks of one job start together; set CZ_JOB_ID where that does not hold).
     char key[256];
     if (getenv("CZ_JOB_ID")) snprintf(key, sizeof(key), "%s", getenv("CZ_JOB_ID"));
-    else snprintf(key, sizeof(key), "%s:%s:%ld", getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "-", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0", (long)getppid());
-    std::vector<char> rec(sizeof(key) + nb, 0);
+    else snprintf(key, sizeof(key), "%s:%s", getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "-", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    const long long started = (long long)time(nullptr);
+    std::vector<char> rec(sizeof(key) + sizeof(long long) + nb, 0);
     bool ok = true;
     if (myRank == 0) {
       cz_comm_get_unique_id(id.data());
+      const long long stamp = (long long)time(nullptr);
       memcpy(rec.data(), key, sizeof(key));
-      memcpy(rec.data() + sizeof(key), id.data(), nb);
+      memcpy(rec.data() + sizeof(key), &stamp, sizeof(stamp));
+      memcpy(rec.data() + sizeof(key) + sizeof(stamp), id.data(), nb);
       const std::string tmp = path + ".tmp";
       unlink(path.c_str());  // a file an earlier job left behind
       unlink(tmp.c_str());
@@ -73,13 +81,17 @@ int main(int argc, char* argv[]) {
       for (int tries = 0; tries < 600 && !ok; tries++) {  // 60 s
         const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
         if (fd >= 0) {
-          if (read(fd, rec.data(), rec.size()) == (ssize_t)rec.size() && !strncmp(rec.data(), key, sizeof(key))) ok = true;
+          long long stamp = 0;
+          if (read(fd, rec.data(), rec.size()) == (ssize_t)rec.size() && !strncmp(rec.data(), key, sizeof(key))) {
+            memcpy(&stamp, rec.data() + sizeof(key), sizeof(stamp));
+            if (stamp >= started - 60) ok = true;
+          }
           close(fd);
         }
         if (!ok) usleep(100000);
       }
-      if (ok) memcpy(id.data(), rec.data() + sizeof(key), nb);
-      else printf("\trank %d: no communicator id for job %s in %s after 60 s\n", myRank, key, path.c_str());
+      if (ok) memcpy(id.data(), rec.data() + sizeof(key) + sizeof(long long), nb);
+      else printf("\trank %d: no communicator id for job '%s' in %s after 60 s (the key is $CZ_JOB_ID or MASTER_ADDR:MASTER_PORT and must be the same on every rank)\n", myRank, key, path.c_str());
     }
     if (!ok) {
       czhip_finalize();

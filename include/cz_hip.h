@@ -248,7 +248,15 @@ int czhip_set_pcr_lex(int one_launch, int groups, int rows_per_thread);
 /* Bound, in seconds, of every wait of one workgroup for another inside the one-launch sweep (default 2; negative = keep); returns the bound in
  * force.  If a wait runs out, every workgroup leaves and the residual of that sweep is NaN. */
 double czhip_set_pcr_lex_timeout(double seconds);
+/* Launch limits of the one-launch sweep (test aid; negative = keep, 0 = chosen per launch): workgroups per CU, workgroups in all, lines per
+ * hand-off ring between two rows (rounded up to a power of two).  The launcher's own ring size lets the sweep finish however few of its
+ * workgroups the device keeps resident; a ring forced small with few workgroups cannot, and the sweep then ends as described above. */
+int czhip_set_pcr_lex_limits(int wg_per_cu, int max_wg, int slots);
 int czhip_use_t2(void);
+/* Decomposed runs keep k CUs of every XCD free of the sweeps (CZ_COMM_CUS, default 2) so that RCCL's send/recv kernels run while an interior
+ * sweep fills the chip.  Self-test: with k CUs set aside, per_xcd[0..7] = the CUs of each XCD a launch on the compute stream ran on
+ * (expected 32 - k each); returns their total. */
+int czhip_selftest_cu_reserve(int k, int* per_xcd);
 /* self-test: numerators (of 2^32) whose quotient by d in the two-stage pass differs from the IEEE division (expected 0); -1 = divisor not eligible */
 long long czhip_selftest_fastdiv(CZ_REAL d);
 
@@ -285,7 +293,7 @@ void cz_set_quiet(cz_handle*, int quiet);     /* suppress stdout / history file 
 double cz_last_solve_seconds(const cz_handle*);
 /* What a (multi-GPU) run decided: what = 0 ranks, 1 every brick takes the fused pass, 2 shell slabs of this brick, 3 overlapped exchange,
  * 4 the last stationary solve ran its residual all-reduce + test one pass behind, 5 ranks of the RCCL communicator (ncclCommCount; 0 = LOCAL
- * test transport or single process). */
+ * test transport or single process), 6 CUs per XCD the sweeps leave to the exchange stream (CZ_COMM_CUS). */
 int cz_info(const cz_handle*, int what);
 double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
 

@@ -851,3 +851,51 @@ def test_hoisted_division_is_the_ieee_division(prec):
     for d in (6.0, 6.2, 6.3, -6.0, 7.3e-4, 1.9e7):
         assert h.lib.czhip_selftest_fastdiv(d) == 0, d
     assert h.lib.czhip_selftest_fastdiv(3.0e38 if prec == "f32" else 1e300) == -1
+
+
+def test_cu_reservation_keeps_the_sweeps_off_the_reserved_cus():
+    """Decomposed runs give k CUs of every XCD to the exchange stream (CU mask on the compute stream, reserve_comm_cus): a launch on the
+    compute stream then runs on exactly 32 - k CUs of each of the 8 XCDs -- on this box, not only on the one the mask layout was measured on."""
+    import ctypes as C
+    h = _hip("f32")
+    per = (C.c_int * 8)()
+    for k in (0, 2, 4):
+        tot = h.lib.czhip_selftest_cu_reserve(k, per)
+        assert list(per) == [32 - k] * 8 and tot == 8 * (32 - k), (k, tot, list(per))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_lexicographic_line_sor_with_few_resident_workgroups(prec):
+    """the one-launch sweep must finish however few of its workgroups the device keeps resident.  Four workgroups for 60 rows:
+    the launcher sizes the hand-off rings so that the strip at the head of the window can always end (ring >= the whole row when it may
+    count on one resident workgroup) -- same bits as the launch-per-diagonal form.  The same four workgroups with a ring forced to four
+    lines cannot finish: every wait is bounded, the sweep returns, its residual is NaN."""
+    import ctypes as C
+    ni, nj, nk = 70, 62, 66
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(11)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    h.lib.czhip_set_pcr_lex_timeout.restype = C.c_double
+    h.lib.czhip_set_pcr_lex_timeout.argtypes = [C.c_double]
+    before = h.lib.czhip_set_pcr_lex_timeout(-1.0)
+    try:
+        assert h.lib.czhip_set_pcr_lex(1, 0, 1) == 0
+        h.lib.czhip_set_pcr_lex_limits(1, 4, 0)  # four workgroups, the launcher's ring
+        x1, dx = x0.copy(), h.alloc(sz, x0)
+        for it in range(2):
+            r1, r2 = ko.pcr(sz, idx, pn, x1, msk, rhs, 1.3), h.pcr(sz, idx, pn, dx, dm, dr, 1.3)
+            assert r2 == r2 and _beq(dx.get(), x1), it
+        h.lib.czhip_set_pcr_lex_limits(1, 4, 4)  # ... and a ring of four lines: 4 x 4 < 68 lines per row
+        h.lib.czhip_set_pcr_lex_timeout(0.3)
+        r = h.pcr(sz, idx, pn, h.alloc(sz, x0), dm, dr, 1.3)
+        assert r != r, r  # NaN: the sweep is void, and the call came back
+    finally:
+        h.lib.czhip_set_pcr_lex_limits(0, 0, 0)
+        h.lib.czhip_set_pcr_lex_timeout(before)

