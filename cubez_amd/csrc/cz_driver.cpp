@@ -85,6 +85,9 @@ CZ::CZ() {
 
 CZ::~CZ() {
   czhip_sync();
+  // give the CUs reserved for the exchange stream back: the library context outlives this object, and a queue with a CU mask that is still
+  // alive at process exit crashed rocprofv3's finalisation (gpurun_out/probe_c, round 3)
+  if (comm_cus > 0) reserve_comm_cus(0);
   REAL_TYPE* arrs[] = {WRK, WRK2, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt, MSK};
   if (d_xc) (void)hipFree(d_xc);
   if (d_yc) (void)hipFree(d_yc);
@@ -320,7 +323,8 @@ int CZ::Setup(int argc, char** argv) {
     // Bricks of an uneven division can differ (k-extent multiple of the vector width or not): agree on the weakest.
     int idx1[6];
     for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
-    const double mine = pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE, cf[6]) ? 0.0 : 1.0;
+    // (the MAF flavour of the pass needs a little more LDS -- the table of the k metric terms -- and is probed as well where it will run)
+    const double mine = (pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE, cf[6], 0) && (!SW_maf || pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE, cf[6], 1))) ? 0.0 : 1.0;
     pairs_ok = comm_allreduce_max_host(comm, mine) == 0.0;
     if (getenv("CZ_COMM_DEBUG")) {  // one line per rank on stderr: what a multi-GPU run decided
       int dev = -1;
@@ -598,21 +602,21 @@ void CZ::plan_overlap() {
 //   comm_stream : wait ev_src -> shell slabs -> pack, send/recv, unpack -> [ev_comm]
 // The slabs and the interior write disjoint cells of dst and read only src; the unpack writes ghost cells of dst.
 // Returns false (nothing launched) when the split does not apply; the caller then takes the unsplit path.
-bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot) {
+bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot, const MafPtrs* maf) {
   if (n_shell == 0) return false;
   double* rs = res_slot ? res_slot : d_res;
   const int gc = GUIDE;
   hipStream_t st = stream();
-  if (!pair_probe(src, dst, B, size, interior, interior1, gc, cf[6])) return false;
+  if (!pair_probe(src, dst, B, size, interior, interior1, gc, cf[6], maf ? 1 : 0)) return false;
   // The shell slabs and the interior read src and write disjoint cells of dst: they run side by side (round 2; round 1 ran the slabs first
   // on the compute stream, 49 us per pass of a corner brick during which the GPU was mostly idle).  The slabs go first on the exchange
   // stream, which has the higher priority, so the exchange starts as early as before.
   HIP_CHECK(hipEventRecord(ev_src, st));  // src is complete (and nobody reads dst any more) once everything issued so far on st is done
   HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_src, 0));
-  pair_shell_async(src, dst, B, size, idx1, shell_boxes, n_shell, gc, cf, ac1, rb, skip, comm_stream);
+  pair_shell_async(src, dst, B, size, idx1, shell_boxes, n_shell, gc, cf, ac1, rb, skip, comm_stream, maf);
   if (!comm_halo2(comm, dst, skip, comm_stream)) return false;
   HIP_CHECK(hipEventRecord(ev_comm, comm_stream));
-  if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, rs, 0, skip)) {
+  if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, rs, 0, skip, maf)) {
     printf("error : interior launch refused after a successful probe\n");
     exit(1);
   }
@@ -654,16 +658,65 @@ bool CZ::sweep_failed(const char* solver) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// How the sweeps of a stationary solve (or of a preconditioner solve) are executed.  Decided ONCE, before the loop, from what is known
+// then -- solver flavour, iteration budget, whether convergence is tested, the geometry probes of the two-stage pass, what the ranks
+// agreed on at set-up -- and then carried out by the loop without further choices.  (Round 2 chose among five launch paths inside the loop,
+// iteration by iteration, with fallbacks from one to the next.)
+//   kind     SINGLE  one sweep (one colour) per launch, one-layer exchange after each                         cz_Poisson.cpp:58-63, 205-215
+//            WHOLE   two Jacobi sweeps / one red-black iteration per pass over memory (jacobi2p_k), two-layer exchange after the pass
+//            SPLIT   the same pass as shell slabs + interior; the exchange runs on the exchange stream beside the interior (decomposed runs)
+//   lag      SPLIT + convergence test: residual all-reduce and test one pass behind, on the exchange stream; three rotating buffers
+//   zero_start  the start vector is identically zero and the first pass takes it as a literal (first pair of a preconditioner solve)
+// What the ranks of a decomposed run must agree on is the sequence of collectives: the exchange depth (SINGLE against the fused kinds --
+// `pairs_ok`, all-reduced at set-up) and the iteration at which they stop (the poll below).  WHOLE against SPLIT and lag against no lag may
+// differ from brick to brick (a brick too thin to split): the same exchanges and all-reduces in the same order either way.
+CZ::PassPlan CZ::plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, bool converge_check, bool x_is_zero, bool rb) {
+  PassPlan p;
+  p.maf = (s_type == LS_JACOBI_MAF || s_type == LS_SOR2SMA_MAF) ? 1 : 0;
+  p.rb = rb ? 1 : 0;
+  p.comm_cus = comm_cus;
+  int idx1[6];
+  for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
+  bool fused = czhip_use_t2() != 0 && (rb || itr_max >= 2);
+  if (fused) {
+    const bool mine = pair_probe(X, WRK, B, size, innerFidx, idx1, GUIDE, cf[6], p.maf) != 0;
+    if (numProc > 1 && pairs_ok && !mine) {  // (pairs_ok was probed on P / WRK / RHS: same geometry, same alignment)
+      fprintf(stderr, "cz rank %d: the fused pass the ranks agreed on at set-up is refused for this solve\n", myRank);
+      exit(1);
+    }
+    fused = numProc > 1 ? pairs_ok : mine;
+  }
+  if (fused) {
+    p.kind = PassPlan::WHOLE, p.depth = 2;
+    if (numProc > 1 && n_shell > 0 && pair_probe(X, WRK, B, size, interior, interior1, GUIDE, cf[6], p.maf)) p.kind = PassPlan::SPLIT;
+    p.lag = (p.kind == PassPlan::SPLIT && converge_check && lag_reduce != 0) ? 1 : 0;
+    p.buffers = p.lag ? 3 : 2;
+    p.zero_start = (!rb && x_is_zero && numProc == 1 && !converge_check && !p.maf && itr_max >= 2) ? 1 : 0;
+  }
+  if (getenv("CZ_COMM_DEBUG") && numProc > 1 && (p.kind != last_plan.kind || p.lag != last_plan.lag || p.maf != last_plan.maf || p.rb != last_plan.rb || !plan_printed)) {
+    static const char* const kinds[] = {"single sweeps", "fused pass, whole box", "fused pass, shell + interior (exchange overlapped)"};
+    fprintf(stderr, "cz rank %d: %s plan: %s, exchange depth %d, lagged reduce %d, buffers %d, zero start %d, maf %d, comm CUs per XCD %d\n", myRank,
+            rb ? "RBSOR" : "JACOBI", kinds[p.kind], p.depth, p.lag, p.buffers, p.zero_start, p.maf, p.comm_cus);
+    plan_printed = true;
+  }
+  last_plan = p;
+  return p;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // cz_Poisson.cpp:30-82
 int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check,
                bool x_is_zero) {
-  const bool maf = (s_type == LS_JACOBI_MAF);  // cz_Poisson.cpp:45-53
   const int gc = GUIDE;
   hipStream_t st = stream();
+  const PassPlan plan = plan_pass(X, B, s_type, itr_max, converge_check, x_is_zero, false);
+  const bool maf = plan.maf != 0;  // cz_Poisson.cpp:45-53
+  const MafPtrs mp{d_xc, d_yc, d_zc, nullptr};
+  const MafPtrs* mpp = maf ? &mp : nullptr;
   // ping-pong partner: same guide cells / Dirichlet faces as X
   sync_wrk_shell(X);
   REAL_TYPE* buf[3] = {X, WRK, nullptr};
-  int nbuf = 2;
+  const int nbuf = plan.buffers;
   const int* skip = nullptr;
   reset_ticket();
   if (converge_check) {
@@ -671,31 +724,32 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     HIP_CHECK(hipMemsetAsync(d_flag, 0, 4 * sizeof(int), st));  // flag, iteration, the two snapshots of the lagged mode
     skip = d_flag;
   }
-  // Single-domain runs apply the sweeps two at a time (czhip_jacobi2_async: temporal blocking, the intermediate field
-  // stays on chip).  Every launch is remembered so that the state at the converged iteration can be produced exactly.
+  // Fused passes apply the sweeps two at a time (temporal blocking, the intermediate field stays on chip).  Every launch is remembered so
+  // that the state at the converged iteration can be produced exactly.
   struct Launch {
     int first_itr, nsweep, src;
   };
   std::vector<Launch> launches;
-  // (the MAF flavour forms pairs in single-domain runs only: the shell kernel of the overlapped exchange has no MAF form)
-  bool can_pair = czhip_use_t2() != 0 && itr_max >= 2 && pairs_ok && (!maf || numProc == 1);
   int idx1[6];  // index range of the first sweep of a pair: one layer into the ghost cells across rank-internal faces
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
-  if (can_pair && numProc > 1) {
+  if (plan.depth == 2 && numProc > 1) {
     // the pair reads two ghost layers (and the edge cells) of X and one of B
     if (!Comm_S2(X) || !Comm_S2(B)) return 0;
     sync_wrk_shell(X);
   }
-  // Decomposed, checked runs: the residual all-reduce and the convergence test of pass n run on the exchange stream while pass n+1
-  // is being swept (one pass of lag: pass n+2 waits for the test of pass n).  A pass may therefore run beyond convergence once; with
-  // THREE rotating buffers it cannot touch the source or the destination of the converged pass, so the exact-iteration fix-up below
-  // still finds both.
-  const bool lag = can_pair && numProc > 1 && converge_check && n_shell > 0 && lag_reduce != 0;
-  if (lag) {
+  // Lagged mode (decomposed, checked runs): the residual all-reduce and the convergence test of pass n run on the exchange stream while
+  // pass n+1 is being swept (pass n+2 waits for the test of pass n).  A pass may therefore run beyond convergence once; with THREE rotating
+  // buffers it cannot touch the source or the destination of the converged pass, so the exact-iteration fix-up below still finds both.
+  if (plan.lag) {
     if (!WRK2) WRK2 = czhip_alloc_s3d(size);
     copy_shell_async(WRK2, X, size, innerFidx, gc);
     buf[2] = WRK2;
-    nbuf = 3;
+  }
+  if (x_is_zero && !plan.zero_start) {
+    // the caller skipped its blas_clear_ (cz_Poisson.cpp:405, 441) and this solve does not take the zero as a literal: clear now
+    // (guide cells / faces are zero already)
+    const size_t nbytes = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
+    HIP_CHECK(hipMemsetAsync(X, 0, nbytes, st));
   }
   hipEvent_t ev[POLL_SLOTS];
   int npoll = 0, cur = 0;
@@ -705,7 +759,8 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     REAL_TYPE* src = buf[cur];
     REAL_TYPE* dst = buf[(cur + 1) % nbuf];
     int done = 0;
-    if (lag && itr + 1 <= itr_max) {
+    const bool pass = plan.kind != PassPlan::SINGLE && itr + 1 <= itr_max;
+    if (pass && plan.kind == PassPlan::SPLIT && plan.lag) {
       const int p = (int)launches.size();
       if (p >= 2) HIP_CHECK(hipStreamWaitEvent(st, ev_chk[p & 1], 0));  // the test of pass p-2
       double* rs = d_res + ((p & 1) ? 10 : 0);
@@ -713,57 +768,48 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       // pass p is over): every workgroup of the pass, its pack and its unpack take the same decision.  The live flag d_flag[0] may be
       // set by the test of pass p-1 while pass p is running.
       int* snap = d_flag + 2 + (p & 1);
-      if (pair_overlapped(src, dst, B, idx1, -1, snap, rs)) {
-        done = 2;
-        HIP_CHECK(hipEventRecord(ev_int, st));
-        HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
-        if (!comm_allreduce_sum(comm, rs, 2, comm_stream)) return 0;                                            // :67, both sweeps
-        check2_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1, snap);               // :69-77
-        HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
-      }
-    }
-    if (!done && x_is_zero && itr == 1) {
-      // start vector identically zero (preconditioner): neither cleared in memory nor read -- if the fused kernel takes it
-      if (can_pair && itr + 1 <= itr_max && !converge_check)
-        done = 2 * czhip_jacobi2_from_zero_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res);
-      if (done) {
-        if (numProc > 1 && !Comm_S2(dst, skip)) return 0;
-      } else {
-        // not taken (geometry, tuning): do the blas_clear_ the caller skipped (guide cells / faces are zero already)
-        const size_t nbytes = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
-        HIP_CHECK(hipMemsetAsync(src, 0, nbytes, st));
-      }
-    }
-    if (lag && !done) {  // an odd last sweep (or a refused split): the tests still in flight on the exchange stream come first
-      HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
-      HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
-    }
-    if (!done && can_pair && itr + 1 <= itr_max && numProc > 1 && pair_overlapped(src, dst, B, idx1, -1, skip)) {
-      done = 2;  // :58 twice, :63 hidden behind the interior
+      if (!pair_overlapped(src, dst, B, idx1, -1, snap, rs, mpp)) return 0;  // :58 twice, :63 hidden behind the interior
+      HIP_CHECK(hipEventRecord(ev_int, st));
+      HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
+      if (!comm_allreduce_sum(comm, rs, 2, comm_stream)) return 0;                                            // :67, both sweeps
+      check2_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1, snap);               // :69-77
+      HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
+      done = 2;
+    } else if (pass && plan.kind == PassPlan::SPLIT) {
+      if (!pair_overlapped(src, dst, B, idx1, -1, skip, nullptr, mpp)) return 0;
       if (converge_check) {
         if (!Comm_SUM_dev(d_res, 2, skip)) return 0;
         czhip_check2_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
-    }
-    if (!done && can_pair && itr + 1 <= itr_max) {
+      done = 2;
+    } else if (pass) {  // the whole inner box in one launch
       const bool in_kernel_check = converge_check && numProc == 1;
-      if (maf)
-        done = 2 * pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, -1, d_res, res_normal, eps, itr,
+      int launched;
+      if (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner): neither cleared in memory nor read
+        launched = czhip_jacobi2_from_zero_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res);
+      else if (maf)
+        launched = pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, -1, d_res, res_normal, eps, itr,
                                   in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :45-53 twice
       else
-        done = 2 * czhip_jacobi2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res, res_normal, eps, itr,
+        launched = czhip_jacobi2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res, res_normal, eps, itr,
                                        in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :58 + :67-77, twice
-      if (!done) {
-        can_pair = false;
-      } else if (numProc > 1) {
+      if (!launched) {
+        printf("error : fused pass refused after a successful probe\n");
+        exit(1);
+      }
+      if (numProc > 1) {
         if (!Comm_S2(dst, skip)) return 0;  // :63, two layers once per pair
         if (converge_check) {
           if (!Comm_SUM_dev(d_res, 2, skip)) return 0;  // :67 for both sweeps in one all-reduce
           czhip_check2_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
         }
       }
-    }
-    if (!done) {
+      done = 2;
+    } else {  // one sweep: the SINGLE plan, or the odd last sweep of a fused one
+      if (plan.lag) {  // the tests still in flight on the exchange stream come first
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
+        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
+      }
       const bool fused_check = converge_check && numProc == 1;  // no all-reduce between sweep and test: one launch
       if (maf)
         jacobi_maf_async(src, dst, B, size, innerFidx, gc, d_xc, d_yc, d_zc, ac1, d_res, skip, fused_check ? 1 : 0, res_normal, eps,
@@ -788,7 +834,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       // lagging, non-blocking view of the flag: look at the copy issued two polls ago
       const int slot = npoll % POLL_SLOTS;
       if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
-      if (lag) {
+      if (plan.lag) {
         // every rank must read the same flag here (they all stop issuing passes at the same one): the copy follows the tests of
         // all passes issued so far, which run on the other stream
         HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
@@ -811,8 +857,8 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     }
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
-  if (lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
-  last_lag = lag ? 1 : 0;
+  if (plan.lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
+  last_lag = plan.lag;
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
 
   // which buffer holds the iterate of the last executed sweep?
@@ -853,9 +899,12 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
 
 // cz_Poisson.cpp:159-235
 int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
-  const bool maf = (s_type == LS_SOR2SMA_MAF);  // cz_Poisson.cpp:190-200
   const int gc = GUIDE;
   hipStream_t st = stream();
+  const PassPlan plan = plan_pass(X, B, s_type, itr_max, converge_check, false, true);
+  const bool maf = plan.maf != 0;  // cz_Poisson.cpp:190-200
+  const MafPtrs mp{d_xc, d_yc, d_zc, nullptr};
+  const MafPtrs* mpp = maf ? &mp : nullptr;
   const int* skip = nullptr;
   reset_ticket();
   if (converge_check) {
@@ -868,26 +917,24 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   int ip = 0;
   if (numProc > 1) ip = (head[0] + head[1] + head[2] + 1 + innerFidx[K_minus]) % 2;
 
-  // Preferred form: the whole iteration (colour 0, then colour 1) in ONE pass over memory, out of place X <-> WRK
-  // (czhip_rbsor2_async); decomposed runs then exchange two ghost layers once per iteration.  Fallback: the reference's
-  // two in-place colour launches with an exchange after each colour.
-  bool fused = czhip_use_t2() != 0 && pairs_ok && (!maf || numProc == 1);
+  // Fused plans: the whole iteration (colour 0, then colour 1) in ONE pass over memory, out of place X <-> WRK; decomposed runs then
+  // exchange two ghost layers once per iteration.  SINGLE: the reference's two in-place colour launches with an exchange after each colour.
+  const bool fused = plan.kind != PassPlan::SINGLE;
   int idx1[6];
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f] + ((nID[f] >= 0) ? ((f & 1) ? 1 : -1) : 0);
   REAL_TYPE* buf[3] = {X, WRK, nullptr};
-  int cur = 0, n_fused = 0, nbuf = 2;
+  const int nbuf = plan.buffers;
+  int cur = 0, n_fused = 0;
   if (fused) {
     if (numProc > 1 && (!Comm_S2(X) || !Comm_S2(B))) return 0;
     sync_wrk_shell(X);
   }
-  // decomposed, checked runs: residual all-reduce + test one iteration behind on the exchange stream, three rotating buffers
-  // (see CZ::JACOBI); the iterate of iteration k is in buf[k % nbuf]
-  const bool lag = fused && numProc > 1 && converge_check && n_shell > 0 && lag_reduce != 0;
-  if (lag) {
+  // lagged mode: residual all-reduce + test one iteration behind on the exchange stream, three rotating buffers (see CZ::JACOBI); the
+  // iterate of iteration k is in buf[k % nbuf]
+  if (plan.lag) {
     if (!WRK2) WRK2 = czhip_alloc_s3d(size);
     copy_shell_async(WRK2, X, size, innerFidx, gc);
     buf[2] = WRK2;
-    nbuf = 3;
   }
   hipEvent_t ev[POLL_SLOTS];
   int npoll = 0;
@@ -895,61 +942,42 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   int itr;
   for (itr = 1; itr <= itr_max && !stop; itr++) {
     const bool in_kernel_check = converge_check && numProc == 1;
-    bool done = false;
-    if (lag && fused) {
+    REAL_TYPE* src = buf[cur];
+    REAL_TYPE* dst = buf[(cur + 1) % nbuf];
+    if (plan.kind == PassPlan::SPLIT && plan.lag) {
       const int p = itr - 1;
       if (p >= 2) HIP_CHECK(hipStreamWaitEvent(st, ev_chk[p & 1], 0));  // the test of iteration itr-2
       double* rs = d_res + ((p & 1) ? 10 : 0);
       int* snap = d_flag + 2 + (p & 1);  // the flag as the test of iteration itr-2 left it (see CZ::JACOBI)
-      if (pair_overlapped(buf[cur], buf[(cur + 1) % nbuf], B, idx1, rb_par(gc, innerFidx, ip), snap, rs)) {
-        flop += 18.0 * npts();
-        HIP_CHECK(hipEventRecord(ev_int, st));
-        HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
-        if (!comm_allreduce_sum(comm, rs, 1, comm_stream)) return 0;
-        check_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1, snap);
-        HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
-        cur = (cur + 1) % nbuf;
-        n_fused++;
-        done = true;
-      } else {  // the split was refused: the tests in flight come first, then the paths below
-        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
-        HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
-      }
-    }
-    if (!done && fused && numProc > 1 && pair_overlapped(buf[cur], buf[(cur + 1) % nbuf], B, idx1, rb_par(gc, innerFidx, ip), skip)) {
-      flop += 18.0 * npts();
+      if (!pair_overlapped(src, dst, B, idx1, rb_par(gc, innerFidx, ip), snap, rs, mpp)) return 0;
+      HIP_CHECK(hipEventRecord(ev_int, st));
+      HIP_CHECK(hipStreamWaitEvent(comm_stream, ev_int, 0));
+      if (!comm_allreduce_sum(comm, rs, 1, comm_stream)) return 0;
+      check_on_stream(comm_stream, rs, res_normal, eps, itr, d_hist, d_flag, d_flag + 1, snap);
+      HIP_CHECK(hipEventRecord(ev_chk[p & 1], comm_stream));
+    } else if (plan.kind == PassPlan::SPLIT) {
+      if (!pair_overlapped(src, dst, B, idx1, rb_par(gc, innerFidx, ip), skip, nullptr, mpp)) return 0;
       if (converge_check) {
         if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
         czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
-      cur = (cur + 1) % nbuf;
-      n_fused++;
-      done = true;
-    }
-    if (fused && !done) {
-      REAL_TYPE* src = buf[cur];
-      REAL_TYPE* dst = buf[(cur + 1) % nbuf];
+    } else if (plan.kind == PassPlan::WHOLE) {
       const int launched = maf ? pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, ip, d_res, res_normal, eps, itr,
                                                 in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip)  // :190-200
                                : czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
                                                     in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :205-209 (+ :218-230)
-      if (launched) {
-        flop += (maf ? 66.0 : 18.0) * npts();
-        if (numProc > 1) {
-          if (!Comm_S2(dst, skip)) return 0;  // :215
-          if (converge_check) {
-            if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
-            czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
-          }
-        }
-        cur = (cur + 1) % nbuf;
-        n_fused++;
-        done = true;
-      } else {
-        fused = false;  // geometry not supported: nothing was launched, X is still the current iterate
+      if (!launched) {
+        printf("error : fused red-black iteration refused after a successful probe\n");
+        exit(1);
       }
-    }
-    if (!done) {
+      if (numProc > 1) {
+        if (!Comm_S2(dst, skip)) return 0;  // :215
+        if (converge_check) {
+          if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
+          czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
+        }
+      }
+    } else {
       for (int color = 0; color < 2; color++) {  // :205-209
         if (maf)
           rbsor_maf_async(X, B, size, innerFidx, gc, d_xc, d_yc, d_zc, ip, color, ac1, d_res, color, skip,
@@ -959,7 +987,6 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
                                     d_flag, d_flag + 1);
         else
           czhip_rbsor_async(X, B, size, innerFidx, gc, cf, ip, color, ac1, d_res, color, skip);
-        flop += 9.0 * npts();
         // the reference exchanges once per iteration (:215); exchanging after each colour makes the decomposed run
         // identical to the single-domain one
         if (!Comm_S(X, skip)) return 0;
@@ -969,10 +996,15 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
         czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
     }
+    flop += (maf ? 66.0 : 18.0) * npts();
+    if (fused) {
+      cur = (cur + 1) % nbuf;
+      n_fused++;
+    }
     if (converge_check && itr % POLL_EVERY == 0 && itr < itr_max) {
       const int slot = npoll % POLL_SLOTS;
       if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
-      if (lag) {  // the same flag on every rank: after the tests of all iterations issued so far (see CZ::JACOBI)
+      if (plan.lag) {  // the same flag on every rank: after the tests of all iterations issued so far (see CZ::JACOBI)
         HIP_CHECK(hipStreamWaitEvent(st, ev_chk[0], 0));
         HIP_CHECK(hipStreamWaitEvent(st, ev_chk[1], 0));
       }
@@ -989,8 +1021,8 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
     }
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
-  if (lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
-  last_lag = lag ? 1 : 0;
+  if (plan.lag) HIP_CHECK(hipStreamSynchronize(comm_stream));  // the last tests
+  last_lag = plan.lag;
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
   if (n_fused > 0) {
     // out-of-place iterations: the iterate of iteration k is in buf[k % nbuf] (launches after convergence were no-ops, or -- lagged
@@ -1623,6 +1655,9 @@ int cz_info(const cz_handle* h, int what) {
     case 4: return c.last_lag;
     case 5: return comm_transport_ranks(c.comm);
     case 6: return c.comm_cus;
+    case 7: return c.last_plan.kind;
+    case 8: return c.last_plan.depth;
+    case 9: return c.last_plan.buffers;
     default: return -1;
   }
 }

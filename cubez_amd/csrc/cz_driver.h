@@ -76,6 +76,19 @@ class CZ {
   int wrk_shell_tag = 0;         // whose shell WRK carries: 0 unknown, 1 P's (Dirichlet faces), 2 all zero (sync_wrk_shell)
   void sync_wrk_shell(const REAL_TYPE* X);
   int overlap = 1;               // CZ_OVERLAP=0 turns it off (exchange after the whole sweep, same results)
+  // how the sweeps of the current / last stationary solve are executed (CZ::plan_pass; cz_info 7-9)
+  struct PassPlan {
+    enum Kind { SINGLE = 0, WHOLE = 1, SPLIT = 2 };
+    int kind = SINGLE;  // SINGLE: one sweep / colour per launch; WHOLE: fused pass over the whole inner box; SPLIT: shell slabs + interior, exchange overlapped
+    int depth = 1;      // ghost layers exchanged per pass
+    int lag = 0;        // residual all-reduce + test one pass behind, on the exchange stream
+    int buffers = 2;    // rotating field buffers
+    int zero_start = 0; // the first pass takes the start vector as a literal zero
+    int maf = 0, rb = 0;
+    int comm_cus = 0;
+  };
+  PassPlan last_plan;
+  bool plan_printed = false;
   int comm_cus = 0;              // CUs per XCD the sweeps leave to the exchange stream (CZ_COMM_CUS; 0 in single-domain runs)
   int n_shell = 0;               // shell boxes (cells within two layers of a rank-internal face), 1-based index ranges
   int shell_boxes[36];
@@ -128,7 +141,9 @@ class CZ {
   bool Comm_S2(REAL_TYPE* X, const int* skip_flag = nullptr);  // two layers + edges (fused Jacobi pairs)
   bool Comm_SUM_dev(double* d_val, int count, const int* skip_flag = nullptr);
   void plan_overlap();
-  bool pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot = nullptr);
+  bool pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot = nullptr,
+                       const czhip_internal::MafPtrs* maf = nullptr);
+  PassPlan plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, bool converge_check, bool x_is_zero, bool rb);
   bool Comm_SUM_1(double* host_val);
 
   int finish_stationary(int itr_max, int first_itr, bool converge_check, double& res);

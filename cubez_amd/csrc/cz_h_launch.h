@@ -247,9 +247,9 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
 }
 
 // the shell boxes of a decomposed brick, all in one launch (pair_shell_k); boxes: n x (ist,ied,jst,jed,kst,ked), 1-based
-template <int RB>
+template <int RB, int MAF = 0>
 void launch_pair_shell(const REAL* U, const REAL* B, REAL* W, const Coef& c, const int* sz, int g, const Box& ba, const int* boxes, int n,
-                       int par, const int* skip, hipStream_t st) {
+                       int par, const int* skip, hipStream_t st, const MafArgs& ma = MafArgs()) {
   ShellTab s;
   s.n = n;
   int most_tiles = 0;
@@ -279,7 +279,7 @@ void launch_pair_shell(const REAL* U, const REAL* B, REAL* W, const Coef& c, con
   const unsigned gx = (unsigned)std::min(most_tiles, 2048);
   {
     ScopedTimer tm(LBL_SHELL, st);
-    hipLaunchKernelGGL((pair_shell_k<RB>), dim3(gx, (unsigned)n), dim3(256), lds, st, U, B, W, c, s, ctx.shell_partials, skip);
+    hipLaunchKernelGGL((pair_shell_k<RB, MAF>), dim3(gx, (unsigned)n), dim3(256), lds, st, U, B, W, c, s, ctx.shell_partials, skip, ma);
   }
   HIP_CHECK(hipGetLastError());
   ctx.shell_pending = (int)(gx * n);

@@ -72,13 +72,14 @@ void search_pivot_async(CZ_REAL* pvt, const int* sz, const int* idx, int g, cons
 // decomposed brick owes its neighbours (pair_shell_async, first) and the interior (pair_box_async, overlapped with the exchange)
 int rb_par(int g, const int* idx, int ofst);
 int pair_plan(const int* inner_idx, const int* nID, int* boxes, int* interior, int* interior1);
-int pair_probe(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g, CZ_REAL dd);
+// maf (probe: != 0; launches: device coordinate arrays): the MAF flavour of the pass, cf / dd are then not used
+int pair_probe(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g, CZ_REAL dd, int maf);
 void pair_shell_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx1_brick, const int* boxes, int n,
-                      int g, const CZ_REAL* cf, CZ_REAL omg, int rb, const int* skip, hipStream_t st);
+                      int g, const CZ_REAL* cf, CZ_REAL omg, int rb, const int* skip, hipStream_t st, const MafPtrs* maf);
 void pair_shell_fold_async(double* res_dev, int single, const int* skip, hipStream_t st);
 // with_shell: res_dev = this launch's sums + those of the pair_shell_async launch before it
 int pair_box_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
-                   const CZ_REAL* cf, CZ_REAL omg, int rb, double* res_dev, int with_shell, const int* skip);
+                   const CZ_REAL* cf, CZ_REAL omg, int rb, double* res_dev, int with_shell, const int* skip, const MafPtrs* maf);
 void copy_shell_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
 void copy_inner_async(CZ_REAL* dst, const CZ_REAL* src, const int* sz, const int* idx, int g);
 void bc_async(const int* sz, int g, CZ_REAL* p, CZ_REAL dh, const CZ_REAL* org, const int* nID, int ioff = 0, int joff = 0);

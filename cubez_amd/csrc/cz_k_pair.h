@@ -97,6 +97,29 @@ __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, 
   return o;
 }
 
+// The MAF flavour of the per-point update (cz_maf.f90:193-225, operation for operation as in stencil_k<..., MAF = 1>): the six weights and
+// the diagonal are recomputed at every point from the metric terms of the 1-D grids -- XG, XGG of the row, YE, YEE of the plane, ZT, ZTT of
+// the component.
+template <int V>
+__device__ __forceinline__ Vec<V> relax_vec_maf(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm, const Vec<V>& pn,
+                                                REAL kl, REAL kr, const Vec<V>& bb, REAL XG, REAL XGG, REAL YE, REAL YEE, const Vec<V>& ZT,
+                                                const Vec<V>& ZTT, REAL omg, unsigned mask, unsigned count_mask, double& acc) {
+  Vec<V> o;
+#pragma unroll
+  for (int cc = 0; cc < V; cc++) {
+    const REAL pp = pc.v[cc];
+    const REAL km1 = (cc == 0) ? kl : pc.v[cc > 0 ? cc - 1 : 0];
+    const REAL kp1 = (cc == V - 1) ? kr : pc.v[cc < V - 1 ? cc + 1 : V - 1];
+    const MafW w = maf_weights(XG, XGG, YE, YEE, ZT.v[cc], ZTT.v[cc]);
+    const REAL rp = w.w1 * ip.v[cc] + w.w2 * im.v[cc] + w.w3 * pn.v[cc] + w.w4 * pm.v[cc] + w.w5 * kp1 + w.w6 * km1 + bb.v[cc];  // :219-225
+    const REAL dp = (rp / w.dd - pp) * omg;
+    const REAL d2 = dp * dp;
+    o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;
+    acc += (double)((count_mask & (1u << cc)) ? d2 : (REAL)0);
+  }
+  return o;
+}
+
 // The workgroup whose ticket came last sums all per-workgroup partials in a fixed order (sc1 loads, see stencil_k) and does the
 // bookkeeping of cz_Poisson.cpp:67-77 for the one or two iterations of the pass.  Called by every thread of that workgroup.
 template <int TB>
@@ -172,9 +195,14 @@ struct ShellTab {
 };
 
 // all tiles of one box that this workgroup takes; the tile shape is a compile-time constant (index arithmetic without divisions)
-template <int RB, int TK, int TI, int TJ>
+// MAF = 1: the weights of every point from the 1-D coordinate arrays (cz_maf.f90:193-225; padded index == index into xc / yc / zc for g = 2),
+// through relax_vec_maf<1> like the pass itself.
+template <int RB, int TK, int TI, int TJ, int MAF>
 __device__ __forceinline__ void shell_tiles(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, const Coef& c,
-                                            const ShellTab& s, const ShellBox& d, REAL* lu, double& acc1, double& acc2) {
+                                            const ShellTab& s, const ShellBox& d, REAL* lu, double& acc1, double& acc2, const MafArgs& ma) {
+  // metric terms of padded index x of a 1-D grid: XG-like first difference and XGG-like second difference
+  auto met1 = [](const REAL* __restrict__ xc, int x) { return (REAL)0.5 * (xc[x + 1] - xc[x - 1]); };
+  auto met2 = [](const REAL* __restrict__ xc, int x) { return xc[x + 1] - (REAL)2.0 * xc[x] + xc[x - 1]; };
   constexpr int UK = TK + 4, UI = TI + 4, UJ = TJ + 4;  // u tile: two halo layers
   constexpr int VK = TK + 2, VI = TI + 2, VJ = TJ + 2;  // v tile: one halo layer
   REAL* lv = lu + UK * UI * UJ;
@@ -234,7 +262,15 @@ __device__ __forceinline__ void shell_tiles(const REAL* __restrict__ U, const RE
         Vec<1> pc, im, ip, pm, pn, bb;
         pc.v[0] = v, im.v[0] = lu[cu - UK], ip.v[0] = lu[cu + UK], pm.v[0] = lu[cu - UK * UI], pn.v[0] = lu[cu + UK * UI];
         bb.v[0] = rb1[n];
-        v = relax_vec<1>(pc, im, ip, pm, pn, lu[cu - 1], lu[cu + 1], bb, c, PlainDiv{c.dd}, 1u, core ? 1u : 0u, acc1).v[0];
+        if (MAF) {
+          const int gk = K0 - 1 + k, gi = I0 - 1 + i, gj = J0 - 1 + j;
+          Vec<1> zt, ztt;
+          zt.v[0] = met1(ma.zc, gk), ztt.v[0] = met2(ma.zc, gk);
+          v = relax_vec_maf<1>(pc, im, ip, pm, pn, lu[cu - 1], lu[cu + 1], bb, met1(ma.xc, gi), met2(ma.xc, gi), met1(ma.yc, gj), met2(ma.yc, gj), zt, ztt,
+                               c.omg, 1u, core ? 1u : 0u, acc1).v[0];
+        } else {
+          v = relax_vec<1>(pc, im, ip, pm, pn, lu[cu - 1], lu[cu + 1], bb, c, PlainDiv{c.dd}, 1u, core ? 1u : 0u, acc1).v[0];
+        }
       }
       lv[e] = v;
     }
@@ -252,7 +288,14 @@ __device__ __forceinline__ void shell_tiles(const REAL* __restrict__ U, const RE
         Vec<1> pc, im, ip, pm, pn, bb;
         pc.v[0] = o, im.v[0] = lv[cv - VK], ip.v[0] = lv[cv + VK], pm.v[0] = lv[cv - VK * VI], pn.v[0] = lv[cv + VK * VI];
         bb.v[0] = rb2[n];
-        o = relax_vec<1>(pc, im, ip, pm, pn, lv[cv - 1], lv[cv + 1], bb, c, PlainDiv{c.dd}, 1u, 1u, acc2).v[0];
+        if (MAF) {
+          Vec<1> zt, ztt;
+          zt.v[0] = met1(ma.zc, gk), ztt.v[0] = met2(ma.zc, gk);
+          o = relax_vec_maf<1>(pc, im, ip, pm, pn, lv[cv - 1], lv[cv + 1], bb, met1(ma.xc, gi), met2(ma.xc, gi), met1(ma.yc, gj), met2(ma.yc, gj), zt, ztt,
+                               c.omg, 1u, 1u, acc2).v[0];
+        } else {
+          o = relax_vec<1>(pc, im, ip, pm, pn, lv[cv - 1], lv[cv + 1], bb, c, PlainDiv{c.dd}, 1u, 1u, acc2).v[0];
+        }
       }
       Wt[(k + 2) + (i + 2) * si + (j + 2) * sj] = o;
     }
@@ -260,10 +303,10 @@ __device__ __forceinline__ void shell_tiles(const REAL* __restrict__ U, const RE
   }
 }
 
-template <int RB>
+template <int RB, int MAF = 0>
 __global__ void __launch_bounds__(256)
 pair_shell_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, ShellTab s, double* partials,
-             const int* __restrict__ skip) {
+             const int* __restrict__ skip, MafArgs ma) {
   if (skip != nullptr && *skip != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ double wsum[8];
@@ -272,10 +315,10 @@ pair_shell_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __res
   REAL* lu = reinterpret_cast<REAL*>(smem);
   double acc1 = 0.0, acc2 = 0.0;
   switch (d.kind) {  // uniform per workgroup
-    case 0: shell_tiles<RB, 64, 4, 2>(U, B, W, c, s, d, lu, acc1, acc2); break;
-    case 1: shell_tiles<RB, 64, 2, 4>(U, B, W, c, s, d, lu, acc1, acc2); break;
-    case 2: shell_tiles<RB, 2, 16, 16>(U, B, W, c, s, d, lu, acc1, acc2); break;
-    default: shell_tiles<RB, 32, 4, 4>(U, B, W, c, s, d, lu, acc1, acc2); break;
+    case 0: shell_tiles<RB, 64, 4, 2, MAF>(U, B, W, c, s, d, lu, acc1, acc2, ma); break;
+    case 1: shell_tiles<RB, 64, 2, 4, MAF>(U, B, W, c, s, d, lu, acc1, acc2, ma); break;
+    case 2: shell_tiles<RB, 2, 16, 16, MAF>(U, B, W, c, s, d, lu, acc1, acc2, ma); break;
+    default: shell_tiles<RB, 32, 4, 4, MAF>(U, B, W, c, s, d, lu, acc1, acc2, ma); break;
   }
   // residuals: one pair of sums per workgroup; the interior launch that follows on the stream adds them to its own
   const int nblk = gridDim.x * gridDim.y;

@@ -66,29 +66,6 @@ __device__ __forceinline__ double lane_shl1(double edge, double x) {
   return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
-// The MAF flavour of the per-point update (cz_maf.f90:193-225, operation for operation as in stencil_k<..., MAF = 1>): the six weights and
-// the diagonal are recomputed at every point from the metric terms of the 1-D grids -- XG, XGG of the row, YE, YEE of the plane, ZT, ZTT of
-// the component.
-template <int V>
-__device__ __forceinline__ Vec<V> relax_vec_maf(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm, const Vec<V>& pn,
-                                                REAL kl, REAL kr, const Vec<V>& bb, REAL XG, REAL XGG, REAL YE, REAL YEE, const Vec<V>& ZT,
-                                                const Vec<V>& ZTT, REAL omg, unsigned mask, unsigned count_mask, double& acc) {
-  Vec<V> o;
-#pragma unroll
-  for (int cc = 0; cc < V; cc++) {
-    const REAL pp = pc.v[cc];
-    const REAL km1 = (cc == 0) ? kl : pc.v[cc > 0 ? cc - 1 : 0];
-    const REAL kp1 = (cc == V - 1) ? kr : pc.v[cc < V - 1 ? cc + 1 : V - 1];
-    const MafW w = maf_weights(XG, XGG, YE, YEE, ZT.v[cc], ZTT.v[cc]);
-    const REAL rp = w.w1 * ip.v[cc] + w.w2 * im.v[cc] + w.w3 * pn.v[cc] + w.w4 * pm.v[cc] + w.w5 * kp1 + w.w6 * km1 + bb.v[cc];  // :219-225
-    const REAL dp = (rp / w.dd - pp) * omg;
-    const REAL d2 = dp * dp;
-    o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;
-    acc += (double)((count_mask & (1u << cc)) ? d2 : (REAL)0);
-  }
-  return o;
-}
-
 // Red-black stage: only every other component of a vector belongs to the colour being updated -- component s, s+2 (FP32) / s (FP64), with
 // s = (k + i + j + parity) & 1 of component 0, a per-lane value.  The operands of those components are selected first and the update is
 // evaluated for V/2 points instead of V (the other colour passes through): same arithmetic on the updated points, hence the same bits,

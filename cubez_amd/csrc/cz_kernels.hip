@@ -442,10 +442,10 @@ int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const
   ensure_init();
   int boxes[36], in0[6], in1[6];
   const int n = czhip_internal::pair_plan(idx, nID, boxes, in0, in1);
-  if (n == 0 || !czhip_internal::pair_probe(u, w, b, sz, in0, in1, g, cf[6])) return 0;
+  if (n == 0 || !czhip_internal::pair_probe(u, w, b, sz, in0, in1, g, cf[6], 0)) return 0;
   const int rb = rb_ofst >= 0 ? rb_parity(g, idx, rb_ofst, 0) : -1;
-  czhip_internal::pair_shell_async(u, w, b, sz, idx1 ? idx1 : idx, boxes, n, g, cf, omg, rb, nullptr, nullptr);
-  return czhip_internal::pair_box_async(u, w, b, sz, in0, in1, g, cf, omg, rb, res_dev, 1, nullptr);
+  czhip_internal::pair_shell_async(u, w, b, sz, idx1 ? idx1 : idx, boxes, n, g, cf, omg, rb, nullptr, nullptr, nullptr);
+  return czhip_internal::pair_box_async(u, w, b, sz, in0, in1, g, cf, omg, rb, res_dev, 1, nullptr, nullptr);
 }
 
 // MAF flavour of czhip_jacobi2_async / czhip_rbsor2_async (rb_ofst < 0: two jacobi_maf sweeps, res_dev[0..1]; rb_ofst >= 0: one red-black
@@ -513,6 +513,12 @@ int czhip_selftest_cu_reserve(int k, int* per_xcd) {
     if ((key >> 16) < 8) per_xcd[key >> 16]++;
   czhip_internal::reserve_comm_cus(before);
   return (int)h.size();
+}
+
+// Measurement aid (tools/cu_reserve_cost.py): put the reservation of decomposed runs in force on this context by hand; returns what is in force.
+int czhip_set_comm_cus(int k) {
+  ensure_init();
+  return czhip_internal::reserve_comm_cus(k);
 }
 
 // line-SOR kernel choice: form 0 = pcr_rb_k (the reference's arithmetic literally, pcr_rb only), 1 = table + d in LDS, 2 = table +
@@ -1161,7 +1167,7 @@ int pair_plan(const int* O, const int* nID, int* boxes, int* interior, int* inte
   return n;
 }
 
-int pair_probe(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g, REAL dd) {
+int pair_probe(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g, REAL dd, int maf) {
   ensure_init();
   if (!ctx.tune.fuse_fin || g < 2) return 0;
   const Box bx = make_box(sz, idx, g);
@@ -1169,14 +1175,22 @@ int pair_probe(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* 
   const Box ba = make_box(sz, idx1, g);
   Coef c = make_coef_omg((REAL)1);
   c.dd = dd;  // the divisor decides too: the pass divides with the hoisted form (cz_k_fastdiv.h)
-  return launch_jacobi2<0>(u, b, w, c, bx, ba, nullptr, Fin2(), 0, 0, true) ? 1 : 0;
+  const MafArgs ma = MafArgs();
+  return launch_jacobi2<0>(u, b, w, c, bx, ba, nullptr, Fin2(), 0, 0, true, maf ? &ma : nullptr) ? 1 : 0;
 }
 
+// maf: the MAF flavour (weights from the device coordinate arrays; cf is then not used)
 void pair_shell_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx1_brick, const int* boxes, int n, int g,
-                      const REAL* cf, REAL omg, int rb, const int* skip, hipStream_t st) {
+                      const REAL* cf, REAL omg, int rb, const int* skip, hipStream_t st, const MafPtrs* maf) {
   ensure_init();
   const Box ba = make_box(sz, idx1_brick, g);
   if (!st) st = ctx.stream;
+  if (maf) {
+    const MafArgs ma{maf->xc, maf->yc, maf->zc, nullptr};
+    if (rb >= 0) launch_pair_shell<1, 1>(u, b, w, make_coef_omg(omg), sz, g, ba, boxes, n, rb, skip, st, ma);
+    else launch_pair_shell<0, 1>(u, b, w, make_coef_omg(omg), sz, g, ba, boxes, n, 0, skip, st, ma);
+    return;
+  }
   if (rb >= 0) launch_pair_shell<1>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, rb, skip, st);
   else launch_pair_shell<0>(u, b, w, make_coef(cf, omg), sz, g, ba, boxes, n, 0, skip, st);
 }
@@ -1191,7 +1205,7 @@ void pair_shell_fold_async(double* res_dev, int single, const int* skip, hipStre
 }
 
 int pair_box_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const int* idx, const int* idx1, int g, const REAL* cf,
-                   REAL omg, int rb, double* res_dev, int with_shell, const int* skip) {
+                   REAL omg, int rb, double* res_dev, int with_shell, const int* skip, const MafPtrs* maf) {
   ensure_init();
   const Box bx = make_box(sz, idx, g);
   const Box ba = make_box(sz, idx1, g);
@@ -1201,6 +1215,11 @@ int pair_box_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const i
   if (with_shell) {  // same stream as the shell launch: its sums join this launch's in the finaliser
     fin.extra = ctx.shell_partials, fin.n_extra = ctx.shell_pending;
     ctx.shell_pending = 0;
+  }
+  if (maf) {
+    const MafArgs ma{maf->xc, maf->yc, maf->zc, nullptr};
+    if (rb >= 0) return launch_jacobi2<1>(u, b, w, make_coef_omg(omg), bx, ba, skip, fin, rb, 0, false, &ma) ? 1 : 0;
+    return launch_jacobi2<0>(u, b, w, make_coef_omg(omg), bx, ba, skip, fin, 0, 0, false, &ma) ? 1 : 0;
   }
   if (rb >= 0) return launch_jacobi2<1>(u, b, w, make_coef(cf, omg), bx, ba, skip, fin, rb) ? 1 : 0;
   return launch_jacobi2<0>(u, b, w, make_coef(cf, omg), bx, ba, skip, fin) ? 1 : 0;

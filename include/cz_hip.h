@@ -257,6 +257,9 @@ int czhip_use_t2(void);
  * sweep fills the chip.  Self-test: with k CUs set aside, per_xcd[0..7] = the CUs of each XCD a launch on the compute stream ran on
  * (expected 32 - k each); returns their total. */
 int czhip_selftest_cu_reserve(int k, int* per_xcd);
+/* measurement aid: put that reservation in force by hand (the driver does it itself in decomposed runs and undoes it in single-domain
+ * ones at set-up); returns the reservation in force */
+int czhip_set_comm_cus(int k);
 /* self-test: numerators (of 2^32) whose quotient by d in the two-stage pass differs from the IEEE division (expected 0); -1 = divisor not eligible */
 long long czhip_selftest_fastdiv(CZ_REAL d);
 
@@ -293,7 +296,9 @@ void cz_set_quiet(cz_handle*, int quiet);     /* suppress stdout / history file 
 double cz_last_solve_seconds(const cz_handle*);
 /* What a (multi-GPU) run decided: what = 0 ranks, 1 every brick takes the fused pass, 2 shell slabs of this brick, 3 overlapped exchange,
  * 4 the last stationary solve ran its residual all-reduce + test one pass behind, 5 ranks of the RCCL communicator (ncclCommCount; 0 = LOCAL
- * test transport or single process), 6 CUs per XCD the sweeps leave to the exchange stream (CZ_COMM_CUS). */
+ * test transport or single process), 6 CUs per XCD the sweeps leave to the exchange stream (CZ_COMM_CUS); the plan of the last stationary
+ * solve: 7 kind of pass (0 single sweeps, 1 fused pass over the whole box, 2 fused pass as shell slabs + interior with the exchange
+ * overlapped), 8 ghost layers exchanged per pass, 9 rotating field buffers. */
 int cz_info(const cz_handle*, int what);
 double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
 

