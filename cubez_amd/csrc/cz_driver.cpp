@@ -87,7 +87,7 @@ CZ::~CZ() {
   czhip_sync();
   // give the CUs reserved for the exchange stream back: the library context outlives this object, and a queue with a CU mask that is still
   // alive at process exit crashed rocprofv3's finalisation (gpurun_out/probe_c, round 3)
-  if (comm_cus > 0) reserve_comm_cus(0);
+  if (comm_cus > 0) reserve_comm_cus(0, 0);
   REAL_TYPE* arrs[] = {WRK, WRK2, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt, MSK};
   if (d_xc) (void)hipFree(d_xc);
   if (d_yc) (void)hipFree(d_yc);
@@ -571,14 +571,16 @@ void CZ::plan_overlap() {
   comm_cus = 0;
   if (numProc > 1 && overlap) n_shell = pair_plan(innerFidx, nID, shell_boxes, interior, interior1);
   // CUs per XCD the sweeps leave to the exchange stream while an interior launch fills the chip (RCCL's send/recv kernels need CUs of their
-  // own for as long as a message is in flight; reserve_comm_cus, cz_kernels.hip).  CZ_COMM_CUS, default 2: at 512^3 the interior launch
-  // of the two-stage pass uses 30 of an XCD's 32 CUs anyway (profiles/r03/cu_reserve_cost.txt).  Every rank reserves alike (argv and
-  // environment are the job's), also a brick without a rank-internal face: the launch geometry of a pass depends on the CU count.
+  // own for as long as a message is in flight; reserve_comm_cus, cz_kernels.hip): CZ_COMM_CUS, default 2, through the launch geometry --
+  // at 512^3 FP32 the interior launch of the two-stage pass uses 30 of an XCD's 32 CUs anyway; CZ_COMM_CUS_MASK=1 enforces it with a CU
+  // mask instead (1.8x slower sweeps where the launch fills the remaining CUs in one round: profiles/r03/cu_reserve_cost.txt).  Every rank
+  // reserves alike (argv and environment are the job's), also a brick without a rank-internal face: the launch geometry depends on it.
   if (numProc > 1 && overlap) {
     const char* cc = getenv("CZ_COMM_CUS");
-    comm_cus = reserve_comm_cus(cc ? atoi(cc) : 2);
+    const char* cm = getenv("CZ_COMM_CUS_MASK");
+    comm_cus = reserve_comm_cus(cc ? atoi(cc) : 2, (cm && atoi(cm) != 0) ? 1 : 0);
   } else {
-    reserve_comm_cus(0);
+    reserve_comm_cus(0, 0);
   }
   if (n_shell == 0) return;
   if (!comm_stream) {

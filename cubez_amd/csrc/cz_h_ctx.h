@@ -13,6 +13,8 @@ struct Tuning {
                                                          // CZHIP_PCR_WG_PER_CU, CZHIP_PCR_MAX_WG, CZHIP_PCR_SLOTS, czhip_set_pcr_lex_limits
   int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
                                       // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
+  int psor_col = 1, psor_wg_per_cu = 0;  // psor / psor_maf: 1 = the sweep in one launch (psor_col_k), 0 = a launch per tile hyperplane (psor_tile_k);
+                                         // workgroups per CU of the former (0: four); CZHIP_PSOR=one_launch[,wg_per_cu], czhip_set_psor
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
                                               // the balance model (pair_tj_model, cz_h_launch.h); CZHIP_T2=enable,threads,2,tj fixes them
   int t2_map = 1;                                 // two-stage pass: equal shares of (segment, chunk) items per XCD (CZHIP_T2_MAP=0: whole-segment bands)
@@ -35,6 +37,12 @@ struct Ctx {
   REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
   int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
   size_t pcr_tab_cap = 0;
+  unsigned long long* psor_faces = nullptr;  // psor_col_k: the face words the columns hand to their high-side neighbours (one sweep)
+  size_t psor_faces_cap = 0;
+  int* psor_order = nullptr;                 // ... columns in the order of their diagonals (ticket -> column)
+  int psor_order_nti = 0, psor_order_ntj = 0;
+  unsigned* psor_ctl = nullptr;              // ... ticket and error word
+  unsigned psor_seq = 0;                     // ... sweeps so far: the number a valid face word carries
   REAL* pcr_scratch = nullptr;  // pcr_rb_k<GS = 1>: a, c, d of the lines in flight (lines too long for LDS)
   size_t pcr_scratch_cap = 0;
   double* shell_partials = nullptr;  // per-workgroup sums of the last pair_shell_k launch, folded in by the interior launch
@@ -51,7 +59,8 @@ struct Ctx {
   std::map<long long, PairMap> pair_maps;        // workgroup id -> (segment, chunk) tables of the two-stage pass, key nseg << 32 | nchunk
   int num_cu = 256;             // CUs the compute stream may use (= num_cu_total - 8 * cu_reserved)
   int num_cu_total = 256;
-  int cu_reserved = 0;          // CUs per XCD the compute stream leaves to the exchange stream (decomposed runs; reserve_comm_cus)
+  int cu_reserved = 0;          // CUs per XCD the sweeps leave to the exchange stream (decomposed runs; reserve_comm_cus)
+  bool cu_masked = false;       // ... enforced by a CU mask on the compute stream's queue (hard form) instead of by the launch geometry
   // optional per-launch HIP-event timing of the labelled kernels (bench.py roofline leg)
   bool timing = false;
   struct Ev { hipEvent_t a, b; int label; };

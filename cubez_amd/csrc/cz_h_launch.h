@@ -103,7 +103,9 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 // ceil(band * nchunk / slots) rounds of that (tools/pair_lab sweeps, profiles/r02/pair_lab_sweep_*.txt: the model ranks the measured
 // times of both shapes and both precisions).  Returns the cost in units of plane steps; *tj_out the best chunk length.
 inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, bool balanced, int* tj_out) {
-  const int slots = std::max(1, ctx.num_cu / 8) * wg_per_cu;
+  // (decomposed runs: cu_reserved CUs of every XCD stay free for the exchange stream -- by this count unless a CU mask enforces it, in which
+  // case num_cu is already the smaller number; reserve_comm_cus)
+  const int slots = std::max(1, ctx.num_cu / 8 - (ctx.cu_masked ? 0 : ctx.cu_reserved)) * wg_per_cu;
   double best = 1e300;
   int best_tj = std::min(16, nplanes);
   for (int tj = std::min(12, nplanes); tj <= std::min(nplanes, 128); tj++) {

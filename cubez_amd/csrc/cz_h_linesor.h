@@ -500,13 +500,72 @@ void launch_pcr_maf(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, con
   }
 }
 
-// one lexicographic SOR sweep (psor / psor_maf): a launch per tile hyperplane, then the fixed-order sum of the tile partials
+// psor / psor_maf in one launch (psor_col_k); false when the geometry does not suit it (the caller then launches per tile hyperplane)
+bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* res_dev, int accumulate, const int* skip, const MafArgs* ma) {
+  if (!ctx.tune.psor_col) return false;
+  PsorColGeom g;
+  g.nkp = bx.nkp, g.nip = bx.nip, g.njp = bx.njp;
+  g.kk0 = bx.kk0, g.nk = bx.kk1 - bx.kk0 + 1, g.ii0 = bx.ii0, g.ii1 = bx.ii1, g.jj0 = bx.jj0, g.jj1 = bx.jj1;
+  g.nti = (bx.ii1 - bx.ii0 + PC_T) / PC_T, g.ntj = (bx.jj1 - bx.jj0 + PC_T) / PC_T;
+  g.face_words = (long long)(g.nk + PC_T) * PC_T * kPsorColHW;
+  // the line streams read runs that start up to 2 (PC_T - 1) + 2 elements in front of a line and end up to 2 (PC_T - 1) + 12 behind it, on the
+  // lines ii0-1 .. ii1+1 x jj0-1 .. jj1+1: all of it must lie inside the padded array
+  const long long plane = (long long)bx.nkp * bx.nip, total = plane * bx.njp;
+  const long long lo = (long long)bx.kk0 + (long long)(bx.ii0 - 1) * bx.nkp + (long long)(bx.jj0 - 1) * plane - (2 * (PC_T - 1) + 4);
+  const long long hi = (long long)bx.kk0 + (long long)(bx.ii1 + 1) * bx.nkp + (long long)(bx.jj1 + 1) * plane + g.nk + 2 * (PC_T - 1) + 12;
+  if (bx.ii0 < 1 || bx.jj0 < 1 || bx.kk0 < 1 || lo < 0 || hi >= total) return false;
+  const int ncols = g.nti * g.ntj;
+  if (ctx.psor_order_nti != g.nti || ctx.psor_order_ntj != g.ntj) {
+    std::vector<int> order;
+    for (int d = 0; d <= g.nti + g.ntj - 2; d++)
+      for (int a = std::max(0, d - (g.ntj - 1)); a <= std::min(g.nti - 1, d); a++) order.push_back(a + g.nti * (d - a));
+    if (ctx.psor_order) {
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      HIP_CHECK(hipFree(ctx.psor_order));
+    }
+    HIP_CHECK(hipMalloc(&ctx.psor_order, (size_t)ncols * sizeof(int)));
+    HIP_CHECK(hipMemcpy(ctx.psor_order, order.data(), (size_t)ncols * sizeof(int), hipMemcpyHostToDevice));
+    ctx.psor_order_nti = g.nti, ctx.psor_order_ntj = g.ntj;
+  }
+  const size_t words = (size_t)2 * ncols * g.face_words;
+  if (words > ctx.psor_faces_cap || ctx.psor_seq == 0xffffffffu) {
+    if (ctx.psor_faces && words > ctx.psor_faces_cap) {
+      HIP_CHECK(hipStreamSynchronize(ctx.stream));
+      HIP_CHECK(hipFree(ctx.psor_faces));
+      ctx.psor_faces = nullptr;
+    }
+    if (!ctx.psor_faces) {
+      HIP_CHECK(hipMalloc(&ctx.psor_faces, words * sizeof(unsigned long long)));
+      ctx.psor_faces_cap = words;
+    }
+    HIP_CHECK(hipMemsetAsync(ctx.psor_faces, 0, ctx.psor_faces_cap * sizeof(unsigned long long), ctx.stream));  // no word carries a sweep number yet
+    ctx.psor_seq = 0;
+  }
+  if (!ctx.psor_ctl) HIP_CHECK(hipMalloc(&ctx.psor_ctl, 256));
+  ensure_partials((size_t)ncols);
+  const int per_cu = ctx.tune.psor_wg_per_cu > 0 ? std::min(ctx.tune.psor_wg_per_cu, 8) : 4;
+  const unsigned nblk = (unsigned)std::min(ncols, ctx.num_cu * per_cu);
+  const unsigned seq = ++ctx.psor_seq;
+  ScopedTimer tm(LBL_PSOR);
+  HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 256, ctx.stream));
+  if (ma)
+    hipLaunchKernelGGL((psor_col_k<1>), dim3(nblk), dim3(PC_T * PC_T), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
+                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, *ma);
+  else
+    hipLaunchKernelGGL((psor_col_k<0>), dim3(nblk), dim3(PC_T * PC_T), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
+                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs());
+  HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// one lexicographic SOR sweep (psor / psor_maf): one launch (psor_col_k), or a launch per tile hyperplane and the fixed-order sum of the tile partials
 void launch_psor(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* res_dev, int accumulate, const int* skip,
                  const MafArgs* ma) {
   if (bx.empty) {
     if (!accumulate) HIP_CHECK(hipMemsetAsync(res_dev, 0, sizeof(double), ctx.stream));
     return;
   }
+  if (try_psor_col(p, b, c, bx, res_dev, accumulate, skip, ma)) return;
   constexpr int T = 16;
   PsorGeom g;
   g.nkp = bx.nkp, g.nip = bx.nip, g.njp = bx.njp;

@@ -22,8 +22,9 @@
 
 namespace czhip_internal {
 hipStream_t stream();
-// decomposed runs: the compute stream leaves k CUs per XCD to the exchange stream (CU mask); returns the reservation in force
-int reserve_comm_cus(int k);
+// decomposed runs: the sweeps leave k CUs per XCD to the exchange stream -- through the launch geometry (hard = 0) or a CU mask on the
+// compute stream (hard = 1); returns the reservation in force
+int reserve_comm_cus(int k, int hard = 0);
 int comm_cus_reserved();
 void triad_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, const int* sz, const int* idx, int g);
 void bicg1_async(CZ_REAL* p, const CZ_REAL* r, const CZ_REAL* q, CZ_REAL beta, CZ_REAL omg, const int* sz, const int* idx, int g);

@@ -41,6 +41,7 @@ namespace {
 #include "cz_k_pair.h"
 #include "cz_k_pair2.h"
 #include "cz_k_linesor.h"
+#include "cz_k_psor.h"
 #include "cz_k_blas.h"
 #include "cz_h_ctx.h"
 #include "cz_h_launch.h"
@@ -138,7 +139,7 @@ __global__ void where_k(unsigned* out, long long spin_ticks) {
 }  // namespace
 
 namespace czhip_internal {
-int reserve_comm_cus(int k);
+int reserve_comm_cus(int k, int hard);
 }
 
 // ============================================================================================================
@@ -194,6 +195,11 @@ int czhip_init(int device) {
     sscanf(pp, "%d,%lf,%d,%d", &w, &sec, &rows, &q);
     ctx.tune.pcr_pipe = w, ctx.tune.pipe_spin_ticks = (long long)(sec * 1e8), ctx.tune.pcr_rows = rows, ctx.tune.pcr_q = q;
   }
+  if (const char* v = getenv("CZHIP_PSOR")) {  // "one_launch[,workgroups per CU]"
+    int one = 1, wg = 0;
+    sscanf(v, "%d,%d", &one, &wg);
+    ctx.tune.psor_col = one, ctx.tune.psor_wg_per_cu = wg;
+  }
   if (const char* v = getenv("CZHIP_PCR_WG_PER_CU")) ctx.tune.pcr_wg_per_cu = atoi(v);
   if (const char* v = getenv("CZHIP_PCR_MAX_WG")) ctx.tune.pcr_max_wg = atoi(v);
   if (const char* v = getenv("CZHIP_PCR_SLOTS")) ctx.tune.pcr_slots = atoi(v);
@@ -217,6 +223,9 @@ void czhip_finalize(void) {
   if (ctx.pcr_tab) (void)hipFree(ctx.pcr_tab);
   if (ctx.pcr_tab_perm) (void)hipFree(ctx.pcr_tab_perm);
   if (ctx.pcr_scratch) (void)hipFree(ctx.pcr_scratch);
+  if (ctx.psor_faces) (void)hipFree(ctx.psor_faces);
+  if (ctx.psor_order) (void)hipFree(ctx.psor_order);
+  if (ctx.psor_ctl) (void)hipFree(ctx.psor_ctl);
   if (ctx.pipe_ctl) (void)hipFree(ctx.pipe_ctl);
   ctx.pipe_ctl = nullptr, ctx.pipe_ctl_cap = 0;
   if (ctx.pipe_hb) (void)hipFree(ctx.pipe_hb);
@@ -490,13 +499,13 @@ long long czhip_selftest_fastdiv(CZ_REAL d) {
   return (long long)h;
 }
 
-// Self-test of the CU reservation of decomposed runs (reserve_comm_cus): with k CUs per XCD set aside, where do the workgroups of a launch on
-// the library's compute stream run?  per_xcd[x] receives the number of distinct CUs of XCD x that ran one; returns their total.  The
+// Self-test of the hard form of the CU reservation of decomposed runs (reserve_comm_cus, CU mask): with k CUs per XCD set aside, where do the
+// workgroups of a launch on the library's compute stream run?  per_xcd[x] receives the number of distinct CUs of XCD x that ran one; returns their total.  The
 // reservation is undone before returning.
 int czhip_selftest_cu_reserve(int k, int* per_xcd) {
   ensure_init();
-  const int before = ctx.cu_reserved;
-  czhip_internal::reserve_comm_cus(k);
+  const int before = ctx.cu_reserved, before_hard = ctx.cu_masked ? 1 : 0;
+  czhip_internal::reserve_comm_cus(k, 1);
   const int nwg = 8192;
   unsigned* d = nullptr;
   HIP_CHECK(hipMalloc(&d, nwg * sizeof(unsigned)));
@@ -511,14 +520,14 @@ int czhip_selftest_cu_reserve(int k, int* per_xcd) {
   for (int x = 0; x < 8; x++) per_xcd[x] = 0;
   for (unsigned key : h)
     if ((key >> 16) < 8) per_xcd[key >> 16]++;
-  czhip_internal::reserve_comm_cus(before);
+  czhip_internal::reserve_comm_cus(before, before_hard);
   return (int)h.size();
 }
 
 // Measurement aid (tools/cu_reserve_cost.py): put the reservation of decomposed runs in force on this context by hand; returns what is in force.
-int czhip_set_comm_cus(int k) {
+int czhip_set_comm_cus(int k, int hard) {
   ensure_init();
-  return czhip_internal::reserve_comm_cus(k);
+  return czhip_internal::reserve_comm_cus(k, hard);
 }
 
 // line-SOR kernel choice: form 0 = pcr_rb_k (the reference's arithmetic literally, pcr_rb only), 1 = table + d in LDS, 2 = table +
@@ -548,6 +557,16 @@ double czhip_set_pcr_lex_timeout(double seconds) {
   ensure_init();
   if (seconds >= 0.0) ctx.tune.pipe_spin_ticks = (long long)(seconds * 1e8);
   return (double)ctx.tune.pipe_spin_ticks * 1e-8;
+}
+
+// psor_ / psor_maf_ and the solvers of those names: one_launch 1 = the whole sweep in one launch (psor_col_k: columns of workgroups walking k,
+// faces handed on through memory), 0 = a launch per tile hyperplane (psor_tile_k); workgroups per CU of the former (0 = four).  Negative: keep.
+// Same bits either way.
+int czhip_set_psor(int one_launch, int wg_per_cu) {
+  ensure_init();
+  if (one_launch >= 0) ctx.tune.psor_col = one_launch ? 1 : 0;
+  if (wg_per_cu >= 0) ctx.tune.psor_wg_per_cu = wg_per_cu;
+  return 0;
 }
 
 // pcr_lex_wg_k launch limits (test aid; negative: keep, 0: the launcher's choice): workgroups per CU, workgroups in all, lines per hand-off
@@ -928,32 +947,41 @@ hipStream_t stream() {
   return ctx.stream;
 }
 
-// Decomposed runs: the compute stream gives up k CUs of every XCD, so that what the exchange stream launches while an interior sweep
-// fills the chip -- shell slabs, pack / unpack and above all RCCL's send/recv kernels, which need CUs of their own for as long as a
-// message is in flight -- never waits for a workgroup slot.  The interior launch of the two-stage pass is sized to fill its slots in ONE
-// round with workgroups that live as long as the launch (pair_tj_model), so a stream priority alone frees nothing before the end.
-// Mechanism: the stream's queue gets a CU mask (hipExtStreamCreateWithCUMask).  Bit i of the mask is CU i / 8 of XCD i % 8 on this part
-// (tools/cumask_lab.hip `reserve`: the masked stream runs on 32 - k CUs of every XCD and never on the others; czhip_selftest_cu_reserve
-// checks it on the box it runs on).  Everything sized from the CU count (chunk lengths of the sweeps, resident workgroups of the line
-// solvers) follows ctx.num_cu.  Returns the reservation in force.
-int reserve_comm_cus(int k) {
+// Decomposed runs: the sweeps leave k CUs of every XCD to what the exchange stream launches while an interior sweep fills the chip -- shell
+// slabs, pack / unpack and above all RCCL's send/recv kernels, which need CUs of their own for as long as a message is in flight.  The
+// interior launch of the two-stage pass is sized to fill its slots in ONE round with workgroups that live as long as the launch
+// (pair_tj_model), so a stream priority alone frees nothing before the end.  Two mechanisms:
+//   soft (default)  the launch geometry: pair_tj_model counts num_cu/8 - k slots per XCD, so a one-round launch leaves k CUs of every XCD
+//                   without a workgroup (a 1024-thread workgroup with its ~130 KB of LDS takes a CU for itself), and launches of several
+//                   rounds free slots all the time anyway.  Costs nothing at 512^3 FP32, where the launch uses 30 of the 32 slots as it is.
+//   hard            a CU mask on the compute stream's queue (hipExtStreamCreateWithCUMask; bit i of the mask is CU i / 8 of XCD i % 8 on
+//                   this part: tools/cumask_lab.hip `reserve`, czhip_selftest_cu_reserve).  The reserved CUs are then out of reach of
+//                   every sweep -- and a launch that fills the remaining CUs in one round takes 1.8x as long (0.63 against 0.35 ms at
+//                   512^3 FP32 with k = 1 or 2, profiles/r03/cu_reserve_cost.txt): the dispatcher of a masked queue does not place one
+//                   workgroup on every CU the way it does without a mask.  Kept for measurements (CZ_COMM_CUS_MASK=1), not the default.
+// Returns the reservation in force.
+int reserve_comm_cus(int k, int hard) {
   ensure_init();
   const int per_xcd = ctx.num_cu_total / 8;
   if (ctx.num_cu_total % 8 != 0 || per_xcd < 4) k = 0;  // not the 8-XCD part this was measured on
   k = std::max(0, std::min(k, per_xcd / 2));
-  if (k == ctx.cu_reserved) return k;
-  HIP_CHECK(hipStreamSynchronize(ctx.stream));
-  HIP_CHECK(hipStreamDestroy(ctx.stream));
-  if (k == 0) {
-    HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
-  } else {
-    std::vector<uint32_t> mask((size_t)(ctx.num_cu_total + 31) / 32, 0u);
-    for (int i = 0; i < ctx.num_cu_total; i++)
-      if (i / 8 < per_xcd - k) mask[(size_t)i / 32] |= 1u << (i % 32);
-    HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx.stream, (uint32_t)mask.size(), mask.data()));
+  if (k == 0) hard = 0;
+  if (k == ctx.cu_reserved && (hard != 0) == ctx.cu_masked) return k;
+  if ((hard != 0) != ctx.cu_masked || hard) {  // the stream changes
+    HIP_CHECK(hipStreamSynchronize(ctx.stream));
+    HIP_CHECK(hipStreamDestroy(ctx.stream));
+    if (!hard) {
+      HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    } else {
+      std::vector<uint32_t> mask((size_t)(ctx.num_cu_total + 31) / 32, 0u);
+      for (int i = 0; i < ctx.num_cu_total; i++)
+        if (i / 8 < per_xcd - k) mask[(size_t)i / 32] |= 1u << (i % 32);
+      HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx.stream, (uint32_t)mask.size(), mask.data()));
+    }
   }
   ctx.cu_reserved = k;
-  ctx.num_cu = ctx.num_cu_total - 8 * k;
+  ctx.cu_masked = hard != 0;
+  ctx.num_cu = ctx.num_cu_total - (hard ? 8 * k : 0);  // what a launch can occupy at all
   return k;
 }
 int comm_cus_reserved() { return ctx.cu_reserved; }

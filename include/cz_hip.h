@@ -248,18 +248,23 @@ int czhip_set_pcr_lex(int one_launch, int groups, int rows_per_thread);
 /* Bound, in seconds, of every wait of one workgroup for another inside the one-launch sweep (default 2; negative = keep); returns the bound in
  * force.  If a wait runs out, every workgroup leaves and the residual of that sweep is NaN. */
 double czhip_set_pcr_lex_timeout(double seconds);
+/* the lexicographic point SOR (psor_, psor_maf_; reference: cz_solver.f90:207-269, one thread walking j, i, k): one_launch 1 = the whole sweep
+ * in one launch (default), 0 = one launch per tile hyperplane; workgroups per CU of the former (0 = chosen by the launcher).  Negative = keep.
+ * Same bits either way; the waits of the one-launch form are bounded by czhip_set_pcr_lex_timeout, a lost hand-off gives a NaN residual. */
+int czhip_set_psor(int one_launch, int wg_per_cu);
 /* Launch limits of the one-launch sweep (test aid; negative = keep, 0 = chosen per launch): workgroups per CU, workgroups in all, lines per
  * hand-off ring between two rows (rounded up to a power of two).  The launcher's own ring size lets the sweep finish however few of its
  * workgroups the device keeps resident; a ring forced small with few workgroups cannot, and the sweep then ends as described above. */
 int czhip_set_pcr_lex_limits(int wg_per_cu, int max_wg, int slots);
 int czhip_use_t2(void);
 /* Decomposed runs keep k CUs of every XCD free of the sweeps (CZ_COMM_CUS, default 2) so that RCCL's send/recv kernels run while an interior
- * sweep fills the chip.  Self-test: with k CUs set aside, per_xcd[0..7] = the CUs of each XCD a launch on the compute stream ran on
- * (expected 32 - k each); returns their total. */
+ * sweep fills the chip: through the launch geometry (default) or, with CZ_COMM_CUS_MASK=1, a CU mask on the compute stream.  Self-test of the
+ * mask: with k CUs set aside, per_xcd[0..7] = the CUs of each XCD a launch on the compute stream ran on (expected 32 - k each); returns
+ * their total. */
 int czhip_selftest_cu_reserve(int k, int* per_xcd);
-/* measurement aid: put that reservation in force by hand (the driver does it itself in decomposed runs and undoes it in single-domain
- * ones at set-up); returns the reservation in force */
-int czhip_set_comm_cus(int k);
+/* measurement aid: put that reservation in force by hand, hard = 1 with the CU mask (the driver does it itself in decomposed runs and undoes
+ * it in single-domain ones at set-up); returns the reservation in force */
+int czhip_set_comm_cus(int k, int hard);
 /* self-test: numerators (of 2^32) whose quotient by d in the two-stage pass differs from the IEEE division (expected 0); -1 = divisor not eligible */
 long long czhip_selftest_fastdiv(CZ_REAL d);
 

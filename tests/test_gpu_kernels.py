@@ -853,9 +853,11 @@ def test_hoisted_division_is_the_ieee_division(prec):
     assert h.lib.czhip_selftest_fastdiv(3.0e38 if prec == "f32" else 1e300) == -1
 
 
+@pytest.mark.skipif(os.environ.get("CZ_TEST_CU_MASK") != "1", reason="the CU-mask form of the reservation is an experiment, not the product path: "
+                    "queues with a CU mask hung twice in round 3 after a few were created and destroyed (profiles/r03/cu_reserve_cost.txt)")
 def test_cu_reservation_keeps_the_sweeps_off_the_reserved_cus():
-    """Decomposed runs give k CUs of every XCD to the exchange stream (CU mask on the compute stream, reserve_comm_cus): a launch on the
-    compute stream then runs on exactly 32 - k CUs of each of the 8 XCDs -- on this box, not only on the one the mask layout was measured on."""
+    """The HARD form of the reservation of decomposed runs (CZ_COMM_CUS_MASK=1; the default is the launch geometry): with a CU mask on the
+    compute stream a launch runs on exactly 32 - k CUs of each of the 8 XCDs -- on this box, not only on the one the mask layout was measured on."""
     import ctypes as C
     h = _hip("f32")
     per = (C.c_int * 8)()
