@@ -1084,7 +1084,14 @@ int CZ::PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double&
     }
   }
   for (int i = 0; i < (npoll < POLL_SLOTS ? npoll : POLL_SLOTS); i++) HIP_CHECK(hipEventDestroy(ev[i]));
-  return finish_stationary(itr_max, 1, converge_check, res);
+  const int ret = finish_stationary(itr_max, 1, converge_check, res);
+  if (psor_failed()) {  // a column of the one-launch sweep gave up waiting for the columns before it: the iterate is void
+    fprintf(stderr, "cz rank %d: %s: a sweep gave up a hand-off between its workgroups (bound: czhip_set_pcr_lex_timeout); the iterate is void.  "
+                    "CZHIP_PSOR=0 selects the launch-per-tile-hyperplane form.\n", myRank, printMethod(s_type));
+    line_error = true;
+    return 0;
+  }
+  return ret;
 }
 
 // cz_Poisson.cpp:621-742 (pcr_rb_esa), :745-826 (pcr), :910-1005 (pcr_esa), :1008-1095 (pcr_j_esa): the line-SOR variants that end

@@ -508,11 +508,11 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
   g.kk0 = bx.kk0, g.nk = bx.kk1 - bx.kk0 + 1, g.ii0 = bx.ii0, g.ii1 = bx.ii1, g.jj0 = bx.jj0, g.jj1 = bx.jj1;
   g.nti = (bx.ii1 - bx.ii0 + PC_T) / PC_T, g.ntj = (bx.jj1 - bx.jj0 + PC_T) / PC_T;
   g.face_words = (long long)(g.nk + PC_T) * PC_T * kPsorColHW;
-  // the line streams read runs that start up to 2 (PC_T - 1) + 2 elements in front of a line and end up to 2 (PC_T - 1) + 12 behind it, on the
+  // the line streams read runs that start up to 2 (PC_T - 1) + 2 elements in front of a line and end up to 2 (PC_T - 1) + 48 behind it, on the
   // lines ii0-1 .. ii1+1 x jj0-1 .. jj1+1: all of it must lie inside the padded array
   const long long plane = (long long)bx.nkp * bx.nip, total = plane * bx.njp;
   const long long lo = (long long)bx.kk0 + (long long)(bx.ii0 - 1) * bx.nkp + (long long)(bx.jj0 - 1) * plane - (2 * (PC_T - 1) + 4);
-  const long long hi = (long long)bx.kk0 + (long long)(bx.ii1 + 1) * bx.nkp + (long long)(bx.jj1 + 1) * plane + g.nk + 2 * (PC_T - 1) + 12;
+  const long long hi = (long long)bx.kk0 + (long long)(bx.ii1 + 1) * bx.nkp + (long long)(bx.jj1 + 1) * plane + g.nk + 2 * (PC_T - 1) + 48;
   if (bx.ii0 < 1 || bx.jj0 < 1 || bx.kk0 < 1 || lo < 0 || hi >= total) return false;
   const int ncols = g.nti * g.ntj;
   if (ctx.psor_order_nti != g.nti || ctx.psor_order_ntj != g.ntj) {
@@ -541,19 +541,22 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
     HIP_CHECK(hipMemsetAsync(ctx.psor_faces, 0, ctx.psor_faces_cap * sizeof(unsigned long long), ctx.stream));  // no word carries a sweep number yet
     ctx.psor_seq = 0;
   }
-  if (!ctx.psor_ctl) HIP_CHECK(hipMalloc(&ctx.psor_ctl, 256));
+  if (!ctx.psor_ctl) {
+    HIP_CHECK(hipMalloc(&ctx.psor_ctl, 256));
+    HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 256, ctx.stream));
+  }
   ensure_partials((size_t)ncols);
-  const int per_cu = ctx.tune.psor_wg_per_cu > 0 ? std::min(ctx.tune.psor_wg_per_cu, 8) : 4;
+  const int per_cu = ctx.tune.psor_wg_per_cu > 0 ? std::min(ctx.tune.psor_wg_per_cu, 8) : 2;  // (6 waves of ~130 registers: two workgroups per CU)
   const unsigned nblk = (unsigned)std::min(ncols, ctx.num_cu * per_cu);
   const unsigned seq = ++ctx.psor_seq;
   ScopedTimer tm(LBL_PSOR);
-  HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 256, ctx.stream));
+  HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 2 * sizeof(unsigned), ctx.stream));  // ticket and error word ([2]: sticky "a sweep gave up")
   if (ma)
-    hipLaunchKernelGGL((psor_col_k<1>), dim3(nblk), dim3(PC_T * PC_T), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
-                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, *ma);
+    hipLaunchKernelGGL((psor_col_k<1>), dim3(nblk), dim3(PC_NT), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
+                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, *ma, nullptr);
   else
-    hipLaunchKernelGGL((psor_col_k<0>), dim3(nblk), dim3(PC_T * PC_T), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
-                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs());
+    hipLaunchKernelGGL((psor_col_k<0>), dim3(nblk), dim3(PC_NT), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
+                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs(), nullptr);
   HIP_CHECK(hipGetLastError());
   return true;
 }

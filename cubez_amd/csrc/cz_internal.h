@@ -62,6 +62,7 @@ void rbsor_maf_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx
 int pair_maf_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g, const CZ_REAL* xc,
                    const CZ_REAL* yc, const CZ_REAL* zc, CZ_REAL omg, int rb_ofst, double* res_dev, double res_normal, double eps, int itr,
                    double* hist_dev, int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev);
+int psor_failed();
 void psor_async(CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf, const CZ_REAL* xc,
                 const CZ_REAL* yc, const CZ_REAL* zc, CZ_REAL omg, double* res_dev, int accumulate, const int* skip);
 void calc_ax_maf_async(CZ_REAL* ap, const CZ_REAL* p, const int* sz, const int* idx, int g, const CZ_REAL* xc, const CZ_REAL* yc,

@@ -49,21 +49,42 @@ __device__ __forceinline__ void pc_load(const REAL* __restrict__ p, REAL* o) {
   }
 }
 
+constexpr int PC_NT = PC_T * PC_T + 128;  // 256 computing threads + the wave that feeds the faces + the wave that takes them
+
 template <int MAF>
-__global__ void __launch_bounds__(PC_T * PC_T)
+__global__ void __launch_bounds__(PC_NT)
 psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom g, const int* __restrict__ order, unsigned* ctl,
            unsigned long long* faces, unsigned seq, long long spin_limit, double* partials, double* dst, int accumulate, unsigned* counter,
-           const int* __restrict__ skip, MafArgs ma) {
+           const int* __restrict__ skip, MafArgs ma, long long* prof) {
+  // prof (development aid, tools/psor_lab): per column {start, end} in ticks of the 100 MHz wall clock and the workgroup that ran it
   if (skip != nullptr && *skip != 0) return;
-  constexpr int NT = PC_T * PC_T, G = 4;  // threads; steps per group (one 16-byte access per stream and group)
+  constexpr int NT = PC_NT, G = 4;  // threads; steps per group (one 16-byte access per stream and group)
   constexpr int HW = kPsorColHW;
+  constexpr int NG = 4, NS = NG * G;  // the loop bodies cover NG groups: register rings with compile-time indices
   __shared__ REAL sNEW[2][PC_L * PC_L], sOLD[2][PC_L * PC_L];
+  // The new values go back to memory as WHOLE 128-byte lines: written 16 bytes at a time as they are produced, a line left the XCD's L2 before
+  // its other seven pieces arrived -- 2.1 GB of partial-line writes per 512^3 sweep where 0.53 GB are due (WRITE_SIZE, profiles/r03).  Every
+  // thread therefore collects its values in a ring of two lines in LDS ([entry][thread]: conflict-free) and stores a line in one burst
+  // once it is complete.
+  constexpr int EL = 128 / (int)sizeof(REAL);  // elements per line
+  __shared__ REAL sOUT[2 * EL][PC_T * PC_T];
   __shared__ double wsum[NT / 64 + 2];
   __shared__ int sh[4];
-  const int t = threadIdx.x, i = t & (PC_T - 1), j = t >> 4;
+  const int t = threadIdx.x;
+  // Three kinds of wave.  Memory operations of a wave complete in the order they were issued (one counter, vmcnt, for loads AND stores): a
+  // wave that stores write-through face words and waits for loads would wait for the acknowledgement of its stores at every load -- the
+  // first version of this kernel did, and a column that fed another took 0.55 us per step instead of 0.36.  So:
+  //   waves 0..3  compute: stream their lines (loads, one plain 16-byte store per group); wave 0 also serves the OLD halo (loads)
+  //   wave  4     feeds: reads the new values of the column's high faces from the LDS plane and stores the face words -- stores only
+  //   wave  5     takes: reads the face words (or the boundary) of the low faces and publishes them in the NEW halo -- loads only
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
   const int ncols = g.nti * g.ntj;
   const size_t si = (size_t)g.nkp, sj = (size_t)g.nkp * g.nip;
-  const int li = (i + 1) + PC_L * (j + 1);  // this thread's place in an LDS plane
+  const int nsteps = g.nk + 2 * (PC_T - 1);
+  // whole loop bodies; one step more than the sweep has: the feeding wave stores what step s - 1 computed in step s
+  const int ngroups = ((nsteps + 1 + G - 1) / G + NG - 1) / NG * NG;
+  const int nrows = g.nk + PC_T;
   unsigned polls = 0;
   long long t0 = 0;
   if (t == 0) sh[2] = 0;
@@ -80,204 +101,238 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
     const int col = order[ticket];
     const int a = col % g.nti, b = col / g.nti;
     const int I0 = g.ii0 + a * PC_T, J0 = g.jj0 + b * PC_T;
-    const int gi = I0 + i, gj = J0 + j;
-    const bool col_in = gi <= g.ii1 && gj <= g.jj1;
-    // (threads beyond the box stream the boundary line next to it: their OLD values are what the last inner thread reads as i+1 / j+1)
-    const int gic = min(gi, g.ii1 + 1), gjc = min(gj, g.jj1 + 1);
-    REAL* line = P + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;  // element k = 0 of this thread's line
-    const REAL* bline = B + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;
-    // ---- the halo of the LDS planes, served by wave 0: four groups of 16 lanes (virtual threads (hi, hj) with the same rule k = s - hi - hj)
-    //   lanes  0..15  OLD at (16, lane)        lanes 16..31  OLD at (lane - 16, 16)         old values on the high sides: memory
-    //   lanes 32..47  NEW at (-1, lane - 32)   lanes 48..63  NEW at (lane - 48, -1)         new values on the low sides: face words or boundary
-    const int hgrp = t >> 4;
-    const bool is_halo = t < 64;
-    int hi = 0, hj = 0;
-    if (hgrp == 0) hi = PC_T, hj = t & 15;
-    else if (hgrp == 1) hi = t & 15, hj = PC_T;
-    else if (hgrp == 2) hi = -1, hj = t & 15;
-    else if (hgrp == 3) hi = t & 15, hj = -1;
-    const int hli = (hi + 1) + PC_L * (hj + 1);
-    const bool h_new = is_halo && hgrp >= 2;
-    // (a face word exists only for the rows of the box: the lanes of a partial column's missing rows have nothing to wait for)
-    const bool h_ring = h_new && ((hgrp == 2) ? (a > 0 && J0 + (t & 15) <= g.jj1) : (b > 0 && I0 + (t & 15) <= g.ii1));
-    const int hgi = is_halo ? min(max(I0 + hi, g.ii0 - 1), g.ii1 + 1) : g.ii0, hgj = is_halo ? min(max(J0 + hj, g.jj0 - 1), g.jj1 + 1) : g.jj0;
-    const REAL* hline = P + (size_t)g.kk0 + (size_t)hgi * si + (size_t)hgj * sj;  // (threads of the other waves: one common line, never used)
     // face words: rows are indexed by r = k + (the coordinate inside the face); one row = PC_T values
     unsigned long long* faceI = faces + (size_t)(2 * col) * g.face_words;       // this column's high-i face, for column (a+1, b)
     unsigned long long* faceJ = faces + (size_t)(2 * col + 1) * g.face_words;   // high-j face, for column (a, b+1)
-    const unsigned long long* rin = faces;                                      // the face a halo lane reads (others: a valid dummy)
-    if (h_ring) rin = faces + (size_t)(hgrp == 2 ? 2 * (col - 1) : 2 * (col - g.nti) + 1) * g.face_words;
-    const int hc = h_ring ? ((hgrp == 2) ? hj : hi) : 0;  // the halo lane's coordinate inside the face
-    const bool feedI = a + 1 < g.nti && i == PC_T - 1, feedJ = b + 1 < g.ntj && j == PC_T - 1;
-    const int nrows = g.nk + PC_T;
-
-    REAL XG = 0, XGG = 0, YE = 0, YEE = 0;
-    if (MAF) {  // padded index == index into xc / yc / zc for g = 2 (see MafArgs)
-      const int xi = min(gi, g.ii1), yj = min(gj, g.jj1);
-      const REAL xm = ma.xc[xi - 1], x0 = ma.xc[xi], xp = ma.xc[xi + 1];
-      const REAL ym = ma.yc[yj - 1], y0 = ma.yc[yj], yp = ma.yc[yj + 1];
-      XG = (REAL)0.5 * (xp - xm), XGG = xp - (REAL)2.0 * x0 + xm;
-      YE = (REAL)0.5 * (yp - ym), YEE = yp - (REAL)2.0 * y0 + ym;
-    }
-
-    // ---- line streams.  Group `grp` covers the steps s = G grp .. G grp + G - 1, i.e. this thread's k = kb .. kb + G - 1 with
-    // kb = G grp - i - j.  pb[m] = p_old(kb + m), m = 0 .. 2G - 1 (the second half arrives while the first is used); bb[m] = b(kb + m);
-    // hb[m]: the halo lane's line from hkb, where hb[u + 2] is what it publishes at sub-step u.  Every load is unconditional: elements before
-    // k = -1 or behind k = nk belong to the neighbouring rows of the padded array (the launcher makes sure there is one on either side) and
-    // are never used; k = -1 and k = nk ARE the boundary values the first / last point needs.
-    const int nsteps = g.nk + 2 * (PC_T - 1);
-    const int ngroups = (nsteps + G - 1) / G;
-    REAL pb[2 * G], bb[2 * G], hb[2 * G], ob[G];
-    const int hoff = h_new ? 2 : 0;
-    {
-      const int kb = -i - j;
-      pc_load<G>(line + kb, &pb[0]);
-      pc_load<G>(line + kb + G, &pb[G]);
-      pc_load<G>(bline + kb, &bb[0]);
-      pc_load<G>(bline + kb + G, &bb[G]);
-      const int hks = -hi - hj - hoff;
-      pc_load<G>(hline + hks, &hb[0]);
-      pc_load<G>(hline + hks + G, &hb[G]);
-    }
-    REAL prev_new = line[-1];  // new value of k - 1 of the first point: the low boundary
-    unsigned long long rw[HW];
     double acc = 0.0;
+    if (prof && t == 0) prof[4 * col] = (long long)wall_clock64(), prof[4 * col + 2] = blockIdx.x;
 
-    // What the planes hold for step s is published in step s - 1: the new value of this thread's k (read as i-1 / j-1 next door), its old
-    // value two points ahead (read as i+1 / j+1), and the halo.  `nv`: the thread's new value of this step; `uo`: pb / hb index of sub-step 0.
-    // The face word of the halo lane was asked for one step ago (`rw`); the one for the next step is asked for here.
-    auto publish = [&](int nxt, int s, REAL nv, REAL old2, REAL hv) __attribute__((always_inline)) {
-      sNEW[nxt][li] = nv;
-      sOLD[nxt][li] = old2;
-      const int hk = s - hi - hj;  // the virtual thread's k at step s
-      if (is_halo) {
-        if (!h_new) {
-          sOLD[nxt][hli] = hv;  // old value two points ahead of hk
-        } else if (!h_ring) {
-          sNEW[nxt][hli] = hv;  // boundary value at hk
-        } else if (hk >= 0 && hk < g.nk) {
+    if (wv < 4) {
+      // ================================================================ compute waves
+      const int i = t & (PC_T - 1), j = t >> 4;
+      const int li = (i + 1) + PC_L * (j + 1);  // this thread's place in an LDS plane
+      const int gi = I0 + i, gj = J0 + j;
+      const bool col_in = gi <= g.ii1 && gj <= g.jj1;
+      // (threads beyond the box stream the boundary line next to it: their OLD values are what the last inner thread reads as i+1 / j+1)
+      const int gic = min(gi, g.ii1 + 1), gjc = min(gj, g.jj1 + 1);
+      REAL* line = P + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;  // element k = 0 of this thread's line
+      const REAL* bline = B + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;
+      // the OLD halo, served by lanes 0..31 of wave 0 as virtual threads (hi, hj) of the plane: (16, lane) and (lane - 16, 16)
+      const bool halo_wave = wv == 0;
+      const bool is_halo = t < 32;
+      const int hi = (t < 16) ? PC_T : (t & 15), hj = (t < 16) ? (t & 15) : PC_T;
+      const int hli = (hi + 1) + PC_L * (hj + 1);
+      const int hgi = is_halo ? min(I0 + hi, g.ii1 + 1) : g.ii0, hgj = is_halo ? min(J0 + hj, g.jj1 + 1) : g.jj0;
+      const REAL* hline = P + (size_t)g.kk0 + (size_t)hgi * si + (size_t)hgj * sj;  // (other threads: one common line, never used)
+      const int hk0 = -hi - hj;  // the virtual thread's k at step 0
+      // this line's place in the grid of 128-byte memory lines: element k sits at position phi + k (P is 256-byte aligned)
+      const int phi = (int)((((size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj) + (reinterpret_cast<size_t>(P) / sizeof(REAL))) % EL);
+      int next_line = 0;  // lines of this thread's row stored so far (line n holds the positions n EL .. n EL + EL - 1)
+      // store every complete line that has not been stored yet; `kdone`: the last k this thread has produced (all = the row is finished)
+      auto flush_lines = [&](int kdone, bool all) __attribute__((always_inline)) {
+        if (!col_in) return;
+        const int kd = min(kdone, g.nk - 1);
+        while (kd >= 0 && (next_line + 1) * EL - 1 <= phi + kd + ((all && kd == g.nk - 1) ? EL : 0) && next_line * EL <= phi + g.nk - 1) {
+          const int c0 = next_line * EL;  // first position of the line
+#pragma unroll
+          for (int v = 0; v < EL; v += kRunW) {
+            RunVec x;
+#pragma unroll
+            for (int w = 0; w < kRunW; w++) x[w] = sOUT[(c0 + v + w) % (2 * EL)][t];
+            const int k0 = c0 + v - phi;  // k of the vector's first element
+            if (k0 >= 0 && k0 + kRunW <= g.nk) {
+              *reinterpret_cast<RunVec*>(line + k0) = x;  // (16-byte aligned: c0 + v is a multiple of the vector width)
+            } else {
+#pragma unroll
+              for (int w = 0; w < kRunW; w++)
+                if (k0 + w >= 0 && k0 + w < g.nk) line[k0 + w] = x[w];
+            }
+          }
+          next_line++;
+        }
+      };
+
+      REAL XG = 0, XGG = 0, YE = 0, YEE = 0;
+      if (MAF) {  // padded index == index into xc / yc / zc for g = 2 (see MafArgs)
+        const int xi = min(gi, g.ii1), yj = min(gj, g.jj1);
+        const REAL xm = ma.xc[xi - 1], x0 = ma.xc[xi], xp = ma.xc[xi + 1];
+        const REAL ym = ma.yc[yj - 1], y0 = ma.yc[yj], yp = ma.yc[yj + 1];
+        XG = (REAL)0.5 * (xp - xm), XGG = xp - (REAL)2.0 * x0 + xm;
+        YE = (REAL)0.5 * (yp - ym), YEE = yp - (REAL)2.0 * y0 + ym;
+      }
+      // ---- line streams.  Group `grp` covers the steps s = G grp .. G grp + G - 1, i.e. this thread's k = kb .. kb + G - 1 with
+      // kb = G grp - i - j.  The loop body is unrolled over NG = 4 groups, so that the streams live in register rings with compile-time
+      // indices and nothing in flight is ever copied: pbuf[G q + u] = p_old(kb + u) of group slot q, bbuf likewise b, hbuf the halo lane's
+      // line (hbuf[m + 2] is what it publishes at step m).  A group uses its own slot and the first two entries of the next; when it is
+      // done its slot is asked for again, for the group NG groups ahead -- three groups (12 steps) before the first use.  Every load is
+      // unconditional: elements before k = -1 or behind k = nk belong to the neighbouring rows of the padded array (the launcher makes sure
+      // they exist) and are never used; k = -1 and k = nk ARE the boundary values the first / last point needs.
+      REAL pbuf[NS], bbuf[NS], hbuf[NS];
+#pragma unroll
+      for (int q = 0; q < NG; q++) {
+        pc_load<G>(line + (G * q - i - j), &pbuf[G * q]);
+        pc_load<G>(bline + (G * q - i - j), &bbuf[G * q]);
+        pc_load<G>(hline + (G * q + hk0), &hbuf[G * q]);
+      }
+      REAL prev_new = line[-1];  // new value of k - 1 of the first point: the low boundary
+      // (consumed here, once: a loop-carried register that starts life as a load makes the compiler wait for ALL loads in flight -- the
+      // streams asked for twelve steps ahead -- at every use inside the loop)
+      asm volatile("" : "+v"(prev_new));
+      // What the planes hold for step s + 1 is published in step s: the new value of this thread's k (read as i-1 / j-1 next door), its old
+      // value two points ahead (read as i+1 / j+1), and -- wave 0 -- the OLD halo.
+      auto publish = [&](int nxt, REAL nv, REAL old2, REAL hv) __attribute__((always_inline)) {
+        sNEW[nxt][li] = nv;
+        sOLD[nxt][li] = old2;
+        if (halo_wave && is_halo) sOLD[nxt][hli] = hv;  // old value two points ahead of the virtual thread's k
+      };
+      publish(0, (REAL)0, pbuf[1], hbuf[1]);  // step -1: nothing is computed, the planes of step 0 are published
+      lds_barrier();
+
+      for (int sg = 0; sg < ngroups; sg += NG) {
+#pragma unroll
+        for (int q = 0; q < NG; q++) {
+          const int grp = sg + q;
+          const int kb = G * grp - i - j;  // this thread's k at sub-step 0
+#pragma unroll
+          for (int u = 0; u < G; u++) {
+            const int m = G * q + u;                 // position in the register rings (compile time)
+            const int cur = m & 1, nxt = cur ^ 1;   // (step and m have the same parity: NS is even)
+            const int k = kb + u;
+            const bool active = col_in && k >= 0 && k < g.nk;
+            // ---- operands
+            const REAL pp = pbuf[m], kp1 = pbuf[(m + 1) % NS];
+            const REAL im1 = sNEW[cur][li - 1], jm1 = sNEW[cur][li - PC_L];
+            const REAL ip1 = sOLD[cur][li + 1], jp1 = sOLD[cur][li + PC_L];
+            REAL nv = pp;
+            if (active) {
+              REAL dp;
+              if (MAF) {
+                const int gk = g.kk0 + k;
+                const REAL zm = ma.zc[gk - 1], z0 = ma.zc[gk], zp = ma.zc[gk + 1];
+                const MafW w = maf_weights(XG, XGG, YE, YEE, (REAL)0.5 * (zp - zm), zp - (REAL)2.0 * z0 + zm);
+                const REAL rp = w.w1 * ip1 + w.w2 * im1 + w.w3 * jp1 + w.w4 * jm1 + w.w5 * kp1 + w.w6 * prev_new + bbuf[m];  // cz_maf.f90:93-99
+                dp = (rp / w.dd - pp) * c.omg;
+              } else {
+                const REAL ss = c.c1 * ip1 + c.c2 * im1 + c.c3 * jp1 + c.c4 * jm1 + c.c5 * kp1 + c.c6 * prev_new;  // cz_solver.f90:250-255
+                dp = ((ss - bbuf[m]) / c.dd - pp) * c.omg;
+              }
+              nv = pp + dp;
+              const REAL d2 = dp * dp;
+              acc += (double)d2;
+              prev_new = nv;
+            }
+            if (active) sOUT[(phi + k) % (2 * EL)][t] = nv;
+            publish(nxt, nv, pbuf[(m + 2) % NS], hbuf[(m + 2) % NS]);
+            lds_barrier();
+          }
+          // ---- this group's slot of the rings is free: ask for the runs NG groups ahead
+          pc_load<G>(line + kb + NS, &pbuf[G * q]);
+          pc_load<G>(bline + kb + NS, &bbuf[G * q]);
+          pc_load<G>(hline + (G * grp + hk0) + NS, &hbuf[G * q]);
+        }
+        // ---- the lines completed in this loop body (NS steps <= EL: at most one per thread, two entries of the ring are never in doubt)
+        flush_lines(G * (sg + NG) - 1 - i - j, false);
+        if (sh[2] != 0) break;  // a wait was given up (written before a barrier every thread has passed)
+      }
+      flush_lines(g.nk - 1, true);  // what is left: the last, incomplete line
+    } else if (wv == 4) {
+      // ================================================================ the wave that feeds the faces (stores only)
+      // At step s the plane `cur` holds what the computing threads published in step s - 1: thread (15, j) its new value of k = s - 16 - j,
+      // thread (i, 15) of k = s - 16 - i -- row s - 16 of both faces.  Lanes 0..15: face I (j = lane); lanes 16..31: face J (i = lane - 16).
+      const int fc = lane & 15;                       // coordinate inside the face
+      const bool toI = lane < 16;
+      const bool feeds = lane < 32 && (toI ? (a + 1 < g.nti && J0 + fc <= g.jj1) : (b + 1 < g.ntj && I0 + fc <= g.ii1));
+      const int src = toI ? (PC_T + PC_L * (fc + 1)) : ((fc + 1) + PC_L * PC_T);  // LDS place of thread (15, fc) / (fc, 15)
+      unsigned long long* face = toI ? faceI : faceJ;
+      lds_barrier();  // (step -1)
+      for (int s = 0; s < G * ngroups; s++) {
+        const int cur = s & 1;
+        const int k = s - PC_T - fc;  // what that thread computed in the step before
+        if (feeds && k >= 0 && k < g.nk) {
+          const REAL nv = sNEW[cur][src];
+          const unsigned long long tag = (unsigned long long)seq << 32;
+          unsigned long long* q = face + ((size_t)(k + fc) * PC_T + fc) * HW;
+          if (sizeof(REAL) == 8) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong((double)nv);
+            __hip_atomic_store(q, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + (HW - 1), tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            __hip_atomic_store(q, tag | (unsigned long long)__float_as_uint((float)nv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        lds_barrier();
+        if ((s & (NS - 1)) == NS - 1 && sh[2] != 0) break;  // (where the computing waves look)
+      }
+    } else {
+      // ================================================================ the wave that takes the low faces (loads only)
+      // Lanes 0..15: NEW halo at (-1, lane), from face I of column (a-1, b); lanes 16..31: NEW halo at (lane - 16, -1), from face J of column
+      // (a, b-1); on the box's low faces the boundary line (memory, never written).  Virtual threads of the plane: at step s lane (hi, hj)
+      // publishes, for step s + 1, the new value of k = s - hi - hj = s + 1 - (coordinate): row s + 1 of the face.  Words and boundary
+      // values are asked for eight steps ahead (rq / bq[s & 7]); a word that has not arrived is read again until it carries this sweep's number.
+      const int hc = lane & 15;
+      const bool fromI = lane < 16;
+      const bool takes = lane < 32;
+      const int hi = fromI ? -1 : hc, hj = fromI ? hc : -1;
+      const int hli = (hi + 1) + PC_L * (hj + 1);
+      // (a face word exists only for the rows of the box: the lanes of a partial column's missing rows have nothing to wait for)
+      const bool h_ring = takes && (fromI ? (a > 0 && J0 + hc <= g.jj1) : (b > 0 && I0 + hc <= g.ii1));
+      const unsigned long long* rin = faces;  // (lanes without a face: a valid dummy)
+      if (h_ring) rin = faces + (size_t)(fromI ? 2 * (col - 1) : 2 * (col - g.nti) + 1) * g.face_words;
+      const int hgi = takes ? min(max(I0 + hi, g.ii0 - 1), g.ii1 + 1) : g.ii0, hgj = takes ? min(max(J0 + hj, g.jj0 - 1), g.jj1 + 1) : g.jj0;
+      const REAL* hline = P + (size_t)g.kk0 + (size_t)hgi * si + (size_t)hgj * sj;
+      const int hk0 = -hi - hj;  // = 1 - hc: the virtual thread's k at step 0
+      unsigned long long rq[8][HW];
+      REAL bq[8];
+      auto ask = [&](int slot, int s) __attribute__((always_inline)) {  // what step s publishes: row hk(s) + hc of the face / element hk(s) of the line
+        const int hk = s + hk0;
+        const int r = min(max(hk + hc, 0), nrows - 1);
+        const unsigned long long* q = rin + (h_ring ? ((size_t)r * PC_T + hc) * HW : 0);
+#pragma unroll
+        for (int w = 0; w < HW; w++) rq[slot][w] = __hip_atomic_load(q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bq[slot] = hline[min(max(hk, -1), g.nk)];
+      };
+      auto take = [&](int nxt, int slot, int s) __attribute__((always_inline)) {
+        const int hk = s + hk0;
+        const bool need = h_ring && hk >= 0 && hk < g.nk;
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < HW; w++) ok = ok && (unsigned)(rq[slot][w] >> 32) == seq;
+        if (need && !ok) {
           const unsigned long long* q = rin + ((size_t)(hk + hc) * PC_T + hc) * HW;
-          bool ok = true;
+          do {
 #pragma unroll
-          for (int w = 0; w < HW; w++) ok = ok && (unsigned)(rw[w] >> 32) == seq;
-          while (!ok) {
-#pragma unroll
-            for (int w = 0; w < HW; w++) rw[w] = __hip_atomic_load(q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int w = 0; w < HW; w++) rq[slot][w] = __hip_atomic_load(q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = true;
 #pragma unroll
-            for (int w = 0; w < HW; w++) ok = ok && (unsigned)(rw[w] >> 32) == seq;
+            for (int w = 0; w < HW; w++) ok = ok && (unsigned)(rq[slot][w] >> 32) == seq;
             if (!ok && pipe_give_up(polls, t0, spin_limit, ctl)) {
               sh[2] = 1;
               break;
             }
-          }
+          } while (!ok);
           t0 = 0;
-          REAL v;
-          if (sizeof(REAL) == 8) v = (REAL)__longlong_as_double((long long)((rw[0] & 0xffffffffull) | (rw[HW - 1] << 32)));
-          else v = (REAL)__uint_as_float((unsigned)(rw[0] & 0xffffffffull));
-          sNEW[nxt][hli] = v;
         }
-      }
-      // the word of the next step (all threads: no branch around a load; rows clamped into the face, threads without a face read word 0)
-      {
-        const int r = min(max(hk + 1 + hc, 0), nrows - 1);
-        const unsigned long long* q = rin + (h_ring ? ((size_t)r * PC_T + hc) * HW : 0);
+        REAL rv;
+        if (sizeof(REAL) == 8) rv = (REAL)__longlong_as_double((long long)((rq[slot][0] & 0xffffffffull) | (rq[slot][HW - 1] << 32)));
+        else rv = (REAL)__uint_as_float((unsigned)(rq[slot][0] & 0xffffffffull));
+        if (takes) sNEW[nxt][hli] = need ? rv : bq[slot];  // (a face lane outside its range publishes something nobody reads)
+        ask(slot, s + 8);
+      };
 #pragma unroll
-        for (int w = 0; w < HW; w++) rw[w] = __hip_atomic_load(q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    };
-    // step -1: nothing is computed, the planes of step 0 are published
-    {
-      const int r = min(max(-1 - hi - hj + hc, 0), nrows - 1);
-      const unsigned long long* q = rin + (h_ring ? ((size_t)r * PC_T + hc) * HW : 0);
+      for (int m = -1; m < 7; m++) ask(m & 7, m);
+      take(0, 7, -1);  // step -1
+      lds_barrier();
+      for (int s0 = 0; s0 < G * ngroups; s0 += 8) {
 #pragma unroll
-      for (int w = 0; w < HW; w++) rw[w] = __hip_atomic_load(q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    publish(0, -1, (REAL)0, pb[1], hb[1]);
-    lds_barrier();
-
-    for (int grp = 0; grp < ngroups; grp++) {
-      const int kb = G * grp - i - j;  // this thread's k at sub-step 0
-#pragma unroll
-      for (int u = 0; u < G; u++) {
-        const int s = G * grp + u, cur = s & 1, nxt = cur ^ 1;
-        const int k = kb + u;
-        const bool active = col_in && k >= 0 && k < g.nk;
-        // ---- operands
-        const REAL pp = pb[u], kp1 = pb[u + 1];
-        const REAL im1 = sNEW[cur][li - 1], jm1 = sNEW[cur][li - PC_L];
-        const REAL ip1 = sOLD[cur][li + 1], jp1 = sOLD[cur][li + PC_L];
-        REAL nv = pp;
-        if (active) {
-          REAL dp;
-          if (MAF) {
-            const int gk = g.kk0 + k;
-            const REAL zm = ma.zc[gk - 1], z0 = ma.zc[gk], zp = ma.zc[gk + 1];
-            const MafW w = maf_weights(XG, XGG, YE, YEE, (REAL)0.5 * (zp - zm), zp - (REAL)2.0 * z0 + zm);
-            const REAL rp = w.w1 * ip1 + w.w2 * im1 + w.w3 * jp1 + w.w4 * jm1 + w.w5 * kp1 + w.w6 * prev_new + bb[u];  // cz_maf.f90:93-99
-            dp = (rp / w.dd - pp) * c.omg;
-          } else {
-            const REAL ss = c.c1 * ip1 + c.c2 * im1 + c.c3 * jp1 + c.c4 * jm1 + c.c5 * kp1 + c.c6 * prev_new;  // cz_solver.f90:250-255
-            dp = ((ss - bb[u]) / c.dd - pp) * c.omg;
-          }
-          nv = pp + dp;
-          const REAL d2 = dp * dp;
-          acc += (double)d2;
-          prev_new = nv;
+        for (int m = 0; m < 8; m++) {
+          take((m & 1) ^ 1, m, s0 + m);
+          lds_barrier();
         }
-        ob[u] = nv;
-        // ---- hand the new value to the columns on the high sides: row r = k + (coordinate inside the face) of the face buffer
-        if (active && (feedI || feedJ)) {
-          const unsigned long long tag = (unsigned long long)seq << 32;
-          unsigned long long w0, w1 = 0ull;
-          if (sizeof(REAL) == 8) {
-            const unsigned long long bits = (unsigned long long)__double_as_longlong((double)nv);
-            w0 = tag | (bits & 0xffffffffull), w1 = tag | (bits >> 32);
-          } else {
-            w0 = tag | (unsigned long long)__float_as_uint((float)nv);
-          }
-          if (feedI) {
-            unsigned long long* q = faceI + ((size_t)(k + j) * PC_T + j) * HW;
-            __hip_atomic_store(q, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (HW == 2) __hip_atomic_store(q + (HW - 1), w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (feedJ) {
-            unsigned long long* q = faceJ + ((size_t)(k + i) * PC_T + i) * HW;
-            __hip_atomic_store(q, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (HW == 2) __hip_atomic_store(q + (HW - 1), w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        publish(nxt, s, nv, pb[u + 2], hb[u + 2]);
-        lds_barrier();
-      }
-      if (sh[2] != 0) break;  // a wait was given up (written before a barrier every thread has passed)
-      // ---- the group's new values back to the line: one 16-byte store where all four exist
-      if (col_in) {
-        if (kb >= 0 && kb + G <= g.nk) {
-#pragma unroll
-          for (int cc = 0; cc < G; cc += kRunW) {
-            RunVec v;
-#pragma unroll
-            for (int w = 0; w < kRunW; w++) v[w] = ob[cc + w];
-            *reinterpret_cast<RunVec*>(line + kb + cc) = v;
-          }
-        } else {
-#pragma unroll
-          for (int u = 0; u < G; u++)
-            if (kb + u >= 0 && kb + u < g.nk) line[kb + u] = ob[u];
-        }
-      }
-      // ---- rotate the streams and ask for the runs after the next
-#pragma unroll
-      for (int m = 0; m < G; m++) pb[m] = pb[G + m], bb[m] = bb[G + m], hb[m] = hb[G + m];
-      {
-        const int kn = kb + 2 * G;
-        pc_load<G>(line + kn, &pb[G]);
-        pc_load<G>(bline + kn, &bb[G]);
-        pc_load<G>(hline + (G * grp - hi - hj - hoff) + 2 * G, &hb[G]);
+        if ((s0 & (NS - 1)) == NS - 8 && sh[2] != 0) break;  // (where the computing waves look)
       }
     }
     __syncthreads();
+    if (prof && t == 0) prof[4 * col + 1] = (long long)wall_clock64();
     const double sblk = block_sum<NT>(acc, wsum);
     if (t == 0) __hip_atomic_store(&partials[col], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -294,6 +349,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
     if (t == 0) {
       const bool bad = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
       dst[0] = bad ? __builtin_nan("") : (accumulate ? dst[0] + tot : tot);
+      if (bad) ctl[2] = 1u;  // (sticky: the launcher clears ctl[0..1] only; the host asks with psor_failed)
       *counter = 0u;
     }
   }

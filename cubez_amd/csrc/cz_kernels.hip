@@ -1082,6 +1082,7 @@ void check_on_stream(hipStream_t st, const double* res_dev, double res_normal, d
 void reset_ticket() {
   ensure_init();
   HIP_CHECK(hipMemsetAsync(ctx.counter, 0, 64, ctx.stream));
+  if (ctx.psor_ctl) HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 256, ctx.stream));  // (and the sticky "a psor sweep gave up" word of an earlier solve)
 }
 // MAF line solvers: order 0 = colour `sel` in place, 1 = lexicographic in place; xc, yc, zc device arrays
 void pcr_maf_async(REAL* x, const REAL* msk, const REAL* rhs, const int* sz, const int* idx, int g, int pn, int order, int sel,
@@ -1135,6 +1136,16 @@ int pair_maf_async(const REAL* u, REAL* w, const REAL* b, const int* sz, const i
   const int* skip = hist_dev ? flag_dev : skip_flag_dev;
   if (rb_ofst >= 0) return launch_jacobi2<1>(u, b, w, make_coef_omg(omg), bx, ba, skip, fin, rb_parity(g, idx, rb_ofst, 0), 0, false, &ma) ? 1 : 0;
   return launch_jacobi2<0>(u, b, w, make_coef_omg(omg), bx, ba, skip, fin, 0, 0, false, &ma) ? 1 : 0;
+}
+// has a one-launch psor sweep on this context given up a wait since the last call? (synchronises; the sweep's residual was NaN, the field is void)
+int psor_failed() {
+  ensure_init();
+  if (!ctx.psor_ctl) return 0;
+  unsigned h = 0;
+  HIP_CHECK(hipMemcpyAsync(&h, ctx.psor_ctl + 2, sizeof(h), hipMemcpyDeviceToHost, ctx.stream));
+  HIP_CHECK(hipStreamSynchronize(ctx.stream));
+  if (h) HIP_CHECK(hipMemsetAsync(ctx.psor_ctl + 2, 0, sizeof(unsigned), ctx.stream));
+  return h != 0;
 }
 // one psor / psor_maf sweep (xc == nullptr: constant coefficients cf), res_dev[0] = or += sum dp^2
 void psor_async(REAL* p, const REAL* b, const int* sz, const int* idx, int g, const REAL* cf, const REAL* xc, const REAL* yc,

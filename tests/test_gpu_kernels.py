@@ -537,14 +537,17 @@ def test_psor_golden_vectors(prec):
     assert h.last_flop == float(g["maf_psor_flop"])
 
 
+@pytest.mark.parametrize("form", [1, 0], ids=["one_launch", "tile_hyperplanes"])
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("box", [(16, 16, 16), (18, 18, 18), (33, 17, 50), (70, 41, 90), (5, 64, 7)], ids=lambda b: "x".join(map(str, b)))
-def test_psor_random_boxes_vs_oracle(prec, box):
-    """tile-hyperplane wavefront == the sequential loop, bit for bit; tiles that overhang the box, one-tile and many-tile boxes,
-    sub-boxes that do not start at 2."""
+@pytest.mark.parametrize("box", [(16, 16, 16), (18, 18, 18), (33, 17, 50), (70, 41, 90), (5, 64, 7), (36, 52, 20)], ids=lambda b: "x".join(map(str, b)))
+def test_psor_random_boxes_vs_oracle(prec, box, form):
+    """the wavefront of psor / psor_maf == the sequential loop, bit for bit, in both forms: the whole sweep in ONE launch (psor_col_k: columns of
+    workgroups walking k, faces handed from column to column through memory; round 3) and a launch per tile hyperplane (psor_tile_k); tiles
+    and columns that overhang the box, one and many of them, sub-boxes that do not start at 2."""
     ni, nj, nk = box
     sz = [ni, nj, nk]
     h, ko = _hip(prec), O.Kernels("oracle", prec)
+    assert h.lib.czhip_set_psor(form, -1) == 0
     R = ko.real
     rng = np.random.default_rng(ni * 7 + nj * 3 + nk)
     shape = (nj + 4, ni + 4, nk + 4)
@@ -564,6 +567,41 @@ def test_psor_random_boxes_vs_oracle(prec, box):
         r = h.psor_maf(dp, sz, idx, xc, yc, zc, 1.2, db)
         assert _beq(dp.get(), p1), idx
         assert _rel(r, float(w[0])) < 1e-12
+        # a second sweep on the same context (the face words of the first carry another sweep number)
+        ko.psor_maf(p1, sz, idx, xc, yc, zc, 1.2, b0)
+        h.psor_maf(dp, sz, idx, xc, yc, zc, 1.2, db)
+        assert _beq(dp.get(), p1), idx
+    h.lib.czhip_set_psor(1, -1)
+
+
+def test_psor_one_launch_gives_up_instead_of_hanging():
+    """Every wait of a column for the face words of the columns before it is bounded (the bound of czhip_set_pcr_lex_timeout): with the bound at
+    zero the columns far from the corner give up, every workgroup leaves, the call returns with a NaN residual -- and the next sweep, with the
+    normal bound, is right again."""
+    import ctypes as C
+    prec = "f32"
+    ni, nj, nk = 200, 180, 60
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    rng = np.random.default_rng(5)
+    shape = (nj + 4, ni + 4, nk + 4)
+    p0, b0 = (rng.uniform(-1, 1, shape).astype(ko.real) for _ in range(2))
+    cf = [1.1, 0.9, 1.05, 0.95, 1.2, 0.8, 6.3]
+    h.lib.czhip_set_pcr_lex_timeout.restype = C.c_double
+    h.lib.czhip_set_pcr_lex_timeout.argtypes = [C.c_double]
+    before = h.lib.czhip_set_pcr_lex_timeout(-1.0)
+    try:
+        h.lib.czhip_set_psor(1, -1)
+        h.lib.czhip_set_pcr_lex_timeout(0.0)
+        r = h.psor(h.alloc(sz, p0), sz, idx, cf, 1.2, h.alloc(sz, b0))
+        assert r != r, r  # NaN: the sweep is void
+        h.lib.czhip_set_pcr_lex_timeout(before)
+        p1, dp = p0.copy(), h.alloc(sz, p0)
+        ko.psor(p1, sz, idx, cf, 1.2, b0)
+        r = h.psor(dp, sz, idx, cf, 1.2, h.alloc(sz, b0))
+        assert r == r and _beq(dp.get(), p1)
+    finally:
+        h.lib.czhip_set_pcr_lex_timeout(before)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])

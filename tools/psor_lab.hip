@@ -139,13 +139,19 @@ int main(int argc, char** argv) {
   HIP_CHECK(hipGetDeviceProperties(&prop, 0));
   const int nblk = std::min(ncols, prop.multiProcessorCount * per_cu);
   unsigned seq = 0;
+  long long* prof = nullptr;
+  const bool want_prof = getenv("PSOR_PROF") != nullptr;
+  if (want_prof) {
+    HIP_CHECK(hipMalloc(&prof, (size_t)4 * ncols * sizeof(long long)));
+    HIP_CHECK(hipMemset(prof, 0, (size_t)4 * ncols * sizeof(long long)));
+  }
   for (int rep = 0; rep < reps; rep++) {
     HIP_CHECK(hipMemcpy(P2, P0, n * sizeof(REAL), hipMemcpyDeviceToDevice));
     seq++;
     HIP_CHECK(hipEventRecord(e0, 0));
     HIP_CHECK(hipMemsetAsync(ctl, 0, 256, 0));
-    if (maf) hipLaunchKernelGGL((psor_col_k<1>), dim3(nblk), dim3(PC_T * PC_T), 0, 0, P2, B, c, q, d_order, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma);
-    else hipLaunchKernelGGL((psor_col_k<0>), dim3(nblk), dim3(PC_T * PC_T), 0, 0, P2, B, c, q, d_order, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma);
+    if (maf) hipLaunchKernelGGL((psor_col_k<1>), dim3(nblk), dim3(PC_NT), 0, 0, P2, B, c, q, d_order, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
+    else hipLaunchKernelGGL((psor_col_k<0>), dim3(nblk), dim3(PC_NT), 0, 0, P2, B, c, q, d_order, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
     HIP_CHECK(hipEventRecord(e1, 0));
     HIP_CHECK(hipEventSynchronize(e1));
     HIP_CHECK(hipGetLastError());
@@ -153,6 +159,26 @@ int main(int argc, char** argv) {
     HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
     bestB = std::min(bestB, ms);
     HIP_CHECK(hipMemcpy(&resB, dst + 1, sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (want_prof) {
+    std::vector<long long> h((size_t)4 * ncols);
+    HIP_CHECK(hipMemcpy(h.data(), prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    long long t0 = h[0];
+    for (int cc = 0; cc < ncols; cc++) t0 = std::min(t0, h[4 * cc]);
+    const int nsteps = q.nk + 30;
+    // per diagonal: when its columns start / end, how long a column takes, how far behind its predecessor (a-1, b) a column starts
+    printf("diag: columns | start us (min..max) | duration us (mean) -> us per step | start behind (a-1,b) us (mean)\n");
+    for (int d = 0; d <= q.nti + q.ntj - 2; d += std::max(1, (q.nti + q.ntj) / 16)) {
+      double smin = 1e30, smax = 0, dur = 0, lag = 0;
+      int cntc = 0, nl = 0;
+      for (int a = std::max(0, d - (q.ntj - 1)); a <= std::min(q.nti - 1, d); a++) {
+        const int b = d - a, cc = a + q.nti * b;
+        const double st = (h[4 * cc] - t0) * 0.01, en = (h[4 * cc + 1] - t0) * 0.01;
+        smin = std::min(smin, st), smax = std::max(smax, st), dur += en - st, cntc++;
+        if (a > 0) lag += st - (h[4 * (cc - 1)] - t0) * 0.01, nl++;
+      }
+      printf("  %3d: %3d | %8.1f .. %8.1f | %7.1f -> %.3f | %6.1f\n", d, cntc, smin, smax, dur / cntc, dur / cntc / nsteps, nl ? lag / nl : 0.0);
+    }
   }
   unsigned long long* cnt;
   HIP_CHECK(hipMalloc(&cnt, 8));
