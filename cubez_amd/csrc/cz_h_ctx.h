@@ -40,7 +40,7 @@ struct Ctx {
   unsigned long long* psor_faces = nullptr;  // psor_col_k: the face words the columns hand to their high-side neighbours (one sweep)
   size_t psor_faces_cap = 0;
   int* psor_order = nullptr;                 // ... columns in the order of their diagonals (ticket -> column)
-  int psor_order_nti = 0, psor_order_ntj = 0;
+  int psor_order_nti = 0, psor_order_ntj = 0, psor_ntickets = 0;
   unsigned* psor_ctl = nullptr;              // ... ticket and error word
   unsigned psor_seq = 0;                     // ... sweeps so far: the number a valid face word carries
   REAL* pcr_scratch = nullptr;  // pcr_rb_k<GS = 1>: a, c, d of the lines in flight (lines too long for LDS)

@@ -515,17 +515,22 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
   const long long hi = (long long)bx.kk0 + (long long)(bx.ii1 + 1) * bx.nkp + (long long)(bx.jj1 + 1) * plane + g.nk + 2 * (PC_T - 1) + 48;
   if (bx.ii0 < 1 || bx.jj0 < 1 || bx.kk0 < 1 || lo < 0 || hi >= total) return false;
   const int ncols = g.nti * g.ntj;
+  constexpr int NC = 1;  // (two columns per workgroup were measured: one barrier for ten waves makes every step twice as long -- profiles/r03)
   if (ctx.psor_order_nti != g.nti || ctx.psor_order_ntj != g.ntj) {
+    // tickets in the order of the diagonals a + b; a ticket = NC columns of ONE diagonal (independent of each other), -1 = none
     std::vector<int> order;
-    for (int d = 0; d <= g.nti + g.ntj - 2; d++)
-      for (int a = std::max(0, d - (g.ntj - 1)); a <= std::min(g.nti - 1, d); a++) order.push_back(a + g.nti * (d - a));
+    for (int d = 0; d <= g.nti + g.ntj - 2; d++) {
+      int n = 0;
+      for (int a = std::max(0, d - (g.ntj - 1)); a <= std::min(g.nti - 1, d); a++, n++) order.push_back(a + g.nti * (d - a));
+      while (n % NC) order.push_back(-1), n++;
+    }
     if (ctx.psor_order) {
       HIP_CHECK(hipStreamSynchronize(ctx.stream));
       HIP_CHECK(hipFree(ctx.psor_order));
     }
-    HIP_CHECK(hipMalloc(&ctx.psor_order, (size_t)ncols * sizeof(int)));
-    HIP_CHECK(hipMemcpy(ctx.psor_order, order.data(), (size_t)ncols * sizeof(int), hipMemcpyHostToDevice));
-    ctx.psor_order_nti = g.nti, ctx.psor_order_ntj = g.ntj;
+    HIP_CHECK(hipMalloc(&ctx.psor_order, order.size() * sizeof(int)));
+    HIP_CHECK(hipMemcpy(ctx.psor_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+    ctx.psor_order_nti = g.nti, ctx.psor_order_ntj = g.ntj, ctx.psor_ntickets = (int)(order.size() / NC);
   }
   const size_t words = (size_t)2 * ncols * g.face_words;
   if (words > ctx.psor_faces_cap || ctx.psor_seq == 0xffffffffu) {
@@ -546,17 +551,18 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
     HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 256, ctx.stream));
   }
   ensure_partials((size_t)ncols);
-  const int per_cu = ctx.tune.psor_wg_per_cu > 0 ? std::min(ctx.tune.psor_wg_per_cu, 8) : 2;  // (6 waves of ~130 registers: two workgroups per CU)
-  const unsigned nblk = (unsigned)std::min(ncols, ctx.num_cu * per_cu);
+  const int per_cu = ctx.tune.psor_wg_per_cu > 0 ? std::min(ctx.tune.psor_wg_per_cu, 8) : 1;  // (what a CU holds: registers and 70 KB of LDS per column)
+  const int ntickets = ctx.psor_ntickets;
+  const unsigned nblk = (unsigned)std::min(ntickets, ctx.num_cu * per_cu);
   const unsigned seq = ++ctx.psor_seq;
   ScopedTimer tm(LBL_PSOR);
   HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 2 * sizeof(unsigned), ctx.stream));  // ticket and error word ([2]: sticky "a sweep gave up")
   if (ma)
-    hipLaunchKernelGGL((psor_col_k<1>), dim3(nblk), dim3(PC_NT), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
-                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, *ma, nullptr);
+    hipLaunchKernelGGL((psor_col_k<1, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
+                       ctx.psor_faces, seq, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, *ma, nullptr);
   else
-    hipLaunchKernelGGL((psor_col_k<0>), dim3(nblk), dim3(PC_NT), 0, ctx.stream, p, b, c, g, ctx.psor_order, ctx.psor_ctl, ctx.psor_faces, seq,
-                       ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs(), nullptr);
+    hipLaunchKernelGGL((psor_col_k<0, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
+                       ctx.psor_faces, seq, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs(), nullptr);
   HIP_CHECK(hipGetLastError());
   return true;
 }

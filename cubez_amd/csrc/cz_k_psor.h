@@ -49,34 +49,44 @@ __device__ __forceinline__ void pc_load(const REAL* __restrict__ p, REAL* o) {
   }
 }
 
-constexpr int PC_NT = PC_T * PC_T + 128;  // 256 computing threads + the wave that feeds the faces + the wave that takes them
+// threads of a workgroup that walks NC columns at once: NC x 256 computing threads + the wave that feeds the faces + the wave that takes
+// them (32 lanes of each per column).  Two columns (of ONE diagonal, hence independent) per workgroup double the columns in flight where a
+// CU holds one workgroup: ten waves spread over the four SIMDs as 3, 3, 2, 2 and fit the 3 waves per SIMD that ~150 registers allow, two
+// workgroups of six waves (2, 2, 1, 1 each) do not.
+constexpr int psor_col_threads(int nc) { return nc * PC_T * PC_T + 128; }
 
-template <int MAF>
-__global__ void __launch_bounds__(PC_NT)
-psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom g, const int* __restrict__ order, unsigned* ctl,
+template <int MAF, int NC>
+__global__ void __launch_bounds__(psor_col_threads(NC))
+psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom g, const int* __restrict__ order, int ntickets, unsigned* ctl,
            unsigned long long* faces, unsigned seq, long long spin_limit, double* partials, double* dst, int accumulate, unsigned* counter,
            const int* __restrict__ skip, MafArgs ma, long long* prof) {
   // prof (development aid, tools/psor_lab): per column {start, end} in ticks of the 100 MHz wall clock and the workgroup that ran it
   if (skip != nullptr && *skip != 0) return;
-  constexpr int NT = PC_NT, G = 4;  // threads; steps per group (one 16-byte access per stream and group)
+  constexpr int NT = psor_col_threads(NC);
+  // steps per group: one run of G elements per stream and group.  FP32: 32-byte runs (two 16-byte loads back to back) -- a CU sustains only so
+  // many line requests in flight, and with 16-byte runs every one of them fetched a line for 16 bytes: 1.42 -> 1.23 ms per 512^3 sweep
+  // (profiles/r03/psor_one_launch_vs_tile_hyperplanes.txt); FP64 stays at 16 elements per loop body = one line (the flush period)
+  constexpr int G = sizeof(REAL) == 4 ? 8 : 4;
+  constexpr int NCW = 4 * NC;                       // computing waves
   constexpr int HW = kPsorColHW;
   constexpr int NG = 4, NS = NG * G;  // the loop bodies cover NG groups: register rings with compile-time indices
-  __shared__ REAL sNEW[2][PC_L * PC_L], sOLD[2][PC_L * PC_L];
+  static_assert(NS <= 128 / (int)sizeof(REAL), "a loop body must not outrun the two-line output ring");
+  __shared__ REAL sNEW[NC][2][PC_L * PC_L], sOLD[NC][2][PC_L * PC_L];
   // The new values go back to memory as WHOLE 128-byte lines: written 16 bytes at a time as they are produced, a line left the XCD's L2 before
   // its other seven pieces arrived -- 2.1 GB of partial-line writes per 512^3 sweep where 0.53 GB are due (WRITE_SIZE, profiles/r03).  Every
   // thread therefore collects its values in a ring of two lines in LDS ([entry][thread]: conflict-free) and stores a line in one burst
   // once it is complete.
   constexpr int EL = 128 / (int)sizeof(REAL);  // elements per line
-  __shared__ REAL sOUT[2 * EL][PC_T * PC_T];
+  __shared__ REAL sOUT[NC][2 * EL][PC_T * PC_T];
   __shared__ double wsum[NT / 64 + 2];
-  __shared__ int sh[4];
+  __shared__ int sh[4 + NC];
   const int t = threadIdx.x;
   // Three kinds of wave.  Memory operations of a wave complete in the order they were issued (one counter, vmcnt, for loads AND stores): a
   // wave that stores write-through face words and waits for loads would wait for the acknowledgement of its stores at every load -- the
   // first version of this kernel did, and a column that fed another took 0.55 us per step instead of 0.36.  So:
-  //   waves 0..3  compute: stream their lines (loads, one plain 16-byte store per group); wave 0 also serves the OLD halo (loads)
-  //   wave  4     feeds: reads the new values of the column's high faces from the LDS plane and stores the face words -- stores only
-  //   wave  5     takes: reads the face words (or the boundary) of the low faces and publishes them in the NEW halo -- loads only
+  //   waves 0..4NC-1  compute (four per column): stream their lines (loads, whole-line plain stores); the first of a column also serves its OLD halo
+  //   the next wave   feeds: reads the new values of the columns' high faces from the LDS planes and stores the face words -- stores only
+  //   the last wave   takes: reads the face words (or the boundary) of the low faces and publishes them in the NEW halos -- loads only
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = t & 63;
   const int ncols = g.nti * g.ntj;
@@ -97,30 +107,35 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
     }
     __syncthreads();
     const int ticket = sh[0];
-    if (ticket >= ncols || sh[1] != 0 || sh[2] != 0) break;
-    const int col = order[ticket];
+    if (ticket >= ntickets || sh[1] != 0 || sh[2] != 0) break;
+    // this thread's column: computing threads by their block of 256, the lanes of the two other waves by their half
+    const int cs = (wv < NCW) ? (wv >> 2) : ((NC > 1) ? ((t >> 5) & 1) : 0);
+    const int colx = order[NC * ticket + cs];  // (-1: an odd column count on the diagonal leaves this place empty)
+    const bool has_col = colx >= 0;
+    const int col = has_col ? colx : order[NC * ticket];  // (an empty place shadows the ticket's first column: loads only, nothing stored)
     const int a = col % g.nti, b = col / g.nti;
     const int I0 = g.ii0 + a * PC_T, J0 = g.jj0 + b * PC_T;
     // face words: rows are indexed by r = k + (the coordinate inside the face); one row = PC_T values
     unsigned long long* faceI = faces + (size_t)(2 * col) * g.face_words;       // this column's high-i face, for column (a+1, b)
     unsigned long long* faceJ = faces + (size_t)(2 * col + 1) * g.face_words;   // high-j face, for column (a, b+1)
     double acc = 0.0;
-    if (prof && t == 0) prof[4 * col] = (long long)wall_clock64(), prof[4 * col + 2] = blockIdx.x;
+    if (prof && has_col && (t & 255) == 0 && wv < NCW) prof[4 * col] = (long long)wall_clock64(), prof[4 * col + 2] = blockIdx.x;
 
-    if (wv < 4) {
+    if (wv < NCW) {
       // ================================================================ compute waves
-      const int i = t & (PC_T - 1), j = t >> 4;
+      const int tc = t & 255;  // thread of the column
+      const int i = tc & (PC_T - 1), j = tc >> 4;
       const int li = (i + 1) + PC_L * (j + 1);  // this thread's place in an LDS plane
       const int gi = I0 + i, gj = J0 + j;
-      const bool col_in = gi <= g.ii1 && gj <= g.jj1;
+      const bool col_in = has_col && gi <= g.ii1 && gj <= g.jj1;
       // (threads beyond the box stream the boundary line next to it: their OLD values are what the last inner thread reads as i+1 / j+1)
       const int gic = min(gi, g.ii1 + 1), gjc = min(gj, g.jj1 + 1);
       REAL* line = P + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;  // element k = 0 of this thread's line
       const REAL* bline = B + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;
       // the OLD halo, served by lanes 0..31 of wave 0 as virtual threads (hi, hj) of the plane: (16, lane) and (lane - 16, 16)
-      const bool halo_wave = wv == 0;
-      const bool is_halo = t < 32;
-      const int hi = (t < 16) ? PC_T : (t & 15), hj = (t < 16) ? (t & 15) : PC_T;
+      const bool halo_wave = (wv & 3) == 0;
+      const bool is_halo = tc < 32;
+      const int hi = (tc < 16) ? PC_T : (tc & 15), hj = (tc < 16) ? (tc & 15) : PC_T;
       const int hli = (hi + 1) + PC_L * (hj + 1);
       const int hgi = is_halo ? min(I0 + hi, g.ii1 + 1) : g.ii0, hgj = is_halo ? min(J0 + hj, g.jj1 + 1) : g.jj0;
       const REAL* hline = P + (size_t)g.kk0 + (size_t)hgi * si + (size_t)hgj * sj;  // (other threads: one common line, never used)
@@ -138,7 +153,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
           for (int v = 0; v < EL; v += kRunW) {
             RunVec x;
 #pragma unroll
-            for (int w = 0; w < kRunW; w++) x[w] = sOUT[(c0 + v + w) % (2 * EL)][t];
+            for (int w = 0; w < kRunW; w++) x[w] = sOUT[cs][(c0 + v + w) % (2 * EL)][tc];
             const int k0 = c0 + v - phi;  // k of the vector's first element
             if (k0 >= 0 && k0 + kRunW <= g.nk) {
               *reinterpret_cast<RunVec*>(line + k0) = x;  // (16-byte aligned: c0 + v is a multiple of the vector width)
@@ -181,9 +196,9 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       // What the planes hold for step s + 1 is published in step s: the new value of this thread's k (read as i-1 / j-1 next door), its old
       // value two points ahead (read as i+1 / j+1), and -- wave 0 -- the OLD halo.
       auto publish = [&](int nxt, REAL nv, REAL old2, REAL hv) __attribute__((always_inline)) {
-        sNEW[nxt][li] = nv;
-        sOLD[nxt][li] = old2;
-        if (halo_wave && is_halo) sOLD[nxt][hli] = hv;  // old value two points ahead of the virtual thread's k
+        sNEW[cs][nxt][li] = nv;
+        sOLD[cs][nxt][li] = old2;
+        if (halo_wave && is_halo) sOLD[cs][nxt][hli] = hv;  // old value two points ahead of the virtual thread's k
       };
       publish(0, (REAL)0, pbuf[1], hbuf[1]);  // step -1: nothing is computed, the planes of step 0 are published
       lds_barrier();
@@ -201,8 +216,8 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
             const bool active = col_in && k >= 0 && k < g.nk;
             // ---- operands
             const REAL pp = pbuf[m], kp1 = pbuf[(m + 1) % NS];
-            const REAL im1 = sNEW[cur][li - 1], jm1 = sNEW[cur][li - PC_L];
-            const REAL ip1 = sOLD[cur][li + 1], jp1 = sOLD[cur][li + PC_L];
+            const REAL im1 = sNEW[cs][cur][li - 1], jm1 = sNEW[cs][cur][li - PC_L];
+            const REAL ip1 = sOLD[cs][cur][li + 1], jp1 = sOLD[cs][cur][li + PC_L];
             REAL nv = pp;
             if (active) {
               REAL dp;
@@ -221,7 +236,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
               acc += (double)d2;
               prev_new = nv;
             }
-            if (active) sOUT[(phi + k) % (2 * EL)][t] = nv;
+            if (active) sOUT[cs][(phi + k) % (2 * EL)][tc] = nv;
             publish(nxt, nv, pbuf[(m + 2) % NS], hbuf[(m + 2) % NS]);
             lds_barrier();
           }
@@ -235,13 +250,14 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
         if (sh[2] != 0) break;  // a wait was given up (written before a barrier every thread has passed)
       }
       flush_lines(g.nk - 1, true);  // what is left: the last, incomplete line
-    } else if (wv == 4) {
+    } else if (wv == NCW) {
       // ================================================================ the wave that feeds the faces (stores only)
       // At step s the plane `cur` holds what the computing threads published in step s - 1: thread (15, j) its new value of k = s - 16 - j,
-      // thread (i, 15) of k = s - 16 - i -- row s - 16 of both faces.  Lanes 0..15: face I (j = lane); lanes 16..31: face J (i = lane - 16).
+      // thread (i, 15) of k = s - 16 - i -- row s - 16 of both faces.  Of each half of the wave (one per column): lanes 0..15 face I (j = lane),
+      // lanes 16..31 face J (i = lane - 16).
       const int fc = lane & 15;                       // coordinate inside the face
-      const bool toI = lane < 16;
-      const bool feeds = lane < 32 && (toI ? (a + 1 < g.nti && J0 + fc <= g.jj1) : (b + 1 < g.ntj && I0 + fc <= g.ii1));
+      const bool toI = (lane & 16) == 0;
+      const bool feeds = has_col && (NC > 1 || lane < 32) && (toI ? (a + 1 < g.nti && J0 + fc <= g.jj1) : (b + 1 < g.ntj && I0 + fc <= g.ii1));
       const int src = toI ? (PC_T + PC_L * (fc + 1)) : ((fc + 1) + PC_L * PC_T);  // LDS place of thread (15, fc) / (fc, 15)
       unsigned long long* face = toI ? faceI : faceJ;
       lds_barrier();  // (step -1)
@@ -249,7 +265,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
         const int cur = s & 1;
         const int k = s - PC_T - fc;  // what that thread computed in the step before
         if (feeds && k >= 0 && k < g.nk) {
-          const REAL nv = sNEW[cur][src];
+          const REAL nv = sNEW[cs][cur][src];
           const unsigned long long tag = (unsigned long long)seq << 32;
           unsigned long long* q = face + ((size_t)(k + fc) * PC_T + fc) * HW;
           if (sizeof(REAL) == 8) {
@@ -270,12 +286,12 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       // publishes, for step s + 1, the new value of k = s - hi - hj = s + 1 - (coordinate): row s + 1 of the face.  Words and boundary
       // values are asked for eight steps ahead (rq / bq[s & 7]); a word that has not arrived is read again until it carries this sweep's number.
       const int hc = lane & 15;
-      const bool fromI = lane < 16;
-      const bool takes = lane < 32;
+      const bool fromI = (lane & 16) == 0;
+      const bool takes = NC > 1 || lane < 32;  // (of each half of the wave, one per column: lanes 0..15 the i side, 16..31 the j side)
       const int hi = fromI ? -1 : hc, hj = fromI ? hc : -1;
       const int hli = (hi + 1) + PC_L * (hj + 1);
       // (a face word exists only for the rows of the box: the lanes of a partial column's missing rows have nothing to wait for)
-      const bool h_ring = takes && (fromI ? (a > 0 && J0 + hc <= g.jj1) : (b > 0 && I0 + hc <= g.ii1));
+      const bool h_ring = has_col && takes && (fromI ? (a > 0 && J0 + hc <= g.jj1) : (b > 0 && I0 + hc <= g.ii1));
       const unsigned long long* rin = faces;  // (lanes without a face: a valid dummy)
       if (h_ring) rin = faces + (size_t)(fromI ? 2 * (col - 1) : 2 * (col - g.nti) + 1) * g.face_words;
       const int hgi = takes ? min(max(I0 + hi, g.ii0 - 1), g.ii1 + 1) : g.ii0, hgj = takes ? min(max(J0 + hj, g.jj0 - 1), g.jj1 + 1) : g.jj0;
@@ -315,7 +331,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
         REAL rv;
         if (sizeof(REAL) == 8) rv = (REAL)__longlong_as_double((long long)((rq[slot][0] & 0xffffffffull) | (rq[slot][HW - 1] << 32)));
         else rv = (REAL)__uint_as_float((unsigned)(rq[slot][0] & 0xffffffffull));
-        if (takes) sNEW[nxt][hli] = need ? rv : bq[slot];  // (a face lane outside its range publishes something nobody reads)
+        if (takes) sNEW[cs][nxt][hli] = need ? rv : bq[slot];  // (a face lane outside its range publishes something nobody reads)
         ask(slot, s + 8);
       };
 #pragma unroll
@@ -332,9 +348,14 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       }
     }
     __syncthreads();
-    if (prof && t == 0) prof[4 * col + 1] = (long long)wall_clock64();
-    const double sblk = block_sum<NT>(acc, wsum);
-    if (t == 0) __hip_atomic_store(&partials[col], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prof && has_col && (t & 255) == 0 && wv < NCW) prof[4 * col + 1] = (long long)wall_clock64();
+    // one partial sum per column (in the order of the columns whatever NC is: the same bits)
+#pragma unroll
+    for (int n = 0; n < NC; n++) {
+      const double sblk = block_sum<NT>((wv < NCW && cs == n) ? acc : 0.0, wsum);
+      if (t == 0 && order[NC * ticket + n] >= 0) __hip_atomic_store(&partials[order[NC * ticket + n]], sblk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
   }
   // ---- residual: the columns' partials in column order, by the workgroup that arrives last (hand-off as in stencil_k)
   const int nblk = gridDim.x;

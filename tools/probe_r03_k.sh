@@ -2,4 +2,4 @@
 cd "$(dirname "$0")/.."
 O=gpurun_out/probe_k
 mkdir -p $O
-(for a in "36 52 20" "18 18 18" "33 17 50" "20 20 20" "36 36 34" "36 36 20" "24 20 36"; do tools/bin/psor_lab $a 2 0; done; tools/bin/psor_lab64 36 52 20 2 0; tools/bin/psor_lab64 24 20 36 2 0) 2>&1 | tee $O/psor_small.log
+(for b in psor_lab psor_lab_g8; do for a in "70 50 40 2 0" "36 52 20 2 0" "256 256 256 3 0" "512 512 512 4 0"; do timeout -k 5 60 tools/bin/$b $a || exit 1; done; done) 2>&1 | tee $O/psor_g8.log

@@ -51,7 +51,7 @@ __global__ void sum_k(const double* p, int n, double* out) {
 
 int main(int argc, char** argv) {
   const int ni = argc > 1 ? atoi(argv[1]) : 128, nj = argc > 2 ? atoi(argv[2]) : ni, nk = argc > 3 ? atoi(argv[3]) : ni;
-  const int reps = argc > 4 ? atoi(argv[4]) : 5, maf = argc > 5 ? atoi(argv[5]) : 0, per_cu = argc > 6 ? atoi(argv[6]) : 4;
+  const int reps = argc > 4 ? atoi(argv[4]) : 5, maf = argc > 5 ? atoi(argv[5]) : 0, per_cu = argc > 6 ? atoi(argv[6]) : 1;
   const int nip = ni + 4, njp = nj + 4, nkp = nk + 4;
   const size_t n = (size_t)nip * njp * nkp;
   REAL *P0, *B, *P1, *P2;
@@ -122,14 +122,22 @@ int main(int argc, char** argv) {
   q.nti = (ii1 - ii0 + PC_T) / PC_T, q.ntj = (jj1 - jj0 + PC_T) / PC_T;
   q.face_words = (long long)(q.nk + PC_T) * PC_T * kPsorColHW;
   const int ncols = q.nti * q.ntj;
+#ifndef PSOR_NC
+#define PSOR_NC 1
+#endif
+  constexpr int NC = PSOR_NC;
   std::vector<int> order;
-  for (int d = 0; d <= q.nti + q.ntj - 2; d++)
-    for (int a = std::max(0, d - (q.ntj - 1)); a <= std::min(q.nti - 1, d); a++) order.push_back(a + q.nti * (d - a));
+  for (int d = 0; d <= q.nti + q.ntj - 2; d++) {
+    int nn = 0;
+    for (int a = std::max(0, d - (q.ntj - 1)); a <= std::min(q.nti - 1, d); a++, nn++) order.push_back(a + q.nti * (d - a));
+    while (nn % NC) order.push_back(-1), nn++;
+  }
+  const int ntickets = (int)(order.size() / NC);
   int* d_order;
   unsigned *ctl, *counter;
   unsigned long long* faces;
-  HIP_CHECK(hipMalloc(&d_order, ncols * sizeof(int)));
-  HIP_CHECK(hipMemcpy(d_order, order.data(), ncols * sizeof(int), hipMemcpyHostToDevice));
+  HIP_CHECK(hipMalloc(&d_order, order.size() * sizeof(int)));
+  HIP_CHECK(hipMemcpy(d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
   HIP_CHECK(hipMalloc(&ctl, 256));
   HIP_CHECK(hipMalloc(&counter, 64));
   HIP_CHECK(hipMemset(counter, 0, 64));
@@ -137,7 +145,7 @@ int main(int argc, char** argv) {
   HIP_CHECK(hipMemset(faces, 0, (size_t)2 * ncols * q.face_words * sizeof(unsigned long long)));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, 0));
-  const int nblk = std::min(ncols, prop.multiProcessorCount * per_cu);
+  const int nblk = std::min(ntickets, prop.multiProcessorCount * per_cu);
   unsigned seq = 0;
   long long* prof = nullptr;
   const bool want_prof = getenv("PSOR_PROF") != nullptr;
@@ -150,8 +158,8 @@ int main(int argc, char** argv) {
     seq++;
     HIP_CHECK(hipEventRecord(e0, 0));
     HIP_CHECK(hipMemsetAsync(ctl, 0, 256, 0));
-    if (maf) hipLaunchKernelGGL((psor_col_k<1>), dim3(nblk), dim3(PC_NT), 0, 0, P2, B, c, q, d_order, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
-    else hipLaunchKernelGGL((psor_col_k<0>), dim3(nblk), dim3(PC_NT), 0, 0, P2, B, c, q, d_order, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
+    if (maf) hipLaunchKernelGGL((psor_col_k<1, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, 0, P2, B, c, q, d_order, ntickets, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
+    else hipLaunchKernelGGL((psor_col_k<0, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, 0, P2, B, c, q, d_order, ntickets, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
     HIP_CHECK(hipEventRecord(e1, 0));
     HIP_CHECK(hipEventSynchronize(e1));
     HIP_CHECK(hipGetLastError());
