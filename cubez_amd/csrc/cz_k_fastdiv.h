@@ -91,7 +91,36 @@ __device__ __forceinline__ double fastdiv(double n, const FastDiv<double>& f) {
   return __builtin_amdgcn_div_fixup(q, f.d, n);
 }
 
+// The short form (FP32): with r = RN(1/d), q0 = n*r is within an ulp of the quotient, e = n - d*q0 is exact in one fma, and
+// q1 = q0 + e*r rounds to the correctly rounded quotient -- where nothing underflows on the way.  div_fixup supplies zeros with their
+// sign, infinities and NaNs.  4 instructions against 10.  "Where nothing underflows" is not argued but CHECKED: a divisor takes this
+// form only after shortdiv_check_k has compared it with `n / d` for all 2^32 numerators (czhip fastdiv gate, cz_kernels.hip); any
+// difference and the divisor keeps the form above.
+__device__ __forceinline__ float shortdiv(float n, const FastDiv<float>& f) {
+  const float q0 = n * f.r1;
+  const float e = __builtin_fmaf(-f.d, q0, n);
+  const float q1 = __builtin_fmaf(e, f.r1, q0);
+  return __builtin_amdgcn_div_fixupf(q1, f.d, n);
+}
+__device__ __forceinline__ double shortdiv(double n, const FastDiv<double>& f) { return fastdiv(n, f); }  // (FP64: no short form)
+
+// The hoisted form with ONE correction step instead of two (FP32; the FP64 form above has one already): q0 = num_s * r1 is within an ulp
+// when r1 is the correctly rounded reciprocal, and div_fmas rounds once, also into the subnormal range.  8 instructions against 10.
+// Checked per divisor like the short form.
+__device__ __forceinline__ float mediumdiv(float n, const FastDiv<float>& f) {
+  bool vcc, unused;
+  const float den_s = __builtin_amdgcn_div_scalef(n, f.d, false, &unused);
+  const float num_s = __builtin_amdgcn_div_scalef(n, f.d, true, &vcc);
+  const float r1 = (den_s == f.d) ? f.r1 : f.r1s;
+  const float q0 = num_s * r1;
+  const float e2 = __builtin_fmaf(-den_s, q0, num_s);
+  const float q = __builtin_amdgcn_div_fmasf(e2, r1, q0, vcc);
+  return __builtin_amdgcn_div_fixupf(q, f.d, n);
+}
+__device__ __forceinline__ double mediumdiv(double n, const FastDiv<double>& f) { return fastdiv(n, f); }
+
 // every numerator of the self-test (see above); counts results whose bits differ from the compiler's n / d (two NaNs count as equal)
+template <int SHORT>
 __global__ void fastdiv_check_k(REAL d, unsigned long long* bad) {
   const FastDiv<REAL> f = fastdiv_init(d);
   unsigned long long c = 0;
@@ -111,7 +140,7 @@ __global__ void fastdiv_check_k(REAL d, unsigned long long* bad) {
       const unsigned long long b = (se << 52) | (mant & 0xfffffffffffffull);
       __builtin_memcpy(&n, &b, sizeof(REAL));
     }
-    const REAL q = fastdiv(n, f), r = n / d;
+    const REAL q = SHORT == 1 ? shortdiv(n, f) : SHORT == 2 ? mediumdiv(n, f) : fastdiv(n, f), r = n / d;
     if ((sizeof(REAL) == 4 ? (__builtin_bit_cast(unsigned, (float)q) != __builtin_bit_cast(unsigned, (float)r)) : (__builtin_bit_cast(unsigned long long, (double)q) != __builtin_bit_cast(unsigned long long, (double)r))) && !(q != q && r != r)) c++;
   }
   if (c) atomicAdd(bad, c);

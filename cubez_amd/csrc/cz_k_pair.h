@@ -66,6 +66,16 @@ struct HoistedDiv {
   __device__ __forceinline__ REAL operator()(REAL n) const { return fastdiv(n, f); }
 };
 
+struct ShortDiv {  // cz_k_fastdiv.h: only for divisors that passed the exhaustive comparison
+  FastDiv<REAL> f;
+  __device__ __forceinline__ REAL operator()(REAL n) const { return shortdiv(n, f); }
+};
+
+struct MediumDiv {
+  FastDiv<REAL> f;
+  __device__ __forceinline__ REAL operator()(REAL n) const { return mediumdiv(n, f); }
+};
+
 template <int V, class DIV>
 __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
                                             const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c, const DIV& dv,

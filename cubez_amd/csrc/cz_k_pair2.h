@@ -150,6 +150,10 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
   double acc1 = 0.0, acc2 = 0.0;
 #ifdef CZ_P2_PLAIN_DIV  // tools/pair_lab A/B only
   const PlainDiv dv{c.dd};
+#elif defined(CZ_P2_SHORT_DIV)
+  const ShortDiv dv{fastdiv_init(c.dd)};
+#elif defined(CZ_P2_MEDIUM_DIV)
+  const MediumDiv dv{fastdiv_init(c.dd)};
 #else
   const HoistedDiv dv{fastdiv_init(c.dd)};  // exact IEEE quotients, the divisor's share of the work done once (cz_k_fastdiv.h)
 #endif

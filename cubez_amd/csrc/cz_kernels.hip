@@ -490,7 +490,7 @@ long long czhip_selftest_fastdiv(CZ_REAL d) {
   unsigned long long* bad = nullptr;
   HIP_CHECK(hipMalloc(&bad, sizeof(*bad)));
   HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(*bad), ctx.stream));
-  hipLaunchKernelGGL(fastdiv_check_k, dim3(4096), dim3(256), 0, ctx.stream, d, bad);
+  hipLaunchKernelGGL(fastdiv_check_k<0>, dim3(4096), dim3(256), 0, ctx.stream, d, bad);
   HIP_CHECK(hipGetLastError());
   unsigned long long h = 0;
   HIP_CHECK(hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, ctx.stream));
