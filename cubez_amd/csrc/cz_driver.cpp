@@ -631,7 +631,9 @@ bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int
 int CZ::finish_stationary(int itr_max, int first_itr, bool converge_check, double& res) {
   (void)first_itr;
   if (!converge_check) {
-    czhip_sync();
+    // (a preconditioner solve inside BiCGSTAB returns without draining: 20-30 us of idle GPU per solve otherwise, see
+    // profiles/r03/bicgstab_iteration_timeline_512_f64.txt)
+    if (!in_precond) czhip_sync();
     return itr_max + 1;
   }
   HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, stream()));
@@ -1286,6 +1288,11 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
   // (single-domain only: a decomposed run leaves the neighbours' values in xx's ghost layers)
   const bool zero_start = (s_type == LS_JACOBI) && numProc == 1 && czhip_use_t2() != 0 && xx_shell_is_zero(xx);
   if (!zero_start) HIP_CHECK(hipMemsetAsync(xx, 0, nbytes, stream()));
+  struct Scope {
+    bool& f;
+    explicit Scope(bool& x) : f(x) { f = true; }
+    ~Scope() { f = false; }
+  } scope(in_precond);
   switch (s_type) {
     case LS_JACOBI:
     case LS_JACOBI_MAF:

@@ -68,6 +68,7 @@ class CZ {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_shell = nullptr, ev_src = nullptr, ev_comm = nullptr, ev_int = nullptr, ev_chk[2] = {nullptr, nullptr};
   bool pairs_ok = true;          // decomposed runs: EVERY brick can run the fused pass (agreed at set-up; the exchange pattern depends on it)
+  bool in_precond = false;       // inside Preconditioner: an unchecked solve does not drain the queue (the caller's next launch follows in stream order)
   int last_lag = 0;              // the last stationary solve ran its all-reduce + test one pass behind (cz_info)
   int skew_rank = -1, skew_ms = 0;  // CZ_TEST_SKEW=rank,ms: that rank sleeps before each look at the convergence flag (tests)
   void skew_wait() const;

@@ -104,11 +104,20 @@ def test_bicgstab_vs_golden(case):
     hist = np.array(g["hist"][:m])
     run_gpu = np.maximum.accumulate(np.abs(hist - ref[:m]) / ref[:m])
     run_perm = np.maximum.accumulate(np.abs(perm[:m] - ref[:m]) / ref[:m])
-    # floor: the stated 1e-6, or -- FP32 -- the error the reference's sequential REAL accumulation of an n-term dot product carries
-    # against the exact sum the GPU rounds once (random-walk estimate sqrt(n) eps, x10): two orderings of the same REAL sum share most of it
-    npts = float(np.prod([n - 2 for n in case["gsz"]]))
-    floor = max(1e-6, 10.0 * np.sqrt(npts) * float(np.finfo(np.float32 if case["prec"] == "f32" else np.float64).eps))
-    assert np.all(run_gpu <= np.maximum(floor, DRIFT_FACTOR * run_perm)), (case["tag"], run_gpu[-1], run_perm[-1])
+    # floor: the stated 1e-6, or -- FP32 -- the error the reference's sequential REAL accumulation of its dot products carries against
+    # the sum the GPU rounds once, which two orderings of the same REAL sum largely share.  MEASURED (round 2 used the
+    # random-walk estimate 10 sqrt(n) eps): the same reference kernels run once more with the dot products accumulated in double
+    # (the oracle's wide mode, which test_oracle_vs_reference pins to the reference), twice its running deviation from the reference.
+    floor = np.full(m, 1e-6)
+    if case["prec"] == "f32":
+        w = O.run(case["gsz"], case["solver"], case["itr_max"], case["coef"], case["precond"], kind="oracle", prec="f32", wide=True)
+        wide = np.array([r for _, r in w.history])
+        mw = min(m, len(wide))
+        run_wide = np.maximum.accumulate(np.abs(wide[:mw] - ref[:mw]) / ref[:mw])
+        floor[:mw] = np.maximum(floor[:mw], 2.0 * run_wide)
+        floor[mw:] = floor[mw - 1]
+    assert np.all(run_gpu <= np.maximum(floor, DRIFT_FACTOR * run_perm)), (case["tag"], run_gpu[-1], run_perm[-1], floor[-1])
+    floor = float(floor[-1])
     if band == 0:
         tol = max(floor, DRIFT_FACTOR * abs(p["res"] - p["res_reference"]) / p["res_reference"])
         assert abs(g["res"] - case["res"]) <= tol * case["res"]
