@@ -45,7 +45,7 @@ ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--repeats", type=int, default=5, help="how many times the --steps region is timed (median reported)")
 ap.add_argument("--settle", type=float, default=0.15, help="seconds of untimed sweeps before the warm-up steps (clock ramp)")
-ap.add_argument("--n", type=int, default=512, help="cells per GPU and axis")
+ap.add_argument("--n", "--cells", dest="n", type=int, default=512, help="cells per GPU and axis (--cells: the spelling torch.distributed.run does not take for one of its own options)")
 ap.add_argument("--solver", default="jacobi", choices=SOLVERS)
 ap.add_argument("--precond", default="jacobi", choices=["none", "jacobi", "sor2sma"])
 ap.add_argument("--prec", default=None, choices=["f32", "f64"])
@@ -97,6 +97,14 @@ if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
 rank = int(os.environ.get("RANK", "0"))
 world = int(os.environ.get("WORLD_SIZE", "1"))
 local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+# Rehearsal of the multi-rank line on a box with ONE GPU (tests/test_gpu_rccl.py): every rank on device 0, RCCL told that each rank is a host
+# of its own so that it takes the socket transport over loopback.  The line says so ("rehearsal"); it is not a measurement of anything.
+ONE_GPU = os.environ.get("CZ_BENCH_ONE_GPU") == "1" and world > 1
+if ONE_GPU:
+    os.environ["NCCL_HOSTID"] = f"cz-bench-one-gpu-rank-{rank}"
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    local_rank = 0
 if world != args.gpus:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -383,6 +391,8 @@ if rank == 0:
                    "step": "one sweep + residual reduction + convergence bookkeeping (cz_Poisson.cpp:39-79)"},
         "roofline": roofline_of(m),
     }
+    if ONE_GPU:
+        out["rehearsal"] = f"{world} RCCL ranks (processes) sharing ONE GPU, socket transport over loopback: exercises the code of the multi-GPU line, measures nothing"
     if world > 1:
         nk2, kern2_ms = m["fused"]
         out["multi_gpu"] = {"ranks": devs, "rccl_ranks": info["rccl_ranks"], "fused_pass": bool(info["fused_pass"]), "shell_slabs_rank0": info["shell_slabs"],

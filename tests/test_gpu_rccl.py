@@ -115,3 +115,30 @@ def test_rccl_ranks_bicgstab():
     assert all(rec["itr"] == itr1 and rec["info"]["rccl_ranks"] == 4 for rec in recs)
     assert np.allclose(recs[0]["history"], hist1, rtol=1e-6, atol=0)
     assert np.abs(G[2:-2, 2:-2, 2:-2] - P1[2:-2, 2:-2, 2:-2]).max() < 1e-9
+
+
+@pytest.mark.parametrize("gpus,extra", [(2, []), (4, []), (2, ["--solver", "sor2sma"])], ids=["2_ranks", "4_ranks", "2_ranks_rbsor"])
+def test_bench_line_of_a_multi_rank_run(gpus, extra):
+    """The command the driver runs for N > 1 -- `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- rehearsed with
+    the N ranks on the one GPU of the box (CZ_BENCH_ONE_GPU=1: every rank on device 0, one RCCL host id per rank): rendezvous, id broadcast,
+    ncclCommInitRank, the timed loop with its barriers and max over ranks, the rccl_ranks check, exposed_ms_per_step, ONE JSON line from
+    rank 0.  The numbers mean nothing (the ranks share the GPU); that the line exists and what it says about the path does."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.update({"CZ_BENCH_ONE_GPU": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "OMP_NUM_THREADS": "1", "CZ_COMM_TIMEOUT": "90"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(gpus), "--steps", "8", "--warmup", "2", "--repeats", "2", "--settle", "0", "--cells", "96"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["steps"] == 8 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "rehearsal" in d
+    assert d["config"]["division"] == {2: [1, 2, 1], 4: [2, 2, 1]}[gpus]
+    mg = d["multi_gpu"]
+    assert mg["rccl_ranks"] == gpus and [x["rccl_ranks"] for x in mg["ranks"]] == [gpus] * gpus
+    assert mg["fused_pass"] and mg["overlap"] and mg["shell_slabs_rank0"] > 0 and mg["comm_cus_per_xcd"] == 2
+    assert mg["exposed_ms_per_step"] is not None and d["roofline"]["kernel_launches_timed"] > 0
