@@ -710,10 +710,14 @@ CZ::PassPlan CZ::plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, 
 // ------------------------------------------------------------------------------------------------------------
 // cz_Poisson.cpp:30-82
 int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check,
-               bool x_is_zero) {
+               bool x_is_zero, const BMade* made) {
   const int gc = GUIDE;
   hipStream_t st = stream();
   const PassPlan plan = plan_pass(X, B, s_type, itr_max, converge_check, x_is_zero, false);
+  if (made && !(plan.kind == PassPlan::WHOLE && plan.zero_start)) {  // (bicg_fusable asked the same questions before the update was withheld)
+    printf("error : the solve that was to make its right-hand side does not start with a whole fused pass from zero\n");
+    exit(1);
+  }
   const bool maf = plan.maf != 0;  // cz_Poisson.cpp:45-53
   const MafPtrs mp{d_xc, d_yc, d_zc, nullptr};
   const MafPtrs* mpp = maf ? &mp : nullptr;
@@ -789,7 +793,10 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
     } else if (pass) {  // the whole inner box in one launch
       const bool in_kernel_check = converge_check && numProc == 1;
       int launched;
-      if (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner): neither cleared in memory nor read
+      if (plan.zero_start && itr == 1 && made)  // ... and the right-hand side made on the way (BiCGSTAB's vector update folded in)
+        launched = czhip_jacobi2_from_zero_made_async(src, dst, B, made->op, made->x, made->y, made->z, made->a, made->b, size, innerFidx, idx1, gc,
+                                                      cf, ac1, d_res, 0);
+      else if (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner): neither cleared in memory nor read
         launched = czhip_jacobi2_from_zero_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res);
       else if (maf)
         launched = pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, -1, d_res, res_normal, eps, itr,
@@ -1278,7 +1285,22 @@ REAL_TYPE CZ::Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop) {
 bool CZ::xx_shell_is_zero(const REAL_TYPE* xx) const { return xx == pcg_p_ || xx == pcg_s_; }
 
 // cz_Poisson.cpp:273-322
-void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) {
+// May PBiCGSTAB withhold `p = r + beta (p - omega q)` and `s = r - alpha q` and let the first pair of the preconditioner solve that follows
+// make them (jacobi2p_k<BS>)?  Plain Jacobi preconditioner on the whole-box fused pass with the literal zero start, one rank (a decomposed
+// solve reads the right-hand side in its ghost layer, where the operands are not valid), and the launcher takes it.  CZ_BICG_FUSE=0: never.
+bool CZ::bicg_fusable(int pc_type) {
+  const char* e = getenv("CZ_BICG_FUSE");
+  if (e && atoi(e) == 0) return false;
+  if (pc_type != LS_JACOBI || numProc != 1 || czhip_use_t2() == 0) return false;
+  const PassPlan plan = plan_pass(pcg_p_, pcg_p, LS_JACOBI, 8, false, true, false);
+  if (!(plan.kind == PassPlan::WHOLE && plan.zero_start)) return false;
+  int idx1[6];
+  for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f];
+  return czhip_jacobi2_from_zero_made_async(pcg_p_, WRK, pcg_s, 2, pcg_r, pcg_q, pcg_p, (REAL_TYPE)0, (REAL_TYPE)0, size, innerFidx, idx1, GUIDE, cf, ac1,
+                                            d_res, 1) != 0;
+}
+
+void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type, const BMade* made) {
   double res = 0.0;
   const int lc_max = 8;  // :280
   const size_t nbytes = (size_t)(size[0] + 2 * GUIDE) * (size[1] + 2 * GUIDE) * (size[2] + 2 * GUIDE) * sizeof(REAL_TYPE);
@@ -1296,7 +1318,7 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type) 
   switch (s_type) {
     case LS_JACOBI:
     case LS_JACOBI_MAF:
-      JACOBI(res, xx, bb, lc_max, flop, s_type, false, zero_start);
+      JACOBI(res, xx, bb, lc_max, flop, s_type, false, zero_start, made);
       break;
     case LS_SOR2SMA:
     case LS_SOR2SMA_MAF:
@@ -1358,6 +1380,10 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     return true;
   };
   REAL_TYPE rho_next = 0.0;
+  // The two vector updates that make the right-hand side of a preconditioner solve (:398, :434) are folded into the first pair of that solve
+  // where it is the whole-box fused pass from a literal zero: one launch and one read of an array less per solve.
+  const bool fuse = !maf && bicg_fusable(pc_type);
+  bicg_fused = 0;
 
   for (itr = 1; itr < ItrMax; itr++) {  // :373
     REAL_TYPE rho;
@@ -1373,16 +1399,25 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
       itr = 0;
       break;
     }
+    BMade made_p{0, nullptr, nullptr, nullptr, (REAL_TYPE)0, (REAL_TYPE)0};
     if (itr == 1) {
       HIP_CHECK(hipMemcpyAsync(pcg_p, pcg_r, nbytes, hipMemcpyDeviceToDevice, st));  // :387
     } else {
       REAL_TYPE beta = rho / rho_old * alpha / omega;  // :394
-      bicg1_async(pcg_p, pcg_r, pcg_q, beta, omega, size, innerFidx, gc);  // :398
+      if (fuse) {
+        // :398 withheld: the first pair of the solve below makes p = r + beta (p - omega q) on its way and writes it to the array of s
+        // (dead until :434), which then IS p -- the pass cannot update p in place: neighbouring workgroups read each other's rows
+        made_p = BMade{2, pcg_r, pcg_q, pcg_p, beta, omega};
+        std::swap(pcg_p, pcg_s);
+        bicg_fused++;
+      } else {
+        bicg1_async(pcg_p, pcg_r, pcg_q, beta, omega, size, innerFidx, gc);  // :398
+      }
       flop += 4.0 * npts();
     }
     if (!Comm_S(pcg_p)) return 0;                    // :402
     flop_count = 0.0;                                // :405 blas_clear_(pcg_p_) happens inside Preconditioner
-    Preconditioner(pcg_p_, pcg_p, flop_count, pc_type);  // :409
+    Preconditioner(pcg_p_, pcg_p, flop_count, pc_type, made_p.op ? &made_p : nullptr);  // :409
     flop += flop_count;
     if (line_error) return 0;
 
@@ -1394,12 +1429,14 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     alpha = rho / q_r0;  // :427
 
     REAL_TYPE r_alpha = -alpha;
-    triad_async(pcg_s, pcg_q, pcg_r, r_alpha, size, innerFidx, gc);  // :434
+    BMade made_s{1, pcg_q, pcg_r, nullptr, r_alpha, (REAL_TYPE)0};
+    if (fuse) bicg_fused++;  // :434 withheld likewise: s = r - alpha q
+    else triad_async(pcg_s, pcg_q, pcg_r, r_alpha, size, innerFidx, gc);  // :434
     flop += 2.0 * npts();
     if (!Comm_S(pcg_s)) return 0;  // :438
 
     flop_count = 0.0;  // :441 blas_clear_(pcg_s_) happens inside Preconditioner
-    Preconditioner(pcg_s_, pcg_s, flop_count, pc_type);  // :445
+    Preconditioner(pcg_s_, pcg_s, flop_count, pc_type, fuse ? &made_s : nullptr);  // :445
     flop += flop_count;
     if (line_error) return 0;
 
@@ -1669,6 +1706,7 @@ int cz_info(const cz_handle* h, int what) {
     case 2: return c.n_shell;
     case 3: return c.overlap;
     case 4: return c.last_lag;
+    case 10: return c.bicg_fused;
     case 5: return comm_transport_ranks(c.comm);
     case 6: return c.comm_cus;
     case 7: return c.last_plan.kind;

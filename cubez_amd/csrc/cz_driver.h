@@ -68,6 +68,7 @@ class CZ {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_shell = nullptr, ev_src = nullptr, ev_comm = nullptr, ev_int = nullptr, ev_chk[2] = {nullptr, nullptr};
   bool pairs_ok = true;          // decomposed runs: EVERY brick can run the fused pass (agreed at set-up; the exchange pattern depends on it)
+  int bicg_fused = 0;            // vector updates of the last BiCGSTAB solve that were made inside the first pair of a preconditioner solve (cz_info 10)
   bool in_precond = false;       // inside Preconditioner: an unchecked solve does not drain the queue (the caller's next launch follows in stream order)
   int last_lag = 0;              // the last stationary solve ran its all-reduce + test one pass behind (cz_info)
   int skew_rank = -1, skew_ms = 0;  // CZ_TEST_SKEW=rank,ms: that rank sleeps before each look at the convergence flag (tests)
@@ -124,8 +125,18 @@ class CZ {
   void ensure_hist(int n);
 
   // cz_Poisson.cpp
+  // the right-hand side of a preconditioner solve as the vector update that makes it (PBiCGSTAB): op 1: B = a*x + y, op 2: B = x + a*(z - b*y);
+  // the first pair of the solve then makes B on its way instead of reading it (czhip_jacobi2_from_zero_made_async)
+  struct BMade {
+    int op;
+    const REAL_TYPE* x;
+    const REAL_TYPE* y;
+    const REAL_TYPE* z;
+    REAL_TYPE a, b;
+  };
   int JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true,
-             bool x_is_zero = false);
+             bool x_is_zero = false, const BMade* made = nullptr);
+  bool bicg_fusable(int pc_type);
   bool xx_shell_is_zero(const REAL_TYPE* xx) const;
   int RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   int PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
@@ -134,7 +145,7 @@ class CZ {
   int LSOR_PCR_RB(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   REAL_TYPE Fdot1(REAL_TYPE* x, double& flop);
   REAL_TYPE Fdot2(REAL_TYPE* x, REAL_TYPE* y, double& flop);
-  void Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type);
+  void Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type, const BMade* made = nullptr);
   int PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_type);
 
   // cz_comm.cpp replacements (no-ops when numProc == 1, like cz_comm.cpp:25,76,104)

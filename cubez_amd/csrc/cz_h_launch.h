@@ -160,9 +160,10 @@ inline const int* pair_xcd_map(int nseg, int nchunk, long long* nblk_out) {
 inline bool pair_use_map(int nseg) { return ctx.tune.t2_map && nseg >= 8 && 10 * nseg < 9 * 8 * ((nseg + 7) / 8); }
 
 // two fused sweeps (jacobi2p_k); returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
-template <int TB, int MV, int RB, int ZU, int MAF = 0>
+template <int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
-                         const int* skip, const Fin2& fin_in, int par, bool probe, double* model_cost, const MafArgs& ma = MafArgs()) {
+                         const int* skip, const Fin2& fin_in, int par, bool probe, double* model_cost, const MafArgs& ma = MafArgs(),
+                         const BSrc& bs = BSrc()) {
   constexpr int V = VW;
   Geom2 g;
   g.R = b.nkp / V;
@@ -199,7 +200,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU, MAF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
@@ -207,7 +208,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   fin.counter = ctx.counter;
   {
     ScopedTimer tm(RB ? LBL_RBSOR2 : LBL_JACOBI2);
-    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU, MAF>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin, ma);
+    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin, ma, bs);
   }
   HIP_CHECK(hipGetLastError());
   return true;
@@ -215,7 +216,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
 
 template <int RB>
 bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
-                    const Fin2& fin, int par = 0, int zero_u = 0, bool probe = false, const MafArgs* ma = nullptr) {
+                    const Fin2& fin, int par = 0, int zero_u = 0, bool probe = false, const MafArgs* ma = nullptr, const BSrc* bs = nullptr, int bs_op = 0) {
   if (!vec_ok(b, {U, B, W})) return false;
   if (!ma && !fastdiv_ok(c.dd)) return false;  // jacobi2p_k divides by dd with the hoisted form (cz_k_fastdiv.h); odd magnitudes take single sweeps
   if (ma && b.g != 2) return false;             // the MAF kernels index the coordinate arrays with the padded index (GUIDE = 2)
@@ -239,6 +240,15 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   if (ma) {  // MAF flavour (cz_maf.f90): weights recomputed per point from the 1-D grids
     if (tb == 512 && launch_jacobi2_inst<512, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma)) return true;
     return launch_jacobi2_inst<1024, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma);
+  }
+  if (RB == 0 && zero_u && bs_op != 0) {  // the right-hand side made from the operands of the vector update before the solve (jacobi2p_k<BS>)
+    if (!bs || !vec_ok(b, {bs->x, bs->y, bs->z, bs->out})) return false;
+    if (bs_op == 1) {
+      if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
+      return launch_jacobi2_inst<1024, 2, 0, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
+    }
+    if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1, 0, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
+    return launch_jacobi2_inst<1024, 2, 0, 1, 0, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
   }
   if (RB == 0 && zero_u) {
     if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);

@@ -35,6 +35,15 @@ struct Geom2 {
   const int* map;   // or by a table: map[2 * id] = segment (nseg: no work), map[2 * id + 1] = chunk (pair_xcd_map, cz_h_launch.h)
 };
 
+// jacobi2p_k<..., BS>: the right-hand side made on the fly (see there).  x, y, z: operands; out: where the owner of a vector stores it.
+struct BSrc {
+  const REAL* x = nullptr;
+  const REAL* y = nullptr;
+  const REAL* z = nullptr;
+  REAL* out = nullptr;
+  REAL a = 0, b = 0;
+};
+
 struct Fin2 {
   double* dst = nullptr;   // [0] <- sum of sweep n+1, [1] <- sum of sweep n+2
   int do_check = 0, itr = 0;  // itr = iteration number of sweep n+1

@@ -109,10 +109,15 @@ __device__ __forceinline__ Vec<V> relax_vec_rb(const Vec<V>& pc_, const Vec<V>& 
 
 // ZU = 1: the input field is identically zero and is not read (the first pair of a preconditioner solve).
 // MAF = 1: weights from the 1-D coordinate arrays `ma` (device copies; index = padded index for g = 2) instead of c.
-template <int V, int TB, int MV, int RB, int ZU, int MAF = 0>
+// BS = 1 | 2 (with ZU = 1): the right-hand side is not read but MADE, point by point, from the vectors the preceding element-wise update of
+// BiCGSTAB would have made it from -- 1: b = a*x + y (blas_triad, cz_blas.f90:297; s = r - alpha q), 2: b = x + a*(z - b*y) (blas_bicg_1, :490;
+// p = r + beta (p - omega q)) -- with the same operations on the same values, and the workgroup that owns a vector writes it to bs.out (the
+// array the later passes of the solve read as b): the update kernel and one read of its result are saved (BSrc, cz_k_pair.h).
+template <int V, int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0>
 __global__ void __launch_bounds__(TB, TB == 512 ? 4 : 1)
 jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
-           const int* __restrict__ skip, Fin2 fin, MafArgs ma) {
+           const int* __restrict__ skip, Fin2 fin, MafArgs ma, BSrc bs) {
+  static_assert(BS == 0 || (ZU == 1 && RB == 0 && MAF == 0), "a made right-hand side belongs to the first pair of a preconditioner solve");
   if (skip != nullptr && *skip != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -224,10 +229,16 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
     const char* Ub = reinterpret_cast<const char*>(U);
     const char* Bb = reinterpret_cast<const char*>(B);
     char* Wb = reinterpret_cast<char*>(W);
+    const char* SXb = reinterpret_cast<const char*>(bs.x);
+    const char* SYb = reinterpret_cast<const char*>(bs.y);
+    const char* SZb = reinterpret_cast<const char*>(bs.z);
+    char* SOb = reinterpret_cast<char*>(bs.out);
 
     // Register sets.  Two of each, used alternately by even and odd steps, so that nothing in flight is ever copied (a v_mov of a
     // register with a pending load would wait for it): u(q+1) / u(q+2) and b(q) / b(q+1).
     Vec<V> uA[MV], uB[MV], bA[MV], bB[MV], b2[MV], vc[MV], hx;
+    Vec<V> rx[BS ? MV : 1], ry[BS ? MV : 1], rz[BS == 2 ? MV : 1];  // BS: the operands of b(q), asked for one step ahead (ONE set: b(q) is made
+                                                                     // from them at the top of step q, before the requests of that step)
     // prologue: LDS_U[1] <- u(ja-2) (own vectors), LDS_U[0] <- u(ja-1) on E2; in flight: u(ja) and b(ja-1)
     {
       const char* P2 = Ub + (size_t)(ja - 2) * PB;
@@ -244,7 +255,14 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
 #pragma unroll
       for (int m = 0; m < MV; m++) {
         uA[m] = ZU ? zerov<V>() : ld16<V>(P0, bo[m]);
-        bA[m] = ld16<V>(Q1, bo[m]);
+        if (BS) {
+          rx[m] = ld16<V>(SXb + (size_t)(ja - 1) * PB, bo[m]);
+          ry[m] = ld16<V>(SYb + (size_t)(ja - 1) * PB, bo[m]);
+          if (BS == 2) rz[m] = ld16<V>(SZb + (size_t)(ja - 1) * PB, bo[m]);
+          bA[m] = zerov<V>();
+        } else {
+          bA[m] = ld16<V>(Q1, bo[m]);
+        }
         b2[m] = zerov<V>();
       }
 #pragma unroll
@@ -262,6 +280,31 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       const bool plane_inner = (q >= g.jj0a && q <= g.jj1a);
       const bool count1 = (q >= ja && q <= jb);
       const bool do2 = (q - 1 >= ja);
+      if (BS) {
+        // b(q) from its operands (requested one step ago; loads return in order, nothing younger is waited for), kept in b1
+#pragma unroll
+        for (int m = 0; m < MV; m++) {
+#pragma unroll
+          for (int cc = 0; cc < V; cc++) {
+            if (BS == 1) b1[m].v[cc] = bs.a * rx[m].v[cc] + ry[m].v[cc];
+            if (BS == 2) b1[m].v[cc] = rx[m].v[cc] + bs.a * (rz[m].v[cc] - bs.b * ry[m].v[cc]);
+          }
+        }
+        if (count1) {  // the planes of this chunk, the vectors of this segment: every point of the inner box has exactly one owner
+          char* Sq = SOb + (size_t)q * PB;
+#pragma unroll
+          for (int m = 0; m < MV; m++) {
+            if (own[m] == (1u << V) - 1) {
+              st16<V>(Sq, bo[m], b1[m]);
+            } else if (own[m] != 0) {
+              REAL* sp = reinterpret_cast<REAL*>(Sq + bo[m]);
+#pragma unroll
+              for (int cc = 0; cc < V; cc++)
+                if (own[m] & (1u << cc)) sp[cc] = b1[m].v[cc];
+            }
+          }
+        }
+      }
       // ---- requests for the NEXT step (the last step re-reads a plane it already has: no branch around a load)
       {
         const int qu = (q + 2 <= jb + 2) ? q + 2 : jb + 2;
@@ -272,8 +315,18 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
         hx = ZU ? zerov<V>() : ld16<V>(Ub + (size_t)(q + 1) * PB, hbo);
 #pragma unroll
         for (int m = 0; m < MV; m++) un[m] = ZU ? zerov<V>() : ld16<V>(Un, bo[m]);
+        if (BS) {
+          const size_t po = (size_t)qb * PB;
 #pragma unroll
-        for (int m = 0; m < MV; m++) bn[m] = ld16<V>(Bn, bo[m]);
+          for (int m = 0; m < MV; m++) {
+            rx[m] = ld16<V>(SXb + po, bo[m]);
+            ry[m] = ld16<V>(SYb + po, bo[m]);
+            if (BS == 2) rz[m] = ld16<V>(SZb + po, bo[m]);
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < MV; m++) bn[m] = ld16<V>(Bn, bo[m]);
+        }
       }
       const Vec<V>* cU = ldsU + (size_t)cur * LU;        // u(q) on E2
       Vec<V>* pU = ldsU + (size_t)(cur ^ 1) * LU;        // u(q-1), own vectors; receives u(q+1)

@@ -225,6 +225,13 @@ int czhip_pair_split_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const
  * calling czhip_jacobi2_async. */
 int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1,
                                   int g, const CZ_REAL* cf, CZ_REAL omg, double* res_dev);
+/* The same with the right-hand side of the solve MADE on the way from the operands of the vector update that precedes a preconditioner
+ * solve in BiCGSTAB -- op 1: b = a*x + y (blas_triad_, cz_blas.f90:297), op 2: b = x + a*(z - bb*y) (blas_bicg_1_, :490) -- and stored
+ * to b_out (not one of x, y, z) for the later passes of the solve: update and first pair in one launch, same bits as the two calls.
+ * probe != 0: only says whether the launch would be taken. */
+int czhip_jacobi2_from_zero_made_async(const CZ_REAL* u_shape, CZ_REAL* w, CZ_REAL* b_out, int op, const CZ_REAL* x, const CZ_REAL* y,
+                                       const CZ_REAL* z, CZ_REAL a, CZ_REAL bb, const int* sz, const int* idx, const int* idx1, int g,
+                                       const CZ_REAL* cf, CZ_REAL omg, double* res_dev, int probe);
 /* The same bookkeeping for a pair whose two sums were all-reduced first (decomposed runs). */
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);
@@ -303,7 +310,8 @@ double cz_last_solve_seconds(const cz_handle*);
  * 4 the last stationary solve ran its residual all-reduce + test one pass behind, 5 ranks of the RCCL communicator (ncclCommCount; 0 = LOCAL
  * test transport or single process), 6 CUs per XCD the sweeps leave to the exchange stream (CZ_COMM_CUS); the plan of the last stationary
  * solve: 7 kind of pass (0 single sweeps, 1 fused pass over the whole box, 2 fused pass as shell slabs + interior with the exchange
- * overlapped), 8 ghost layers exchanged per pass, 9 rotating field buffers. */
+ * overlapped), 8 ghost layers exchanged per pass, 9 rotating field buffers; 10 vector updates of the last BiCGSTAB solve that were made inside
+ * the first pair of the preconditioner solve they feed (czhip_jacobi2_from_zero_made_async). */
 int cz_info(const cz_handle*, int what);
 double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
 

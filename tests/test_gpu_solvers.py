@@ -138,6 +138,29 @@ def test_bicgstab_vs_wide_oracle(case):
     assert diff <= (1e-9 if case["prec"] == "f64" else 1e-4)
 
 
+@pytest.mark.parametrize("prec,gsz", [("f64", (64, 64, 64)), ("f32", (40, 36, 44)), ("f64", (33, 47, 62)), ("f32", (128, 128, 128))],
+                         ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
+def test_bicgstab_with_its_vector_updates_made_inside_the_preconditioner_pass(prec, gsz, monkeypatch):
+    """p = r + beta (p - omega q) and s = r - alpha q are not launched on their own where the Jacobi preconditioner starts with the whole-box
+    fused pass from zero: that pass makes its right-hand side from their operands and stores it (jacobi2p_k<BS>).  Same operations on the
+    same values: history and field of the solve equal those of the solve with the updates launched (CZ_BICG_FUSE=0), bit for bit."""
+    from cubez_amd import CZ
+    out = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CZ_BICG_FUSE", fuse)
+        cz = CZ(prec, quiet=True)
+        assert cz.setup(list(gsz) + ["pbicgstab", 40, 0.8, "jacobi"]) == 1
+        itr = cz.solve()
+        out[fuse] = (itr, cz.res, list(cz.history()), cz.field().tobytes(), cz.info()["bicg_fused"])
+        cz.close()
+    assert out["0"][4] == 0
+    n = len(out["1"][2])
+    assert out["1"][4] in (0, 2 * n - 1), out["1"][4]  # all or nothing: every update but the first iteration's copy
+    if gsz in ((64, 64, 64), (128, 128, 128)):
+        assert out["1"][4] == 2 * n - 1  # shapes the two-stage pass is known to take
+    assert out["1"][:4] == out["0"][:4]
+
+
 def test_convergence_stops_at_the_reference_iteration():
     """64^3 FP64 Jacobi to eps: 2742 iterations in the reference CLI; the device-side flag must stop
     the field exactly there although the host keeps queueing sweeps."""

@@ -92,7 +92,7 @@ float run(Lab& L, int which, int reps, double* sums) {
     if (which == 1)
       hipLaunchKernelGGL((jacobi2_k<V, TB, MV, RB>), dim3(L.nblk), dim3(TB), L.lds1, 0, L.U, L.B, W, L.c, L.g, L.partials, nullptr, fin);
     else
-      hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, 0>), dim3(L.nblk), dim3(TB), L.lds2, 0, L.U, L.B, W, L.c, L.g, L.partials, nullptr, fin, MafArgs());
+      hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, 0>), dim3(L.nblk), dim3(TB), L.lds2, 0, L.U, L.B, W, L.c, L.g, L.partials, nullptr, fin, MafArgs(), BSrc());
   };
   if (which == 1)
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2_k<V, TB, MV, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
