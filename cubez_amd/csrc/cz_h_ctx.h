@@ -11,6 +11,7 @@ struct Tuning {
   long long pipe_spin_ticks = 200000000;  // bound of every wait inside it, in ticks of the 100 MHz wall clock (2 s)
   int pcr_wg_per_cu = 0, pcr_max_wg = 0, pcr_slots = 0;  // pcr_lex_wg_k: workgroups per CU / in all, lines per hand-off ring (0: the launcher's choice);
                                                          // CZHIP_PCR_WG_PER_CU, CZHIP_PCR_MAX_WG, CZHIP_PCR_SLOTS, czhip_set_pcr_lex_limits
+  int t2_any_rows = 1;               // the two-stage pass takes row lengths that are no multiple of the vector width (CZHIP_T2_ROWS)
   int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
                                       // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
   int psor_col = 1, psor_wg_per_cu = 0;  // psor / psor_maf: 1 = the sweep in one launch (psor_col_k), 0 = a launch per tile hyperplane (psor_tile_k);
@@ -155,6 +156,17 @@ inline bool vec_ok(const Box& b, std::initializer_list<const void*> ptrs) {
   for (const void* p : ptrs)
     if (p && (reinterpret_cast<uintptr_t>(p) & 15u)) return false;
   return true;
+}
+
+// the two-stage pass (jacobi2p_k) takes rows of any length and arrays of any REAL alignment (Geom2); CZHIP_T2_ROWS=0 restores the rule of
+// rounds 1-2 (A/B measurements)
+inline bool rows_ok(const Box& b, std::initializer_list<const void*> ptrs) {
+  if (ctx.tune.t2_any_rows) {
+    for (const void* p : ptrs)
+      if (p && (reinterpret_cast<uintptr_t>(p) & (sizeof(REAL) - 1))) return false;
+    return true;
+  }
+  return vec_ok(b, ptrs);
 }
 
 template <int V>

@@ -166,10 +166,14 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
                          const BSrc& bs = BSrc()) {
   constexpr int V = VW;
   Geom2 g;
-  g.R = b.nkp / V;
+  g.R = (b.nkp + V - 1) / V;  // rows as R vectors from a vector boundary each; the last one partial where nkp % V != 0 (Geom2)
   if (2 * g.R > TB || 4 * g.R >= TB * MV) return false;  // the outer rows are staged by 2R threads / halo rows would dominate
   g.PSV = (long long)g.R * b.nip;
+  g.nkp = b.nkp;
+  g.PSB = (long long)b.nkp * b.nip * (long long)sizeof(REAL);
   if (g.PSV * (long long)sizeof(Vec<V>) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
+  g.jlast = b.njp - 1;
+  g.last_off = (unsigned)(g.PSB - (long long)sizeof(Vec<V>));
   g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
   g.F0 = (long long)b.ii0 * g.R;
   g.Fend = (long long)(b.ii1 + 1) * g.R;
@@ -183,7 +187,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   g.nseg = (int)((nf + g.S - 1) / g.S);
   const int nplanes = b.jj1 - b.jj0 + 1;
   const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double) +
-                     (MAF ? (size_t)2 * b.nkp * sizeof(REAL) : 0);  // MAF: the table of the k metric terms
+                     (MAF ? (size_t)2 * g.R * V * sizeof(REAL) : 0);  // MAF: the table of the k metric terms
   if (lds > 160 * 1024) return false;
   const int wg_per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / TB));
   int tj = tj_req;
@@ -217,7 +221,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
 template <int RB>
 bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, const int* skip,
                     const Fin2& fin, int par = 0, int zero_u = 0, bool probe = false, const MafArgs* ma = nullptr, const BSrc* bs = nullptr, int bs_op = 0) {
-  if (!vec_ok(b, {U, B, W})) return false;
+  if (!rows_ok(b, {U, B, W})) return false;
   if (!ma && !fastdiv_ok(c.dd)) return false;  // jacobi2p_k divides by dd with the hoisted form (cz_k_fastdiv.h); odd magnitudes take single sweeps
   if (ma && b.g != 2) return false;             // the MAF kernels index the coordinate arrays with the padded index (GUIDE = 2)
   // the stage-1 box may exceed the output box by at most one layer per side
@@ -242,7 +246,7 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
     return launch_jacobi2_inst<1024, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma);
   }
   if (RB == 0 && zero_u && bs_op != 0) {  // the right-hand side made from the operands of the vector update before the solve (jacobi2p_k<BS>)
-    if (!bs || !vec_ok(b, {bs->x, bs->y, bs->z, bs->out})) return false;
+    if (!bs || !rows_ok(b, {bs->x, bs->y, bs->z, bs->out})) return false;
     if (bs_op == 1) {
       if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
       return launch_jacobi2_inst<1024, 2, 0, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);

@@ -20,8 +20,17 @@
 // that owns it.
 // ------------------------------------------------------------------------------------------------------------
 struct Geom2 {
+  // Rows of the (k, i) plane as the pass sees them: R vectors each, row i starting at a vector boundary.  In memory a row is nkp elements
+  // long and rows follow one another without padding: where nkp is not a multiple of the vector width the last vector of a row is partial
+  // (its tail belongs to the next row and is masked like every k outside the box) and a vector is only REAL-aligned in memory -- the global
+  // accesses of the pass are dword-aligned dwordx4, which this hardware takes.  (Rounds 1-2 required nkp % V == 0 and sent every other
+  // size to the one-sweep scalar kernel: 220 000 against 740 000 MLUPS at 511^3, profiles/r03/unaligned_k_extent.txt.)
   int R;
-  long long PSV;
+  long long PSV;               // R * nip: vectors per plane in that view
+  int nkp = 0;                 // elements per row in memory
+  long long PSB = 0;           // bytes per plane in memory
+  int jlast = 0;               // index of the array's last plane, whose last vector must not be read beyond the array:
+  unsigned last_off = 0;       // ... offsets into that plane are clamped to this (the values clamped away are never used)
   int kk0, kk1, jj0, jj1;      // stage-2 (output) box = the inner box
   long long F0, Fend;
   // stage-1 box: the inner box, grown by one layer across rank-internal faces of a decomposed run (the first sweep

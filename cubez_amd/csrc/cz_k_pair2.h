@@ -18,10 +18,12 @@
 // LDS: u(q) on E2 = own segment +- 2 rows and u(q-1), v(q-1) on E1 = own +- 1 row and v(q-2); two buffers each, one barrier
 // per plane.
 // ------------------------------------------------------------------------------------------------------------
+// global accesses of the pass: a vector is REAL-aligned in memory (16-byte aligned where the row length is a multiple of the vector width)
 template <int V>
 __device__ __forceinline__ Vec<V> ld16(const char* plane, unsigned byte_off) {
   typedef typename NatVec<V>::type nv;
-  const nv x = *reinterpret_cast<const nv*>(plane + byte_off);
+  typedef nv unv __attribute__((aligned(sizeof(REAL))));
+  const nv x = *reinterpret_cast<const unv*>(plane + byte_off);
   Vec<V> r;
   __builtin_memcpy(&r, &x, sizeof(r));
   return r;
@@ -29,9 +31,10 @@ __device__ __forceinline__ Vec<V> ld16(const char* plane, unsigned byte_off) {
 template <int V>
 __device__ __forceinline__ void st16(char* plane, unsigned byte_off, const Vec<V>& x) {
   typedef typename NatVec<V>::type nv;
+  typedef nv unv __attribute__((aligned(sizeof(REAL))));
   nv y;
   __builtin_memcpy(&y, &x, sizeof(y));
-  *reinterpret_cast<nv*>(plane + byte_off) = y;
+  *reinterpret_cast<unv*>(plane + byte_off) = y;
 }
 
 // one ds_read_b128 per vector: left to itself the compiler re-reads overlapping pieces of a vector with ds_read_b32 / ds_read2_b32
@@ -167,7 +170,14 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
     const long long e1_0 = fb - R;      // first vector of E1
     const long long e2_0 = fb - 2 * R;  // first vector of E2
     const long long vlast = g.PSV - 1;
-    const size_t PB = (size_t)g.PSV * sizeof(Vec<V>);  // bytes per plane
+    const size_t PB = (size_t)g.PSB;  // bytes per plane
+    // byte offset of vector f of the row view inside a plane in memory
+    auto off_of = [&](long long f) -> unsigned {
+      const long long r = f / R;
+      return (unsigned)((r * g.nkp + (f - r * R) * V) * (long long)sizeof(REAL));
+    };
+    // (the array's last plane: see Geom2::last_off)
+    auto lim = [&](unsigned off, int plane) -> unsigned { return plane == g.jlast ? (off < g.last_off ? off : g.last_off) : off; };
     unsigned bo[MV];   // byte offset of the thread's m-th vector inside a plane (clamped into the plane: such lanes are masked)
     unsigned ka[MV];   // stage-1 bits: components of the vector inside the stage-1 box (0 when the row is outside)
     unsigned own[MV];  // stage-2 bits if this workgroup owns the vector (stores, residual counts), else 0
@@ -177,7 +187,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       const int e = t + m * TB;
       const long long f = e1_0 + e;
       const long long fc = f < vlast ? f : vlast;
-      bo[m] = (unsigned)(fc * (long long)sizeof(Vec<V>));
+      bo[m] = off_of(fc);
       const long long row = f / R;
       const int kv = (int)(f - row * R);
       unsigned bits1 = 0, bits2 = 0;
@@ -194,7 +204,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
     REAL XG[MAF ? MV : 1], XGG[MAF ? MV : 1];  // MAF: metric terms of the rows of the thread's vectors
     int kvo[MAF ? MV : 1];                      // MAF: first k of the vector (offset into ztab)
     if (MAF) {
-      const int nkp = R * V;
+      const int nkp = R * V;  // (the row view; g.nkp elements of it exist)
 #pragma unroll
       for (int m = 0; m < MV; m++) {
         const long long f = e1_0 + t + m * TB;
@@ -210,7 +220,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       }
       for (int kk = t; kk < nkp; kk += TB) {
         int kc = kk < 1 ? 1 : kk;
-        if (kc > nkp - 2) kc = nkp - 2;
+        if (kc > g.nkp - 2) kc = g.nkp - 2;
         const REAL zm = ma.zc[kc - 1], z0 = ma.zc[kc], zp = ma.zc[kc + 1];
         ztab[kk] = (REAL)0.5 * (zp - zm);
         ztab[nkp + kk] = zp - (REAL)2.0 * z0 + zm;
@@ -224,7 +234,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       long long fh = e2_0 + hl;
       if (!has_halo) fh = e1_0 + t;
       if (fh > vlast) fh = vlast;
-      hbo = (unsigned)(fh * (long long)sizeof(Vec<V>));
+      hbo = off_of(fh);
     }
     const char* Ub = reinterpret_cast<const char*>(U);
     const char* Bb = reinterpret_cast<const char*>(B);
@@ -248,13 +258,13 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       Vec<V> t2[MV], t1[MV], h1;
 #pragma unroll
       for (int m = 0; m < MV; m++) {
-        t2[m] = ZU ? zerov<V>() : ld16<V>(P2, bo[m]);
-        t1[m] = ZU ? zerov<V>() : ld16<V>(P1, bo[m]);
+        t2[m] = ZU ? zerov<V>() : ld16<V>(P2, lim(bo[m], ja - 2));
+        t1[m] = ZU ? zerov<V>() : ld16<V>(P1, lim(bo[m], ja - 1));
       }
-      h1 = ZU ? zerov<V>() : ld16<V>(P1, hbo);
+      h1 = ZU ? zerov<V>() : ld16<V>(P1, lim(hbo, ja - 1));
 #pragma unroll
       for (int m = 0; m < MV; m++) {
-        uA[m] = ZU ? zerov<V>() : ld16<V>(P0, bo[m]);
+        uA[m] = ZU ? zerov<V>() : ld16<V>(P0, lim(bo[m], ja));
         if (BS) {
           rx[m] = ld16<V>(SXb + (size_t)(ja - 1) * PB, bo[m]);
           ry[m] = ld16<V>(SYb + (size_t)(ja - 1) * PB, bo[m]);
@@ -312,9 +322,9 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
         const char* Un = Ub + (size_t)qu * PB;
         const char* Bn = Bb + (size_t)qb * PB;
         // the outer rows of u(q+1) go to LDS at the end of THIS step (one register set; the oldest request of the step)
-        hx = ZU ? zerov<V>() : ld16<V>(Ub + (size_t)(q + 1) * PB, hbo);
+        hx = ZU ? zerov<V>() : ld16<V>(Ub + (size_t)(q + 1) * PB, lim(hbo, q + 1));
 #pragma unroll
-        for (int m = 0; m < MV; m++) un[m] = ZU ? zerov<V>() : ld16<V>(Un, bo[m]);
+        for (int m = 0; m < MV; m++) un[m] = ZU ? zerov<V>() : ld16<V>(Un, lim(bo[m], qu));
         if (BS) {
           const size_t po = (size_t)qb * PB;
 #pragma unroll

@@ -189,6 +189,7 @@ int czhip_init(int device) {
     sscanf(pc, "%d,%d", &f, &v);
     ctx.tune.pcr_fast = f, ctx.tune.pcr_variant = v;
   }
+  if (const char* ar = getenv("CZHIP_T2_ROWS")) ctx.tune.t2_any_rows = atoi(ar) ? 1 : 0;
   if (const char* pp = getenv("CZHIP_PCR_PIPE")) {  // "form[,seconds[,groups[,rows per thread]]]": form as Tuning::pcr_pipe; bound of the waits inside the kernel
     int w = 1, rows = 0, q = 1;
     double sec = 2.0;

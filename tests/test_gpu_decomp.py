@@ -89,7 +89,7 @@ CASES = [
     ("f32", (40, 36, 44), "jacobi", 25, 0.8, (1, 2, 1)),
     ("f32", (40, 36, 44), "jacobi", 25, 0.8, (2, 1, 1)),
     ("f32", (40, 36, 44), "jacobi", 24, 0.8, (1, 1, 2)),
-    ("f32", (41, 37, 45), "jacobi", 17, 0.8, (2, 2, 2)),     # uneven bricks, odd sizes (scalar path)
+    ("f32", (41, 37, 45), "jacobi", 17, 0.8, (2, 2, 2)),     # uneven bricks, odd sizes (rows of 27 / 26 values)
     ("f64", (36, 40, 44), "jacobi", 20, 0.9, (2, 2, 1)),
     ("f32", (40, 36, 44), "sor2sma", 20, 1.5, (1, 2, 1)),
     ("f32", (41, 37, 45), "sor2sma", 15, 1.5, (2, 2, 2)),    # odd heads: colour offset per brick
@@ -97,7 +97,7 @@ CASES = [
     ("f32", (48, 36, 44), "jacobi", 12, 0.8, (3, 1, 1)),     # middle brick: both faces of an axis border a rank
     ("f32", (40, 48, 44), "sor2sma", 9, 1.5, (1, 3, 1)),
     ("f64", (36, 40, 54), "jacobi", 10, 0.8, (1, 1, 3)),
-    ("f32", (40, 36, 41), "jacobi", 10, 0.8, (1, 1, 2)),      # k-extents 21 / 20: only one brick could fuse pairs -> all agree on single sweeps
+    ("f32", (40, 36, 41), "jacobi", 10, 0.8, (1, 1, 2)),      # k-extents 21 / 20: one brick with rows of 25 values, one of 24
     ("f32", (40, 36, 41), "sor2sma", 8, 1.5, (1, 1, 2)),
     ("f32", (40, 36, 32), "pcr_rb", 8, 1.2, (2, 1, 1)),       # line SOR: whole k-lines per brick, exchange after each colour
     ("f64", (41, 37, 32), "pcr_rb", 8, 1.2, (2, 2, 1)),       # odd heads: global colouring
@@ -117,15 +117,12 @@ def test_decomposed_equals_single_domain(case, overlap):
     g = 2
     inner = (slice(g, -g),) * 3
     assert G[inner].tobytes() == P1[inner].tobytes()
-    vw = 4 if prec == "f32" else 2
-    all_aligned = all((r[4]["size"][2] + 4) % vw == 0 for r in results)
     for itr, res, hist, P, loc in results:
         assert itr == itr1
         assert np.allclose(hist, hist1, rtol=1e-12, atol=0)
-        if solver in ("jacobi", "sor2sma") and not all_aligned:
-            assert loc["fused_pairs"] == 0 and loc["shell_launches"] == 0, loc   # the bricks agreed on the one-layer path
-        if solver in ("jacobi", "sor2sma") and all_aligned:
-            # aligned bricks take the two-sweeps-per-pass kernel with the two-layer exchange
+        if solver in ("jacobi", "sor2sma"):
+            # every brick takes the two-sweeps-per-pass kernel with the two-layer exchange -- since round 3 also bricks whose k extent is no
+            # multiple of the vector width (rounds 1-2: such a brick made all of them agree on single sweeps)
             npass = itmax // 2 if solver == "jacobi" else itmax
             assert loc["fused_pairs"] == npass, loc
             assert loc["shell_launches"] == (npass if overlap else 0), loc

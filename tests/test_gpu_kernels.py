@@ -236,7 +236,10 @@ def test_residual_is_run_to_run_deterministic():
 
 
 T2_BOXES = [((40, 36, 60), None), ((33, 70, 124), None), ((130, 20, 252), None), ((70, 45, 124), None),
-            ((24, 20, 28), (1, 24, 1, 20, 1, 28)), ((64, 9, 60), None), ((96, 40, 508), None)]
+            ((24, 20, 28), (1, 24, 1, 20, 1, 28)), ((64, 9, 60), None), ((96, 40, 508), None),
+            # row lengths that are no multiple of the vector width (round 3: the pass takes them; nk + 4 = 65, 127, 130, 257, 63, 511)
+            ((40, 36, 61), None), ((33, 50, 123), None), ((70, 20, 126), None), ((29, 31, 253), None),
+            ((24, 20, 59), (1, 24, 1, 20, 1, 59)), ((31, 23, 507), None)]
 T2_TUNINGS = [(512, 2, 32), (512, 2, 5), (512, 2, 7), (512, 2, 16), (-2, 2, 0), (1024, 2, 16), (1024, 2, 11), (1024, 2, 4)]  # (-2, 2, 0): shape and chunk chosen by the library
 
 
@@ -274,7 +277,7 @@ def test_two_fused_sweeps_equal_two_oracle_sweeps(prec, box):
             dw.free()
     finally:
         h.set_tuning2(-2, 2, 0, 1)
-    if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:
+    if nk + 4 >= 64:
         assert launched > 0
 
 
@@ -310,7 +313,7 @@ def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
                 dw.free()
     finally:
         h.set_tuning2(-2, 2, 0, 1)
-    if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0:
+    if nk + 4 >= 64:
         assert launched > 0
 
 
@@ -435,7 +438,7 @@ def test_maf_two_stage_pass_equals_two_oracle_sweeps(prec, box):
             dw.free()
     finally:
         h.set_tuning2(-2, 2, 0, 1)
-    if nk + 4 >= 64 and (nk + 4) % (4 if prec == "f32" else 2) == 0 and idx[0] >= 2:
+    if nk + 4 >= 64 and idx[0] >= 2:
         assert launched > 0
 
 

@@ -62,6 +62,7 @@ bool geom(Lab& L, int tj, int rb) {
   g.R = L.nkp / V;
   if (2 * g.R >= TB * MV / 2 || 2 * g.R > TB) return false;
   g.PSV = (long long)g.R * L.nip;
+  g.nkp = L.nkp, g.PSB = (long long)L.nkp * L.nip * (long long)sizeof(REAL), g.jlast = L.njp - 1, g.last_off = (unsigned)(g.PSB - (long long)sizeof(Vec<V>));
   // single-domain inner box: 1-based (2..n-1) -> padded 0-based (2+1 .. n-1+1) with g = 2
   g.kk0 = 3, g.kk1 = L.nk, g.jj0 = 3, g.jj1 = L.nj;
   const int ii0 = 3, ii1 = L.ni;
