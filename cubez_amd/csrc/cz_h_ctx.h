@@ -172,8 +172,10 @@ inline bool rows_ok(const Box& b, std::initializer_list<const void*> ptrs) {
 template <int V>
 EGeom make_egeom(const Box& b) {
   EGeom e;
-  e.R = b.nkp / V;
+  e.R = (b.nkp + V - 1) / V;
   e.PSV = (long long)e.R * b.nip;
+  e.nkp = b.nkp;
+  e.PSE = (long long)b.nkp * b.nip;
   e.kk0 = b.kk0, e.kk1 = b.kk1, e.jj0 = b.jj0;
   e.F0 = (long long)b.ii0 * e.R;
   e.Fend = (long long)(b.ii1 + 1) * e.R;

@@ -5,8 +5,12 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
                          const int* skip, int* nblk_out, const Fin& fin, const MafArgs& ma = MafArgs()) {
   Geom g;
   g.nip = b.nip;
-  g.R = b.nkp / V;
+  g.R = (b.nkp + V - 1) / V;  // rows from a vector boundary each; the last vector of a row partial where nkp % V != 0 (Geom)
   g.PSV = (long long)g.R * b.nip;
+  g.nkp = b.nkp;
+  g.PSE = (long long)b.nkp * b.nip;
+  g.jlast = b.njp - 1;
+  g.last_eo = g.PSE - V;
   g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
   g.F0 = (long long)b.ii0 * g.R;
   g.Fend = (long long)(b.ii1 + 1) * g.R;
@@ -56,7 +60,7 @@ template <int MODE>
 void launch_stencil(const REAL* P, const REAL* B, REAL* OUT, const Coef& c, const Box& b, int par, const int* skip,
                     int* nblk_out, const Fin& fin = Fin()) {
   const Tuning& tu = ctx.tune;
-  if (!vec_ok(b, {P, B, OUT})) {
+  if (!rows_ok(b, {P, B, OUT})) {
     launch_stencil_inst<1, 256, 2, 0, MODE>(P, B, OUT, c, b, par, tu.tj, skip, nblk_out, fin);
     return;
   }
@@ -85,7 +89,7 @@ void launch_stencil_maf(const REAL* P, const REAL* B, REAL* OUT, REAL omg, const
   Coef c;
   c.c1 = c.c2 = c.c3 = c.c4 = c.c5 = c.c6 = c.dd = (REAL)0;
   c.omg = omg;
-  if (vec_ok(b, {P, B, OUT, ma.pvt}))
+  if (rows_ok(b, {P, B, OUT, ma.pvt}))
     launch_stencil_inst<VW, 512, 2, 0, MODE, 1>(P, B, OUT, c, b, par, ctx.tune.tj, skip, nblk_out, fin, ma);
   else
     launch_stencil_inst<1, 256, 2, 0, MODE, 1>(P, B, OUT, c, b, par, ctx.tune.tj, skip, nblk_out, fin, ma);
@@ -319,7 +323,7 @@ void launch_ewise(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL bcoef, con
   if (b.empty) return;
   ScopedTimer tm(LBL_EWISE);
   const int nplanes = b.jj1 - b.jj0 + 1;
-  if (vec_ok(b, {Z, X, Y})) {
+  if (rows_ok(b, {Z, X, Y})) {
     EGeom e = make_egeom<VW>(b);
     dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
     hipLaunchKernelGGL((ewise_k<VW, OP>), grid, dim3(256), 0, ctx.stream, Z, X, Y, a, bcoef, e);
@@ -340,7 +344,7 @@ void launch_dot(const REAL* X, const REAL* Y, const Box& b, double* dst) {
   }
   const int nplanes = b.jj1 - b.jj0 + 1;
   ScopedTimer tm(LBL_DOT);
-  if (vec_ok(b, {X, Y})) {
+  if (rows_ok(b, {X, Y})) {
     EGeom e = make_egeom<VW>(b);
     const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
     const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));

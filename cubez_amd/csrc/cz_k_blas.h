@@ -61,14 +61,23 @@ struct EGeom {
   long long PSV;
   int kk0, kk1, jj0;
   long long F0, Fend;
+  // rows as R vectors from a vector boundary each; in memory a row is nkp elements and a plane PSE elements (Geom2, cz_k_pair.h)
+  int nkp = 0;
+  long long PSE = 0;
 };
+// element offset of vector f of the row view inside a plane in memory
+template <int V>
+__device__ __forceinline__ long long egeom_eo(const EGeom& g, long long f) {
+  const long long r = f / g.R;
+  return r * g.nkp + (f - r * g.R) * V;
+}
 
 template <int V, int OP>
 __global__ void __launch_bounds__(256)
 ewise_k(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL b, EGeom g) {
   const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
   if (f >= g.Fend) return;
-  const long long pv = (long long)(g.jj0 + blockIdx.y) * g.PSV + f;
+  const long long pe = (long long)(g.jj0 + blockIdx.y) * g.PSE + egeom_eo<V>(g, f);
   const int kv = (int)(f % g.R);
   unsigned mk = 0;
 #pragma unroll
@@ -77,9 +86,9 @@ ewise_k(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL b, EGeom g) {
     if (kk >= g.kk0 && kk <= g.kk1) mk |= 1u << cc;
   }
   if (mk == 0) return;
-  Vec<V> x = ldv<V>(X, pv), y, z, o;
-  if (OP != OP_COPY) y = ldv<V>(Y, pv);
-  if (OP == OP_BICG1 || OP == OP_BICG2) z = ldv<V>(Z, pv);
+  Vec<V> x = ldve<V>(X, pe), y, z, o;
+  if (OP != OP_COPY) y = ldve<V>(Y, pe);
+  if (OP == OP_BICG1 || OP == OP_BICG2) z = ldve<V>(Z, pe);
 #pragma unroll
   for (int cc = 0; cc < V; cc++) {
     if (OP == OP_TRIAD) o.v[cc] = a * x.v[cc] + y.v[cc];                              // cz_blas.f90:297
@@ -88,11 +97,11 @@ ewise_k(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL b, EGeom g) {
     if (OP == OP_COPY) o.v[cc] = x.v[cc];
   }
   if (mk == (1u << V) - 1) {
-    stv<V>(Z, pv, o);
+    stve<V>(Z, pe, o);
   } else {
 #pragma unroll
     for (int cc = 0; cc < V; cc++)
-      if (mk & (1u << cc)) Z[pv * V + cc] = o.v[cc];
+      if (mk & (1u << cc)) Z[pe + cc] = o.v[cc];
   }
 }
 
@@ -103,9 +112,9 @@ pivot_k(REAL* PVT, EGeom g, MafArgs ma, int nkp, int nip) {
   const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
   if (f >= g.Fend) return;
   const int jj = g.jj0 + blockIdx.y;
-  const long long pv = (long long)jj * g.PSV + f;
   const long long row = f / g.R;
   const int kv = (int)(f - row * g.R);
+  const long long pe = (long long)jj * g.PSE + row * g.nkp + (long long)kv * V;
   const int ii = (int)row;
   const REAL xm = ma.xc[ii - 1], x0 = ma.xc[ii], xp = ma.xc[ii + 1];
   const REAL ym = ma.yc[jj - 1], y0 = ma.yc[jj], yp = ma.yc[jj + 1];
@@ -123,7 +132,7 @@ pivot_k(REAL* PVT, EGeom g, MafArgs ma, int nkp, int nip) {
     ss = fmax(ss, fabs(w.w5));
     ss = fmax(ss, fabs(w.w6));
     ss = fmax(ss, fabs(w.dd));
-    PVT[pv * V + cc] = (REAL)1.0 / ss;
+    PVT[pe + cc] = (REAL)1.0 / ss;
   }
   (void)nkp;
   (void)nip;
@@ -147,11 +156,12 @@ dot_k(const REAL* X, const REAL* Y, EGeom g, int nplanes, double* partials, doub
       const int kk = kv * V + cc;
       if (kk >= g.kk0 && kk <= g.kk1) mk |= 1u << cc;
     }
+    const long long eo = egeom_eo<V>(g, f);
     for (int pl = blockIdx.y; pl < nplanes; pl += gridDim.y) {
-      const long long pv = (long long)(g.jj0 + pl) * g.PSV + f;
-      const Vec<V> x = ldv<V>(X, pv);
+      const long long pe = (long long)(g.jj0 + pl) * g.PSE + eo;
+      const Vec<V> x = ldve<V>(X, pe);
       Vec<V> y = x;
-      if (TWO) y = ldv<V>(Y, pv);
+      if (TWO) y = ldve<V>(Y, pe);
 #pragma unroll
       for (int cc = 0; cc < V; cc++) {
         const REAL tt = x.v[cc] * y.v[cc];
@@ -198,9 +208,10 @@ triad_dots_k(REAL* Z, const REAL* X, const REAL* Y, const REAL* W, REAL a, EGeom
       if (kk >= g.kk0 && kk <= g.kk1) mk |= 1u << cc;
     }
     if (mk != 0) {
+      const long long eo = egeom_eo<V>(g, f);
       for (int pl = blockIdx.y; pl < nplanes; pl += gridDim.y) {
-        const long long pv = (long long)(g.jj0 + pl) * g.PSV + f;
-        const Vec<V> x = ldv<V>(X, pv), y = ldv<V>(Y, pv), w = ldv<V>(W, pv);
+        const long long pe = (long long)(g.jj0 + pl) * g.PSE + eo;
+        const Vec<V> x = ldve<V>(X, pe), y = ldve<V>(Y, pe), w = ldve<V>(W, pe);
         Vec<V> o;
 #pragma unroll
         for (int cc = 0; cc < V; cc++) {
@@ -213,11 +224,11 @@ triad_dots_k(REAL* Z, const REAL* X, const REAL* Y, const REAL* W, REAL a, EGeom
           }
         }
         if (mk == (1u << V) - 1) {
-          stv<V>(Z, pv, o);
+          stve<V>(Z, pe, o);
         } else {
 #pragma unroll
           for (int cc = 0; cc < V; cc++)
-            if (mk & (1u << cc)) Z[pv * V + cc] = o.v[cc];
+            if (mk & (1u << cc)) Z[pe + cc] = o.v[cc];
         }
       }
     }

@@ -21,6 +21,12 @@ struct Geom {
   int nseg;         // segments per plane
   int TJ;           // planes per chunk
   int S;            // vectors per segment
+  // rows as R vectors from a vector boundary each (R = ceil(nkp / V)): in memory a row is nkp elements, the last vector of a row partial where
+  // nkp % V != 0 and a vector only REAL-aligned (see Geom2, cz_k_pair.h)
+  int nkp = 0;            // elements per row in memory
+  long long PSE = 0;      // elements per plane in memory
+  int jlast = 0;          // the array's last plane: element offsets into it are clamped to
+  long long last_eo = 0;  // ... this, so that its last vector is not read beyond the array (values clamped away are never used)
 };
 
 enum { MODE_JACOBI = 0, MODE_RB = 1, MODE_AX = 2, MODE_RK = 3 };
@@ -70,6 +76,24 @@ __device__ __forceinline__ void stv(REAL* base, long long vec_index, const Vec<V
   nv y;
   __builtin_memcpy(&y, &x, sizeof(y));
   *reinterpret_cast<nv*>(base + vec_index * V) = y;
+}
+// vector access at an ELEMENT offset that is only REAL-aligned (rows whose length is no multiple of the vector width)
+template <int V>
+__device__ __forceinline__ Vec<V> ldve(const REAL* base, long long elem) {
+  typedef typename NatVec<V>::type nv;
+  typedef nv unv __attribute__((aligned(sizeof(REAL))));
+  const nv x = *reinterpret_cast<const unv*>(base + elem);
+  Vec<V> r;
+  __builtin_memcpy(&r, &x, sizeof(r));
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void stve(REAL* base, long long elem, const Vec<V>& x) {
+  typedef typename NatVec<V>::type nv;
+  typedef nv unv __attribute__((aligned(sizeof(REAL))));
+  nv y;
+  __builtin_memcpy(&y, &x, sizeof(y));
+  *reinterpret_cast<unv*>(base + elem) = y;
 }
 template <int V>
 __device__ __forceinline__ Vec<V> zerov() {

@@ -51,11 +51,19 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
     REAL XG[MAF ? M : 1], XGG[MAF ? M : 1];   // MAF: metric terms of the row ...
     Vec<V> ZT[MAF ? M : 1], ZTT[MAF ? M : 1];  // ... and of each k component
     const long long lim_ld = g.Fend + R;  // vectors below this exist in the plane (row ii1+1 is a halo row)
+    long long eo[M];  // element offset of the vector inside a plane in memory (rows of g.nkp elements; f counts R vectors per row)
+    auto eoff = [&](long long ff) -> long long {
+      const long long r = ff / R;
+      return r * g.nkp + (ff - r * R) * V;
+    };
+    // (the array's last plane: Geom::last_eo)
+    auto lim = [&](long long e, int plane) -> long long { return plane == g.jlast ? (e < g.last_eo ? e : g.last_eo) : e; };
 #pragma unroll
     for (int m = 0; m < M; m++) {
       f[m] = fb + t + m * TB;
       const long long row = f[m] / R;
       const int kv = (int)(f[m] - row * R);
+      eo[m] = row * g.nkp + (long long)kv * V;
       unsigned bits = 0;
       if (f[m] < g.Fend) {
 #pragma unroll
@@ -67,7 +75,7 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
       mk[m] = bits;
       pbase[m] = (kv * V + (int)row + par) & 1;
       if (MAF) {
-        const int nkp = R * V;
+        const int nkp = g.nkp;
         int ii = (int)row;  // padded row index == index into xc for g = 2
         if (ii < 1) ii = 1;
         if (ii > g.nip - 2) ii = g.nip - 2;
@@ -89,13 +97,13 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
     Vec<V> pm[M], pc[M], pn[M], bb[M];
     Vec<V> pnn[PF ? M : 1], bbn[PF ? M : 1];
 
-    const REAL* Pm = P + (long long)(ja - 1) * g.PSV * V;
-    const REAL* Pc = P + (long long)ja * g.PSV * V;
+    const REAL* Pm = P + (long long)(ja - 1) * g.PSE;
+    const REAL* Pc = P + (long long)ja * g.PSE;
 #pragma unroll
     for (int m = 0; m < M; m++) {
       const bool ok = f[m] < lim_ld;
-      pm[m] = ok ? ldv<V>(Pm, f[m]) : zerov<V>();
-      pc[m] = ok ? ldv<V>(Pc, f[m]) : zerov<V>();
+      pm[m] = ok ? ldve<V>(Pm, eo[m]) : zerov<V>();
+      pc[m] = ok ? ldve<V>(Pc, eo[m]) : zerov<V>();
     }
     // stage plane ja (own vectors + halo rows) into LDS buffer 0
     {
@@ -103,58 +111,60 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
 #pragma unroll
       for (int m = 0; m < M; m++) buf[R + t + m * TB] = pc[m];
       for (int h = t; h < R; h += TB) {
-        buf[h] = ldv<V>(Pc, fb - R + h);
+        buf[h] = ldve<V>(Pc, eoff(fb - R + h));
         const long long fh = fb + g.S + h;
-        buf[R + g.S + h] = (fh < lim_ld) ? ldv<V>(Pc, fh) : zerov<V>();
+        buf[R + g.S + h] = (fh < lim_ld) ? ldve<V>(Pc, eoff(fh)) : zerov<V>();
       }
     }
     if (PF) {
-      const REAL* Pn = P + (long long)(ja + 1) * g.PSV * V;
-      const REAL* Bc = Bsrc + (long long)ja * g.PSV * V;
+      const REAL* Pn = P + (long long)(ja + 1) * g.PSE;
+      const REAL* Bc = Bsrc + (long long)ja * g.PSE;
 #pragma unroll
       for (int m = 0; m < M; m++) {
-        pn[m] = (f[m] < lim_ld) ? ldv<V>(Pn, f[m]) : zerov<V>();
-        if (ldb) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
+        pn[m] = (f[m] < lim_ld) ? ldve<V>(Pn, lim(eo[m], ja + 1)) : zerov<V>();
+        if (ldb) bb[m] = (f[m] < g.Fend) ? ldve<V>(Bc, eo[m]) : zerov<V>();
       }
     }
+    // the halo rows this thread stages for the next centre plane (the same vectors of every plane)
+    const long long eo_lo = (t < R) ? eoff(fb - R + t) : 0, eo_hi = (t < R && fb + g.S + t < lim_ld) ? eoff(fb + g.S + t) : 0;
     __syncthreads();
 
     int cur = 0;
     for (int jj = ja; jj <= jb; jj++) {
       const bool more = jj < jb;
-      const REAL* Pn = P + (long long)(jj + 1) * g.PSV * V;
+      const REAL* Pn = P + (long long)(jj + 1) * g.PSE;
       // ---- issue the loads of the following step early
       if (PF) {
         if (more) {
-          const REAL* Pnn = Pn + g.PSV * V;
-          const REAL* Bn = Bsrc + (long long)(jj + 1) * g.PSV * V;
+          const REAL* Pnn = Pn + g.PSE;
+          const REAL* Bn = Bsrc + (long long)(jj + 1) * g.PSE;
 #pragma unroll
           for (int m = 0; m < M; m++) {
-            pnn[m] = (f[m] < lim_ld) ? ldv<V>(Pnn, f[m]) : zerov<V>();
-            if (ldb) bbn[m] = (f[m] < g.Fend) ? ldv<V>(Bn, f[m]) : zerov<V>();
+            pnn[m] = (f[m] < lim_ld) ? ldve<V>(Pnn, lim(eo[m], jj + 2)) : zerov<V>();
+            if (ldb) bbn[m] = (f[m] < g.Fend) ? ldve<V>(Bn, eo[m]) : zerov<V>();
           }
         }
       } else {
-        const REAL* Bc = Bsrc + (long long)jj * g.PSV * V;
+        const REAL* Bc = Bsrc + (long long)jj * g.PSE;
 #pragma unroll
         for (int m = 0; m < M; m++) {
-          pn[m] = (f[m] < lim_ld) ? ldv<V>(Pn, f[m]) : zerov<V>();
-          if (ldb) bb[m] = (f[m] < g.Fend) ? ldv<V>(Bc, f[m]) : zerov<V>();
+          pn[m] = (f[m] < lim_ld) ? ldve<V>(Pn, lim(eo[m], jj + 1)) : zerov<V>();
+          if (ldb) bb[m] = (f[m] < g.Fend) ? ldve<V>(Bc, eo[m]) : zerov<V>();
         }
       }
       // halo rows of the next centre plane (only the first R threads; R <= TB in the common case)
       Vec<V> hlo = zerov<V>(), hhi = zerov<V>();
       const bool halo_in_regs = (R <= TB);
       if (more && halo_in_regs && t < R) {
-        hlo = ldv<V>(Pn, fb - R + t);
+        hlo = ldve<V>(Pn, lim(eo_lo, jj + 1));
         const long long fh = fb + g.S + t;
-        if (fh < lim_ld) hhi = ldv<V>(Pn, fh);
+        if (fh < lim_ld) hhi = ldve<V>(Pn, lim(eo_hi, jj + 1));
       }
 
       // ---- update plane jj
       const Vec<V>* buf = ldsv + (size_t)cur * L;
       const REAL* buff = ldsf + (size_t)cur * L * V;
-      REAL* Oc = OUT + (long long)jj * g.PSV * V;
+      REAL* Oc = OUT + (long long)jj * g.PSE;
       REAL YE = (REAL)0, YEE = (REAL)0;
       if (MAF) {
         const REAL ym = ma.yc[jj - 1], y0 = ma.yc[jj], yp = ma.yc[jj + 1];
@@ -172,7 +182,7 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
         Vec<V> o;
         unsigned wmask = mk[m];
         Vec<V> pv;
-        if (MAF && (MODE == MODE_AX || MODE == MODE_RK)) pv = ldv<V>(ma.pvt + (long long)jj * g.PSV * V, f[m]);
+        if (MAF && (MODE == MODE_AX || MODE == MODE_RK)) pv = ldve<V>(ma.pvt + (long long)jj * g.PSE, eo[m]);
         if (MODE == MODE_RB) {
           // colour: (kk + ii + jj + par) even
           unsigned cm = 0;
@@ -235,19 +245,19 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
 #pragma unroll
             for (int cc = 0; cc < V; cc++)
               if (!(wmask & (1u << cc))) o.v[cc] = pc[m].v[cc];
-            stv<V>(Oc, f[m], o);
+            stve<V>(Oc, eo[m], o);
           } else {
 #pragma unroll
             for (int cc = 0; cc < V; cc++)
-              if (wmask & (1u << cc)) Oc[f[m] * V + cc] = o.v[cc];
+              if (wmask & (1u << cc)) Oc[eo[m] + cc] = o.v[cc];
           }
         } else {
           if (wmask == (1u << V) - 1) {
-            stv<V>(Oc, f[m], o);
+            stve<V>(Oc, eo[m], o);
           } else {
 #pragma unroll
             for (int cc = 0; cc < V; cc++)
-              if (wmask & (1u << cc)) Oc[f[m] * V + cc] = o.v[cc];
+              if (wmask & (1u << cc)) Oc[eo[m] + cc] = o.v[cc];
           }
         }
       }
@@ -264,9 +274,9 @@ stencil_k(const REAL* P, const REAL* B, REAL* OUT, Coef c, Geom g, int par, doub
           }
         } else {
           for (int h = t; h < R; h += TB) {
-            nbuf[h] = ldv<V>(Pn, fb - R + h);
+            nbuf[h] = ldve<V>(Pn, lim(eoff(fb - R + h), jj + 1));
             const long long fh = fb + g.S + h;
-            nbuf[R + g.S + h] = (fh < lim_ld) ? ldv<V>(Pn, fh) : zerov<V>();
+            nbuf[R + g.S + h] = (fh < lim_ld) ? ldve<V>(Pn, lim(eoff(fh), jj + 1)) : zerov<V>();
           }
         }
       }

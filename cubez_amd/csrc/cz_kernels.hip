@@ -106,7 +106,7 @@ MafArgs upload_xyz(const int* sz, int g, const REAL* X, const REAL* Y, const REA
 void launch_pivot(REAL* pvt, const Box& b, const MafArgs& ma) {
   if (b.empty) return;
   const int nplanes = b.jj1 - b.jj0 + 1;
-  if (vec_ok(b, {pvt})) {
+  if (rows_ok(b, {pvt})) {
     EGeom e = make_egeom<VW>(b);
     dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
     hipLaunchKernelGGL((pivot_k<VW>), grid, dim3(256), 0, ctx.stream, pvt, e, ma, b.nkp, b.nip);
@@ -1049,7 +1049,7 @@ void triad_dots_async(REAL* z, const REAL* x, const REAL* y, const REAL* w, REAL
   }
   const int nplanes = b.jj1 - b.jj0 + 1;
   ScopedTimer tm(LBL_EWISE);
-  if (vec_ok(b, {z, x, y, w})) {
+  if (rows_ok(b, {z, x, y, w})) {
     EGeom e = make_egeom<VW>(b);
     const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
     const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));
