@@ -112,9 +112,12 @@ inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, bool balanced,
   const int slots = std::max(1, ctx.num_cu / 8 - (ctx.cu_masked ? 0 : ctx.cu_reserved)) * wg_per_cu;
   double best = 1e300;
   int best_tj = std::min(16, nplanes);
-  for (int tj = std::min(12, nplanes); tj <= std::min(nplanes, 128); tj++) {
+  // (chunks from two planes up: on small grids, where one round of short chunks holds every item, the chain of plane steps of a workgroup is
+  // the whole launch -- 64^3 FP64: 16 us per pass with chunks of 2 planes against 32 us with 12, the floor of rounds 1-2;
+  // profiles/r03/small_grids_chunk_length.txt)
+  for (int tj = std::min(2, nplanes); tj <= std::min(nplanes, 128); tj++) {
     const int nchunk = (nplanes + tj - 1) / tj;
-    if (tj > 12 && (nplanes + tj - 2) / (tj - 1) == nchunk) continue;  // a shorter chunk gives the same count: not a candidate
+    if (tj > 2 && (nplanes + tj - 2) / (tj - 1) == nchunk) continue;  // a shorter chunk gives the same count: not a candidate
     // items of the busiest XCD: a band of whole segments, or an eighth of all items with the balanced table (pair_xcd_map)
     const long long items = balanced ? ((long long)nseg * nchunk + 7) / 8 : (long long)((nseg + 7) / 8) * nchunk;
     const double cost = (double)((items + slots - 1) / slots) * (tj + 3.5);
