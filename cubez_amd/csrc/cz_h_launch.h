@@ -164,7 +164,9 @@ inline const int* pair_xcd_map(int nseg, int nchunk, long long* nblk_out) {
   return it->second.dev;
 }
 
-inline bool pair_use_map(int nseg) { return ctx.tune.t2_map && nseg >= 8 && 10 * nseg < 9 * 8 * ((nseg + 7) / 8); }
+// (fewer than eight segments -- small planes, boxes long in j -- leave whole XCDs without a band: 40 x 2000 x 40 ran on ONE XCD, at 0.6 of the
+// single-sweep rate, until round 3; profiles/r03/non_cubic_boxes.txt)
+inline bool pair_use_map(int nseg) { return ctx.tune.t2_map && 10 * nseg < 9 * 8 * ((nseg + 7) / 8); }
 
 // two fused sweeps (jacobi2p_k); returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
 template <int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0>
