@@ -166,6 +166,18 @@ def test_bicgstab_vs_wide_oracle(case):
                                       ("f64", (33, 47, 61)), ("f32", (40, 36, 61)), ("f32", (70, 50, 126))],  # the last three: rows no multiple of the vector width
                          ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
 def test_bicgstab_with_its_vector_updates_made_inside_the_preconditioner_pass(prec, gsz, monkeypatch):
+    _fused_equals_unfused(prec, gsz, "jacobi", monkeypatch)
+
+
+@pytest.mark.parametrize("prec,gsz,pc", [("f64", (64, 64, 64), "none"), ("f32", (40, 36, 61), "none"), ("f64", (33, 47, 62), "pcr_j_esa")],
+                         ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
+def test_bicgstab_without_preconditioner_reads_p_instead_of_a_copy_of_it(prec, gsz, pc, monkeypatch):
+    """"none" (and pcr_j_esa, for which the reference's Preconditioner has no case) copies p to p_: the solve reads p itself.  Same values,
+    so history and field equal those of the solve that copies (CZ_BICG_FUSE=0), bit for bit."""
+    _fused_equals_unfused(prec, gsz, pc, monkeypatch)
+
+
+def _fused_equals_unfused(prec, gsz, pc, monkeypatch):
     """p = r + beta (p - omega q) and s = r - alpha q are not launched on their own where the Jacobi preconditioner starts with the whole-box
     fused pass from zero: that pass makes its right-hand side from their operands and stores it (jacobi2p_k<BS>).  Same operations on the
     same values: history and field of the solve equal those of the solve with the updates launched (CZ_BICG_FUSE=0), bit for bit."""
@@ -174,14 +186,14 @@ def test_bicgstab_with_its_vector_updates_made_inside_the_preconditioner_pass(pr
     for fuse in ("1", "0"):
         monkeypatch.setenv("CZ_BICG_FUSE", fuse)
         cz = CZ(prec, quiet=True)
-        assert cz.setup(list(gsz) + ["pbicgstab", 40, 0.8, "jacobi"]) == 1
+        assert cz.setup(list(gsz) + ["pbicgstab", 40, 0.8, pc]) == 1
         itr = cz.solve()
         out[fuse] = (itr, cz.res, list(cz.history()), cz.field().tobytes(), cz.info()["bicg_fused"])
         cz.close()
     assert out["0"][4] == 0
     n = len(out["1"][2])
     assert out["1"][4] in (0, 2 * n - 1), out["1"][4]  # all or nothing: every update but the first iteration's copy
-    if gsz in ((64, 64, 64), (128, 128, 128)):
+    if pc == "jacobi" and gsz in ((64, 64, 64), (128, 128, 128)):
         assert out["1"][4] == 2 * n - 1  # shapes the two-stage pass is known to take
     assert out["1"][:4] == out["0"][:4]
 
