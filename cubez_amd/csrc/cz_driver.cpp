@@ -695,7 +695,7 @@ CZ::PassPlan CZ::plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, 
     if (numProc > 1 && n_shell > 0 && pair_probe(X, WRK, B, size, interior, interior1, GUIDE, cf[6], p.maf)) p.kind = PassPlan::SPLIT;
     p.lag = (p.kind == PassPlan::SPLIT && converge_check && lag_reduce != 0) ? 1 : 0;
     p.buffers = p.lag ? 3 : 2;
-    p.zero_start = (!rb && x_is_zero && numProc == 1 && !converge_check && !p.maf && itr_max >= 2) ? 1 : 0;
+    p.zero_start = (x_is_zero && numProc == 1 && !converge_check && !p.maf && (rb || itr_max >= 2)) ? 1 : 0;
   }
   if (getenv("CZ_COMM_DEBUG") && numProc > 1 && (p.kind != last_plan.kind || p.lag != last_plan.lag || p.maf != last_plan.maf || p.rb != last_plan.rb || !plan_printed)) {
     static const char* const kinds[] = {"single sweeps", "fused pass, whole box", "fused pass, shell + interior (exchange overlapped)"};
@@ -795,7 +795,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       int launched;
       if (plan.zero_start && itr == 1 && made)  // ... and the right-hand side made on the way (BiCGSTAB's vector update folded in)
         launched = czhip_jacobi2_from_zero_made_async(src, dst, B, made->op, made->x, made->y, made->z, made->a, made->b, size, innerFidx, idx1, gc,
-                                                      cf, ac1, d_res, 0);
+                                                      cf, ac1, -1, d_res, 0);
       else if (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner): neither cleared in memory nor read
         launched = czhip_jacobi2_from_zero_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res);
       else if (maf)
@@ -909,10 +909,19 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
 }
 
 // cz_Poisson.cpp:159-235
-int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check) {
+int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double& flop, int s_type, bool converge_check, bool x_is_zero,
+              const BMade* made) {
   const int gc = GUIDE;
   hipStream_t st = stream();
-  const PassPlan plan = plan_pass(X, B, s_type, itr_max, converge_check, false, true);
+  const PassPlan plan = plan_pass(X, B, s_type, itr_max, converge_check, x_is_zero, true);
+  if (made && !(plan.kind == PassPlan::WHOLE && plan.zero_start)) {  // (see CZ::JACOBI)
+    printf("error : the solve that was to make its right-hand side does not start with a whole fused pass from zero\n");
+    exit(1);
+  }
+  if (x_is_zero && !plan.zero_start) {  // the caller skipped its blas_clear_ and this solve does not take the zero as a literal: clear now
+    const size_t nb = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
+    HIP_CHECK(hipMemsetAsync(X, 0, nb, st));
+  }
   const bool maf = plan.maf != 0;  // cz_Poisson.cpp:190-200
   const MafPtrs mp{d_xc, d_yc, d_zc, nullptr};
   const MafPtrs* mpp = maf ? &mp : nullptr;
@@ -973,7 +982,11 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
         czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
     } else if (plan.kind == PassPlan::WHOLE) {
-      const int launched = maf ? pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, ip, d_res, res_normal, eps, itr,
+      const int launched = (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner), the right-hand side made on the way or read
+                               ? czhip_jacobi2_from_zero_made_async(src, dst, B, made ? made->op : 0, made ? made->x : nullptr, made ? made->y : nullptr,
+                                                                    made ? made->z : nullptr, made ? made->a : (REAL_TYPE)0, made ? made->b : (REAL_TYPE)0,
+                                                                    size, innerFidx, idx1, gc, cf, ac1, ip, d_res, 0)
+                           : maf ? pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, ip, d_res, res_normal, eps, itr,
                                                 in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip)  // :190-200
                                : czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
                                                     in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :205-209 (+ :218-230)
@@ -1286,18 +1299,19 @@ bool CZ::xx_shell_is_zero(const REAL_TYPE* xx) const { return xx == pcg_p_ || xx
 
 // cz_Poisson.cpp:273-322
 // May PBiCGSTAB withhold `p = r + beta (p - omega q)` and `s = r - alpha q` and let the first pair of the preconditioner solve that follows
-// make them (jacobi2p_k<BS>)?  Plain Jacobi preconditioner on the whole-box fused pass with the literal zero start, one rank (a decomposed
+// make them (jacobi2p_k<BS>)?  Plain Jacobi or red-black SOR preconditioner on the whole-box fused pass with the literal zero start, one rank (a decomposed
 // solve reads the right-hand side in its ghost layer, where the operands are not valid), and the launcher takes it.  CZ_BICG_FUSE=0: never.
 bool CZ::bicg_fusable(int pc_type) {
   const char* e = getenv("CZ_BICG_FUSE");
   if (e && atoi(e) == 0) return false;
-  if (pc_type != LS_JACOBI || numProc != 1 || czhip_use_t2() == 0) return false;
-  const PassPlan plan = plan_pass(pcg_p_, pcg_p, LS_JACOBI, 8, false, true, false);
+  if ((pc_type != LS_JACOBI && pc_type != LS_SOR2SMA) || numProc != 1 || czhip_use_t2() == 0) return false;
+  const bool rb = pc_type == LS_SOR2SMA;
+  const PassPlan plan = plan_pass(pcg_p_, pcg_p, pc_type, 8, false, true, rb);
   if (!(plan.kind == PassPlan::WHOLE && plan.zero_start)) return false;
   int idx1[6];
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f];
   return czhip_jacobi2_from_zero_made_async(pcg_p_, WRK, pcg_s, 2, pcg_r, pcg_q, pcg_p, (REAL_TYPE)0, (REAL_TYPE)0, size, innerFidx, idx1, GUIDE, cf, ac1,
-                                            d_res, 1) != 0;
+                                            rb ? 0 : -1, d_res, 1) != 0;
 }
 
 void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type, const BMade* made) {
@@ -1308,7 +1322,7 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type, 
   // the fused-pair path the clear is not even executed: xx's guide cells / faces are zero from allocation on (sweeps only
   // ever write its inner box) and the first pair takes "u == 0" as a literal instead of reading it.
   // (single-domain only: a decomposed run leaves the neighbours' values in xx's ghost layers)
-  const bool zero_start = (s_type == LS_JACOBI) && numProc == 1 && czhip_use_t2() != 0 && xx_shell_is_zero(xx);
+  const bool zero_start = (s_type == LS_JACOBI || s_type == LS_SOR2SMA) && numProc == 1 && czhip_use_t2() != 0 && xx_shell_is_zero(xx);
   if (!zero_start) HIP_CHECK(hipMemsetAsync(xx, 0, nbytes, stream()));
   struct Scope {
     bool& f;
@@ -1322,7 +1336,7 @@ void CZ::Preconditioner(REAL_TYPE* xx, REAL_TYPE* bb, double& flop, int s_type, 
       break;
     case LS_SOR2SMA:
     case LS_SOR2SMA_MAF:
-      RBSOR(res, xx, bb, lc_max, flop, s_type, false);
+      RBSOR(res, xx, bb, lc_max, flop, s_type, false, zero_start, made);
       break;
     case LS_PCR_RB:
       LSOR_PCR_RB(res, xx, bb, lc_max, flop, s_type, false);

@@ -138,7 +138,8 @@ class CZ {
              bool x_is_zero = false, const BMade* made = nullptr);
   bool bicg_fusable(int pc_type);
   bool xx_shell_is_zero(const REAL_TYPE* xx) const;
-  int RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
+  int RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true, bool x_is_zero = false,
+            const BMade* made = nullptr);
   int PSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   int LSOR_PCR_VARIANT(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);
   int LSOR_PCR_MAF(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true);

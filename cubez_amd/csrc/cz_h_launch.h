@@ -254,18 +254,18 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
     if (tb == 512 && launch_jacobi2_inst<512, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma)) return true;
     return launch_jacobi2_inst<1024, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma);
   }
-  if (RB == 0 && zero_u && bs_op != 0) {  // the right-hand side made from the operands of the vector update before the solve (jacobi2p_k<BS>)
+  if (zero_u && bs_op != 0) {  // the right-hand side made from the operands of the vector update before the solve (jacobi2p_k<BS>)
     if (!bs || !rows_ok(b, {bs->x, bs->y, bs->z, bs->out})) return false;
     if (bs_op == 1) {
-      if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
-      return launch_jacobi2_inst<1024, 2, 0, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
+      if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
+      return launch_jacobi2_inst<1024, 2, RB, 1, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
     }
-    if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1, 0, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
-    return launch_jacobi2_inst<1024, 2, 0, 1, 0, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
+    if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 1, 0, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
+    return launch_jacobi2_inst<1024, 2, RB, 1, 0, 2>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, MafArgs(), *bs);
   }
-  if (RB == 0 && zero_u) {
-    if (tb == 512) return launch_jacobi2_inst<512, 2, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
-    return launch_jacobi2_inst<1024, 2, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+  if (zero_u) {
+    if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+    return launch_jacobi2_inst<1024, 2, RB, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
   }
   if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
   return launch_jacobi2_inst<1024, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);

@@ -120,7 +120,7 @@ template <int V, int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0>
 __global__ void __launch_bounds__(TB, TB == 512 ? 4 : 1)
 jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
            const int* __restrict__ skip, Fin2 fin, MafArgs ma, BSrc bs) {
-  static_assert(BS == 0 || (ZU == 1 && RB == 0 && MAF == 0), "a made right-hand side belongs to the first pair of a preconditioner solve");
+  static_assert(BS == 0 || (ZU == 1 && MAF == 0), "a made right-hand side belongs to the first pass of a preconditioner solve");
   if (skip != nullptr && *skip != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;

@@ -426,21 +426,26 @@ int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_R
 
 // The same with the right-hand side of the solve MADE on the way: op 1: b = a*x + y (blas_triad_: s = r - alpha q), op 2: b = x + a*(z - bb*y)
 // (blas_bicg_1_: p = r + beta (p - omega q)), written to `b_out` by the pass (jacobi2p_k<BS>) -- the vector update before a preconditioner
-// solve of BiCGSTAB (cz_Poisson.cpp:398, 434) and the first pair of that solve in one launch.  b_out must not be one of x, y, z.
+// solve of BiCGSTAB (cz_Poisson.cpp:398, 434) and the first pass of that solve in one launch; b_out must not be one of x, y, z.  op 0: b_out
+// is read as the right-hand side (the plain start from zero).  rb_ofst < 0: two Jacobi sweeps; >= 0: one red-black iteration with that offset.
 int czhip_jacobi2_from_zero_made_async(const CZ_REAL* u_shape, CZ_REAL* w, CZ_REAL* b_out, int op, const CZ_REAL* x, const CZ_REAL* y,
                                        const CZ_REAL* z, CZ_REAL a, CZ_REAL bb, const int* sz, const int* idx, const int* idx1, int g,
-                                       const CZ_REAL* cf, CZ_REAL omg, double* res_dev, int probe) {
+                                       const CZ_REAL* cf, CZ_REAL omg, int rb_ofst, double* res_dev, int probe) {
   ensure_init();
-  if (!ctx.tune.fuse_fin || (op != 1 && op != 2)) return 0;
-  if (b_out == x || b_out == y || (op == 2 && b_out == z)) return 0;
+  if (!ctx.tune.fuse_fin || op < 0 || op > 2) return 0;
+  if (op != 0 && (b_out == x || b_out == y || (op == 2 && b_out == z))) return 0;
   const Box bx = make_box(sz, idx, g);
   if (bx.empty || g < 2) return 0;
   const Box ba = idx1 ? make_box(sz, idx1, g) : bx;
   Fin2 fin;
   fin.dst = res_dev;
   BSrc bs;
-  bs.x = x, bs.y = y, bs.z = (op == 2) ? z : x, bs.out = b_out, bs.a = a, bs.b = bb;
-  return launch_jacobi2<0>(u_shape, b_out, w, make_coef(cf, omg), bx, ba, nullptr, fin, 0, 1, probe != 0, nullptr, &bs, op) ? 1 : 0;
+  if (op != 0) bs.x = x, bs.y = y, bs.z = (op == 2) ? z : x, bs.out = b_out, bs.a = a, bs.b = bb;
+  if (rb_ofst >= 0) {
+    fin.single = 1;
+    return launch_jacobi2<1>(u_shape, b_out, w, make_coef(cf, omg), bx, ba, nullptr, fin, rb_parity(g, idx, rb_ofst, 0), 1, probe != 0, nullptr, op ? &bs : nullptr, op) ? 1 : 0;
+  }
+  return launch_jacobi2<0>(u_shape, b_out, w, make_coef(cf, omg), bx, ba, nullptr, fin, 0, 1, probe != 0, nullptr, op ? &bs : nullptr, op) ? 1 : 0;
 }
 
 // One complete red-black SOR iteration (colour 0 then colour 1, cz_Poisson.cpp:205-209) in one pass over memory, u -> w.

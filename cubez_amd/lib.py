@@ -159,6 +159,19 @@ class CzHip:
         self.lib.czhip_d2h(out, self._dres, 16)
         return bool(ok), out[0]
 
+    def pass_from_zero(self, w, b_out, sz, idx, cf, omg, op=0, x=None, y=None, z=None, a=0.0, bb=0.0, rb_ofst=-1):
+        """first pass of a preconditioner solve: start vector a literal zero, right-hand side read (op 0) or made from x, y, z (op 1: a*x + y,
+        op 2: x + a*(z - bb*y)) and stored to b_out; two Jacobi sweeps (rb_ofst < 0) or one red-black iteration; returns launched"""
+        (_, szp), (_, idxp), (_, cfp) = self._i(sz), self._i(idx), self._r(cf)
+        if not hasattr(self, "_dres"):
+            self._dres = self.lib.czhip_alloc_s3d((C.c_int * 3)(4, 4, 4))
+        f = self.lib.czhip_jacobi2_from_zero_made_async
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, self.creal, self.creal, C.c_void_p, C.c_void_p,
+                      C.c_void_p, C.c_int, C.c_void_p, self.creal, C.c_int, C.c_void_p, C.c_int]
+        ptr = lambda d: d.ptr if d is not None else None  # noqa: E731
+        return bool(f(w.ptr, w.ptr, b_out.ptr, int(op), ptr(x), ptr(y), ptr(z), float(a), float(bb), szp, idxp, None, GUIDE, cfp, float(omg), int(rb_ofst),
+                      self._dres, 0))
+
     def pair_split(self, u, w, b, sz, idx, idx1, nID, cf, omg, rb_ofst=-1, read=True):
         """the fused pass as shell slabs + interior (what a decomposed brick runs); returns (launched, res0, res1)."""
         (_, szp), (_, idxp), (_, idx1p), (_, nidp), (_, cfp) = self._i(sz), self._i(idx), self._i(idx1), self._i(nID), self._r(cf)

@@ -227,11 +227,12 @@ int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_R
                                   int g, const CZ_REAL* cf, CZ_REAL omg, double* res_dev);
 /* The same with the right-hand side of the solve MADE on the way from the operands of the vector update that precedes a preconditioner
  * solve in BiCGSTAB -- op 1: b = a*x + y (blas_triad_, cz_blas.f90:297), op 2: b = x + a*(z - bb*y) (blas_bicg_1_, :490) -- and stored
- * to b_out (not one of x, y, z) for the later passes of the solve: update and first pair in one launch, same bits as the two calls.
- * probe != 0: only says whether the launch would be taken. */
+ * to b_out (not one of x, y, z) for the later passes of the solve: update and first pass in one launch, same bits as the two calls.
+ * op 0: b_out is read as the right-hand side.  rb_ofst < 0: two Jacobi sweeps (czhip_jacobi2_async); >= 0: one red-black iteration with
+ * that colour offset (czhip_rbsor2_async).  probe != 0: only says whether the launch would be taken. */
 int czhip_jacobi2_from_zero_made_async(const CZ_REAL* u_shape, CZ_REAL* w, CZ_REAL* b_out, int op, const CZ_REAL* x, const CZ_REAL* y,
                                        const CZ_REAL* z, CZ_REAL a, CZ_REAL bb, const int* sz, const int* idx, const int* idx1, int g,
-                                       const CZ_REAL* cf, CZ_REAL omg, double* res_dev, int probe);
+                                       const CZ_REAL* cf, CZ_REAL omg, int rb_ofst, double* res_dev, int probe);
 /* The same bookkeeping for a pair whose two sums were all-reduced first (decomposed runs). */
 void czhip_check2_async(const double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                         int* conv_itr_dev);

@@ -317,6 +317,48 @@ def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
         assert launched > 0
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", [(40, 36, 60), (33, 50, 123), (29, 31, 253), (70, 20, 126)], ids=lambda b: "x".join(map(str, b)))
+@pytest.mark.parametrize("rb", [-1, 0, 1], ids=["jacobi_pair", "rb_ofst0", "rb_ofst1"])
+def test_first_pass_of_a_preconditioner_solve_from_a_literal_zero(prec, box, rb):
+    """czhip_jacobi2_from_zero_made_async: the start vector is not read (a literal zero) and the right-hand side is read (op 0) or made on the
+    way from the operands of blas_triad_ (op 1) / blas_bicg_1_ (op 2) and stored.  == the vector update launched on its own, then the pass on a
+    cleared start vector; output field and stored right-hand side bit for bit.  Rows that are no multiple of the vector width included."""
+    ni, nj, nk = box
+    sz, idx = [ni, nj, nk], [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h = _hip(prec)
+    R = np.float32 if prec == "f32" else np.float64
+    rng = np.random.default_rng(ni + 3 * nj + 5 * nk + rb)
+    shape = (nj + 4, ni + 4, nk + 4)
+    cf = rng.uniform(0.5, 1.5, 7).astype(R)
+    cf[6] = 6.1
+    x, y, z, keep = (rng.uniform(-1, 1, shape).astype(R) for _ in range(4))
+    zero = np.zeros(shape, dtype=R)
+    dx, dy, dz = h.alloc(sz, x), h.alloc(sz, y), h.alloc(sz, z)
+    for op in (0, 1, 2):
+        # the reference sequence: the update as its own kernel, then the pass reading a cleared start vector
+        db = h.alloc(sz, keep if op != 2 else z)
+        if op == 1:
+            h.blas_triad(db, dx, dy, -0.7, sz, idx)            # b = a*x + y
+        if op == 2:
+            h.blas_bicg_1(db, dx, dy, 0.6, 1.3, sz, idx)        # b = x + a*(b - bb*y), in place on a copy of z
+        du, w1 = h.alloc(sz, zero), h.alloc(sz, zero)
+        ok1 = h.jacobi2(du, w1, db, sz, idx, cf, 0.9)[0] if rb < 0 else h.rbsor2(du, w1, db, sz, idx, cf, rb, 1.2)[0]
+        # the fused launch: b_out starts as what the update would have found there outside the inner box
+        dbo, w2 = h.alloc(sz, keep if op != 2 else z), h.alloc(sz, zero)
+        if op == 0:
+            dbo.put(db.get())
+        ok2 = h.pass_from_zero(w2, dbo, sz, idx, cf, 0.9 if rb < 0 else 1.2, op=op, x=dx, y=dy, z=dz, a=-0.7 if op == 1 else 0.6, bb=1.3, rb_ofst=rb)
+        assert ok1 == ok2
+        if ok2:
+            assert _beq(w2.get(), w1.get()), (op, rb)
+            assert _beq(dbo.get(), db.get()), (op, rb)
+        elif nk + 4 >= 64:
+            raise AssertionError("the pass refused a shape it is known to take")
+        for d in (db, du, w1, dbo, w2):
+            d.free()
+
+
 def _coords(rng, n, R):
     return (np.cumsum(rng.uniform(0.5, 1.5, n + 4)).astype(R) * R(0.05)).astype(R)
 

@@ -169,6 +169,14 @@ def test_bicgstab_with_its_vector_updates_made_inside_the_preconditioner_pass(pr
     _fused_equals_unfused(prec, gsz, "jacobi", monkeypatch)
 
 
+@pytest.mark.parametrize("prec,gsz,pc", [("f64", (64, 64, 64), "sor2sma"), ("f32", (40, 36, 61), "sor2sma"), ("f32", (128, 128, 128), "sor2sma")],
+                         ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
+def test_bicgstab_red_black_preconditioner_from_a_literal_zero_with_its_right_hand_side_made(prec, gsz, pc, monkeypatch):
+    """the same for the red-black SOR preconditioner: its first iteration takes the cleared start vector as a literal and makes the right-hand
+    side (round 3; before, the vector was cleared in memory and read)"""
+    _fused_equals_unfused(prec, gsz, pc, monkeypatch)
+
+
 @pytest.mark.parametrize("prec,gsz,pc", [("f64", (64, 64, 64), "none"), ("f32", (40, 36, 61), "none"), ("f64", (33, 47, 62), "pcr_j_esa")],
                          ids=lambda v: v if isinstance(v, str) else "x".join(map(str, v)))
 def test_bicgstab_without_preconditioner_reads_p_instead_of_a_copy_of_it(prec, gsz, pc, monkeypatch):
@@ -193,7 +201,7 @@ def _fused_equals_unfused(prec, gsz, pc, monkeypatch):
     assert out["0"][4] == 0
     n = len(out["1"][2])
     assert out["1"][4] in (0, 2 * n - 1), out["1"][4]  # all or nothing: every update but the first iteration's copy
-    if pc == "jacobi" and gsz in ((64, 64, 64), (128, 128, 128)):
+    if pc in ("jacobi", "sor2sma") and gsz in ((64, 64, 64), (128, 128, 128)):
         assert out["1"][4] == 2 * n - 1  # shapes the two-stage pass is known to take
     assert out["1"][:4] == out["0"][:4]
 
