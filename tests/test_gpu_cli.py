@@ -107,3 +107,30 @@ def test_cli_writes_the_section_report(tmp_path):
 def test_cli_profile_can_be_switched_off(tmp_path):
     r = _run("f32", [16, 16, 16, "jacobi", 4, 0.8], tmp_path, env={"CZ_PROFILE": "0"})
     assert r.returncode == 0 and not os.path.exists(os.path.join(tmp_path, "profiling.txt"))
+
+
+@pytest.mark.parametrize("prec,args", [("f32", [37, 29, 61, "jacobi", 40, 0.8]), ("f32", [37, 29, 61, "sor2sma", 40, 1.5]),
+                                        ("f64", [29, 33, 63, "pbicgstab", 30, 0.8, "jacobi"]), ("f64", [21, 26, 65, "jacobi_maf", 30, 0.8])],
+                         ids=lambda v: v if isinstance(v, str) else "_".join(map(str, v)))
+def test_scalar_kernels_of_rounds_1_and_2_give_the_history_of_the_vector_kernels(tmp_path, prec, args):
+    """Rows that are no multiple of the vector width took the scalar kernels (V = 1) until round 3; CZHIP_T2_ROWS=0 still sends them there (the
+    'before' of profiles/r03/unaligned_k_extent.txt).  Two independent code paths for the same arithmetic: the history files must agree --
+    byte for byte for the stationary solvers (double-accumulated residuals in a fixed tree differ only in tree shape: compare to 1e-12)."""
+    out = {}
+    for rows in ("1", "0"):
+        d = tmp_path / rows
+        d.mkdir()
+        r = _run(prec, args, d, env={"CZHIP_T2_ROWS": rows})
+        assert r.returncode == 0, r.stdout + r.stderr
+        m = re.search(r"Iter = (\d+)  Res = ([0-9.e+-]+)", r.stdout)
+        e = re.search(r"Error max = ([0-9.e+-]+) at \((\d+) (\d+) (\d+)\)", r.stdout)
+        assert m and e, r.stdout
+        out[rows] = (int(m.group(1)), float(m.group(2)), e.groups(), open(os.path.join(d, f"{args[3]}.txt")).read().splitlines())
+    assert out["1"][0] == out["0"][0]
+    assert out["1"][2] == out["0"][2]  # the analytic error of the final field, as printed: the fields agree
+    tol = 1e-12 if args[3] != "pbicgstab" else 1e-6
+    assert abs(out["1"][1] - out["0"][1]) <= max(tol, 2e-6) * out["0"][1]  # (the printed residual carries 7 digits)
+    assert len(out["1"][3]) == len(out["0"][3])
+    for a, b in zip(out["1"][3][1:], out["0"][3][1:]):
+        ra, rb = float(a.split(",")[1]), float(b.split(",")[1])
+        assert abs(ra - rb) <= 2e-6 * rb
