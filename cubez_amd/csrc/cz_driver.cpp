@@ -794,8 +794,8 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
       const bool in_kernel_check = converge_check && numProc == 1;
       int launched;
       if (plan.zero_start && itr == 1 && made)  // ... and the right-hand side made on the way (BiCGSTAB's vector update folded in)
-        launched = czhip_jacobi2_from_zero_made_async(src, dst, B, made->op, made->x, made->y, made->z, made->a, made->b, size, innerFidx, idx1, gc,
-                                                      cf, ac1, -1, d_res, 0);
+        launched = pass_from_zero_made(src, dst, B, made->op, made->x, made->y, made->z, made->a, made->a_dev, made->b, size, innerFidx, idx1, gc,
+                                       cf, ac1, -1, d_res, 0);
       else if (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner): neither cleared in memory nor read
         launched = czhip_jacobi2_from_zero_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res);
       else if (maf)
@@ -983,9 +983,9 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
       }
     } else if (plan.kind == PassPlan::WHOLE) {
       const int launched = (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner), the right-hand side made on the way or read
-                               ? czhip_jacobi2_from_zero_made_async(src, dst, B, made ? made->op : 0, made ? made->x : nullptr, made ? made->y : nullptr,
-                                                                    made ? made->z : nullptr, made ? made->a : (REAL_TYPE)0, made ? made->b : (REAL_TYPE)0,
-                                                                    size, innerFidx, idx1, gc, cf, ac1, ip, d_res, 0)
+                               ? pass_from_zero_made(src, dst, B, made ? made->op : 0, made ? made->x : nullptr, made ? made->y : nullptr,
+                                                     made ? made->z : nullptr, made ? made->a : (REAL_TYPE)0, made ? made->a_dev : nullptr,
+                                                     made ? made->b : (REAL_TYPE)0, size, innerFidx, idx1, gc, cf, ac1, ip, d_res, 0)
                            : maf ? pair_maf_async(src, dst, B, size, innerFidx, idx1, gc, d_xc, d_yc, d_zc, ac1, ip, d_res, res_normal, eps, itr,
                                                 in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip)  // :190-200
                                : czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
@@ -1398,6 +1398,14 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
   // where it is the whole-box fused pass from a literal zero: one launch and one read of an array less per solve.
   const bool fuse = !maf && bicg_fusable(pc_type);
   bicg_fused = 0;
+  // alpha / omega on the device between their dot products and their users (bicg_scalar_async): d_res[12..15] holds alpha, omega, -alpha, -omega
+  // as REALs.  CZ_BICG_FUSE=0: the host computes them from read-back dot products as in rounds 1-2 (and as the reference does).
+  REAL_TYPE* const d_bs = reinterpret_cast<REAL_TYPE*>(d_res + 12);
+  bool devsc = true;
+  {
+    const char* e = getenv("CZ_BICG_FUSE");
+    if (e && atoi(e) == 0) devsc = false;
+  }
   bool pc_copy;  // Preconditioner() has no case for pc_type: it copies (cz_Poisson.cpp:282-321)
   switch (pc_type) {
     case LS_JACOBI: case LS_JACOBI_MAF: case LS_SOR2SMA: case LS_SOR2SMA_MAF: case LS_PCR_RB: case LS_PSOR: case LS_PSOR_MAF: case LS_PCR:
@@ -1426,7 +1434,7 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
       itr = 0;
       break;
     }
-    BMade made_p{0, nullptr, nullptr, nullptr, (REAL_TYPE)0, (REAL_TYPE)0};
+    BMade made_p{0, nullptr, nullptr, nullptr, (REAL_TYPE)0, (REAL_TYPE)0, nullptr};
     if (itr == 1) {
       HIP_CHECK(hipMemcpyAsync(pcg_p, pcg_r, nbytes, hipMemcpyDeviceToDevice, st));  // :387
     } else {
@@ -1434,7 +1442,7 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
       if (fuse) {
         // :398 withheld: the first pair of the solve below makes p = r + beta (p - omega q) on its way and writes it to the array of s
         // (dead until :434), which then IS p -- the pass cannot update p in place: neighbouring workgroups read each other's rows
-        made_p = BMade{2, pcg_r, pcg_q, pcg_p, beta, omega};
+        made_p = BMade{2, pcg_r, pcg_q, pcg_p, beta, omega, nullptr};
         std::swap(pcg_p, pcg_s);
         bicg_fused++;
       } else {
@@ -1454,14 +1462,21 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     // :417/:421 q = A p_  and  :427 q.r0
     calc_ax_dots_async(pcg_q, p_, pcg_r0, size, innerFidx, gc, cf, maf ? &mp : nullptr, d_res + 2);
     flop += (maf ? 63.0 : 13.0) * npts() + 2.0 * npts();
-    REAL_TYPE q_r0, q_q;
-    if (!fetch2(d_res + 2, q_r0, q_q)) return 0;
-    alpha = rho / q_r0;  // :427
-
-    REAL_TYPE r_alpha = -alpha;
-    BMade made_s{1, pcg_q, pcg_r, nullptr, r_alpha, (REAL_TYPE)0};
+    REAL_TYPE r_alpha = (REAL_TYPE)0;
+    if (devsc) {
+      // alpha = rho / (q . r0) (:427) is made on the device and read there by the launches that need it; the host reads it back with omega and
+      // the residual at the end of the iteration (one wait instead of three: 2 x 25-35 us of idle GPU per iteration, a fifth of an iteration at 128^3)
+      if (!Comm_SUM_dev(d_res + 2, 2)) return 0;
+      bicg_scalar_async(1, d_res + 2, rho, d_bs);
+    } else {
+      REAL_TYPE q_r0, q_q;
+      if (!fetch2(d_res + 2, q_r0, q_q)) return 0;
+      alpha = rho / q_r0;  // :427
+      r_alpha = -alpha;
+    }
+    BMade made_s{1, pcg_q, pcg_r, nullptr, r_alpha, (REAL_TYPE)0, devsc ? d_bs + 2 : nullptr};
     if (fuse) bicg_fused++;  // :434 withheld likewise: s = r - alpha q
-    else triad_async(pcg_s, pcg_q, pcg_r, r_alpha, size, innerFidx, gc);  // :434
+    else triad_async(pcg_s, pcg_q, pcg_r, r_alpha, size, innerFidx, gc, devsc ? d_bs + 2 : nullptr);  // :434
     flop += 2.0 * npts();
     if (!Comm_S(pcg_s)) return 0;  // :438
 
@@ -1474,18 +1489,34 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     // :453/:457 t_ = A s_  and  :464 t_.s, t_.t_
     calc_ax_dots_async(pcg_t_, s_, pcg_s, size, innerFidx, gc, cf, maf ? &mp : nullptr, d_res + 4);
     flop += (maf ? 63.0 : 13.0) * npts() + 4.0 * npts();
-    REAL_TYPE ts, tt;
-    if (!fetch2(d_res + 4, ts, tt)) return 0;
-    omega = ts / tt;  // :464
-    r_omega = -omega;
+    if (devsc) {
+      if (!Comm_SUM_dev(d_res + 4, 2)) return 0;
+      bicg_scalar_async(2, d_res + 4, (REAL_TYPE)0, d_bs);  // omega = (t . s) / (t . t)  :464
+    } else {
+      REAL_TYPE ts, tt;
+      if (!fetch2(d_res + 4, ts, tt)) return 0;
+      omega = ts / tt;  // :464
+      r_omega = -omega;
+    }
 
-    bicg2_async(X, p_, s_, alpha, omega, size, innerFidx, gc);  // :470
+    bicg2_async(X, p_, s_, alpha, omega, size, innerFidx, gc, devsc ? d_bs : nullptr, devsc ? d_bs + 1 : nullptr);  // :470
     flop += 4.0 * npts();
     // :476 r = s - omega t_  with  :481 res = r.r  and the next :376 rho = r.r0
-    triad_dots_async(pcg_r, pcg_t_, pcg_s, pcg_r0, r_omega, size, innerFidx, gc, d_res + 6);
+    triad_dots_async(pcg_r, pcg_t_, pcg_s, pcg_r0, r_omega, size, innerFidx, gc, d_res + 6, devsc ? d_bs + 3 : nullptr);
     flop += 2.0 * npts() + 2.0 * npts();
     REAL_TYPE rr;
-    if (!fetch2(d_res + 6, rr, rho_next)) return 0;
+    if (devsc) {  // the one wait of the iteration: r.r, r.r0 and the two scalars the next beta needs
+      if (!Comm_SUM_dev(d_res + 6, 2)) return 0;
+      HIP_CHECK(hipMemcpyAsync(h_scal + 2, d_res + 6, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(h_scal + 12, d_res + 12, 2 * sizeof(REAL_TYPE), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      rr = (REAL_TYPE)h_scal[2], rho_next = (REAL_TYPE)h_scal[3];
+      const REAL_TYPE* hs = reinterpret_cast<const REAL_TYPE*>(h_scal + 12);
+      alpha = hs[0], omega = hs[1];
+      r_omega = -omega;
+    } else if (!fetch2(d_res + 6, rr, rho_next)) {
+      return 0;
+    }
     res = rr;
 
     if (!Comm_S(X)) return 0;  // :486

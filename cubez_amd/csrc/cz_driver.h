@@ -133,6 +133,7 @@ class CZ {
     const REAL_TYPE* y;
     const REAL_TYPE* z;
     REAL_TYPE a, b;
+    const REAL_TYPE* a_dev;  // where set: a lives on the device (bicg_scalar_async)
   };
   int JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, int itr_max, double& flop, int s_type, bool converge_check = true,
              bool x_is_zero = false, const BMade* made = nullptr);

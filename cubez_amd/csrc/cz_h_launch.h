@@ -324,16 +324,18 @@ Coef make_coef(const REAL* cf, REAL omg) {
 }
 
 template <int OP>
-void launch_ewise(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL bcoef, const Box& b) {
+void launch_ewise(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL bcoef, const Box& b, const REAL* a_dev = nullptr, const REAL* b_dev = nullptr) {
   if (b.empty) return;
   ScopedTimer tm(LBL_EWISE);
   const int nplanes = b.jj1 - b.jj0 + 1;
   if (rows_ok(b, {Z, X, Y})) {
     EGeom e = make_egeom<VW>(b);
+    e.pa = a_dev, e.pb = b_dev;
     dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
     hipLaunchKernelGGL((ewise_k<VW, OP>), grid, dim3(256), 0, ctx.stream, Z, X, Y, a, bcoef, e);
   } else {
     EGeom e = make_egeom<1>(b);
+    e.pa = a_dev, e.pb = b_dev;
     dim3 grid((unsigned)((e.Fend - e.F0 + 255) / 256), (unsigned)nplanes);
     hipLaunchKernelGGL((ewise_k<1, OP>), grid, dim3(256), 0, ctx.stream, Z, X, Y, a, bcoef, e);
   }

@@ -26,9 +26,10 @@ hipStream_t stream();
 // compute stream (hard = 1); returns the reservation in force
 int reserve_comm_cus(int k, int hard = 0);
 int comm_cus_reserved();
-void triad_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, const int* sz, const int* idx, int g);
+void triad_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, const int* sz, const int* idx, int g, const CZ_REAL* a_dev = nullptr);
 void bicg1_async(CZ_REAL* p, const CZ_REAL* r, const CZ_REAL* q, CZ_REAL beta, CZ_REAL omg, const int* sz, const int* idx, int g);
-void bicg2_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, CZ_REAL b, const int* sz, const int* idx, int g);
+void bicg2_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, CZ_REAL a, CZ_REAL b, const int* sz, const int* idx, int g, const CZ_REAL* a_dev = nullptr,
+                 const CZ_REAL* b_dev = nullptr);
 void calc_ax_async(CZ_REAL* ap, const CZ_REAL* p, const int* sz, const int* idx, int g, const CZ_REAL* cf);
 void calc_rk_async(CZ_REAL* r, const CZ_REAL* p, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf);
 struct MafPtrs {
@@ -37,7 +38,14 @@ struct MafPtrs {
 void calc_ax_dots_async(CZ_REAL* ap, const CZ_REAL* p, const CZ_REAL* y, const int* sz, const int* idx, int g, const CZ_REAL* cf,
                         const MafPtrs* maf, double* dots_dev);
 void triad_dots_async(CZ_REAL* z, const CZ_REAL* x, const CZ_REAL* y, const CZ_REAL* w, CZ_REAL a, const int* sz, const int* idx, int g,
-                      double* dots_dev);
+                      double* dots_dev, const CZ_REAL* a_dev = nullptr);
+// BiCGSTAB's alpha (step 1) / omega (step 2) made on the device from the dot products of the launch before: sc_dev[0..3] = alpha, omega, -alpha,
+// -omega; the *_dev arguments of the updates above read them there, so the host does not wait for the dot products in mid-iteration
+void bicg_scalar_async(int step, const double* dots_dev, CZ_REAL rho, CZ_REAL* sc_dev);
+// czhip_jacobi2_from_zero_made_async with the coefficient a of the made right-hand side read from the device (a_dev, may be null)
+int pass_from_zero_made(const CZ_REAL* u_shape, CZ_REAL* w, CZ_REAL* b_out, int op, const CZ_REAL* x, const CZ_REAL* y, const CZ_REAL* z, CZ_REAL a,
+                        const CZ_REAL* a_dev, CZ_REAL bb, const int* sz, const int* idx, const int* idx1, int g, const CZ_REAL* cf, CZ_REAL omg,
+                        int rb_ofst, double* res_dev, int probe);
 void dot1_async(const CZ_REAL* p, const int* sz, const int* idx, int g, double* dst_dev);
 void dot2_async(const CZ_REAL* p, const CZ_REAL* q, const int* sz, const int* idx, int g, double* dst_dev);
 int pcr_num_stage(int n);

@@ -64,6 +64,10 @@ struct EGeom {
   // rows as R vectors from a vector boundary each; in memory a row is nkp elements and a plane PSE elements (Geom2, cz_k_pair.h)
   int nkp = 0;
   long long PSE = 0;
+  // scalars of the update kept on the device (BiCGSTAB's alpha / omega, made by bicg_scal_k from the dot products of the launch before):
+  // where set they replace the by-value arguments a / b of ewise_k and triad_dots_k -- the host need not read the dot products back first
+  const REAL* pa = nullptr;
+  const REAL* pb = nullptr;
 };
 // element offset of vector f of the row view inside a plane in memory
 template <int V>
@@ -77,6 +81,8 @@ __global__ void __launch_bounds__(256)
 ewise_k(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL b, EGeom g) {
   const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
   if (f >= g.Fend) return;
+  if (g.pa) a = *g.pa;
+  if (g.pb) b = *g.pb;
   const long long pe = (long long)(g.jj0 + blockIdx.y) * g.PSE + egeom_eo<V>(g, f);
   const int kv = (int)(f % g.R);
   unsigned mk = 0;
@@ -102,6 +108,23 @@ ewise_k(REAL* Z, const REAL* X, const REAL* Y, REAL a, REAL b, EGeom g) {
 #pragma unroll
     for (int cc = 0; cc < V; cc++)
       if (mk & (1u << cc)) Z[pe + cc] = o.v[cc];
+  }
+}
+
+// BiCGSTAB's scalars on the device (cz_Poisson.cpp:427, 464), from the dot products the launch before left in `dots` (all-reduced in a
+// decomposed run), with the host's own operations -- the double sums rounded to REAL, then one REAL division: the same bits as the host path.
+//   STEP 1: alpha = rho / (q . r0)              sc[0] = alpha, sc[2] = -alpha
+//   STEP 2: omega = (t . s) / (t . t)           sc[1] = omega, sc[3] = -omega
+template <int STEP>
+__global__ void bicg_scal_k(const double* __restrict__ dots, REAL rho, REAL* __restrict__ sc) {
+  if (STEP == 1) {
+    const REAL q_r0 = (REAL)dots[0];
+    const REAL alpha = rho / q_r0;
+    sc[0] = alpha, sc[2] = -alpha;
+  } else {
+    const REAL ts = (REAL)dots[0], tt = (REAL)dots[1];
+    const REAL omega = ts / tt;
+    sc[1] = omega, sc[3] = -omega;
   }
 }
 
@@ -198,6 +221,7 @@ triad_dots_k(REAL* Z, const REAL* X, const REAL* Y, const REAL* W, REAL a, EGeom
   __shared__ double wsum[4];
   __shared__ int last_flag;
   const long long f = g.F0 + (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g.pa) a = *g.pa;
   double acc1 = 0.0, acc2 = 0.0;
   if (f < g.Fend) {
     const int kv = (int)(f % g.R);

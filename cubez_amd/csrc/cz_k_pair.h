@@ -51,6 +51,7 @@ struct BSrc {
   const REAL* z = nullptr;
   REAL* out = nullptr;
   REAL a = 0, b = 0;
+  const REAL* pa = nullptr;  // where set: a is read from the device (bicg_scal_k)
 };
 
 struct Fin2 {

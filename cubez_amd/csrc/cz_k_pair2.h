@@ -239,6 +239,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
     const char* Ub = reinterpret_cast<const char*>(U);
     const char* Bb = reinterpret_cast<const char*>(B);
     char* Wb = reinterpret_cast<char*>(W);
+    const REAL bs_a = (BS && bs.pa) ? *bs.pa : bs.a;
     const char* SXb = reinterpret_cast<const char*>(bs.x);
     const char* SYb = reinterpret_cast<const char*>(bs.y);
     const char* SZb = reinterpret_cast<const char*>(bs.z);
@@ -296,8 +297,8 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
         for (int m = 0; m < MV; m++) {
 #pragma unroll
           for (int cc = 0; cc < V; cc++) {
-            if (BS == 1) b1[m].v[cc] = bs.a * rx[m].v[cc] + ry[m].v[cc];
-            if (BS == 2) b1[m].v[cc] = rx[m].v[cc] + bs.a * (rz[m].v[cc] - bs.b * ry[m].v[cc]);
+            if (BS == 1) b1[m].v[cc] = bs_a * rx[m].v[cc] + ry[m].v[cc];
+            if (BS == 2) b1[m].v[cc] = rx[m].v[cc] + bs_a * (rz[m].v[cc] - bs.b * ry[m].v[cc]);
           }
         }
         if (count1) {  // the planes of this chunk, the vectors of this segment: every point of the inner box has exactly one owner

@@ -431,6 +431,14 @@ int czhip_jacobi2_from_zero_async(const CZ_REAL* u_shape, CZ_REAL* w, const CZ_R
 int czhip_jacobi2_from_zero_made_async(const CZ_REAL* u_shape, CZ_REAL* w, CZ_REAL* b_out, int op, const CZ_REAL* x, const CZ_REAL* y,
                                        const CZ_REAL* z, CZ_REAL a, CZ_REAL bb, const int* sz, const int* idx, const int* idx1, int g,
                                        const CZ_REAL* cf, CZ_REAL omg, int rb_ofst, double* res_dev, int probe) {
+  return czhip_internal::pass_from_zero_made(u_shape, w, b_out, op, x, y, z, a, nullptr, bb, sz, idx, idx1, g, cf, omg, rb_ofst, res_dev, probe);
+}
+}  // extern "C"
+namespace czhip_internal {
+// (a_dev: the coefficient a read from the device instead, see BSrc::pa)
+int pass_from_zero_made(const CZ_REAL* u_shape, CZ_REAL* w, CZ_REAL* b_out, int op, const CZ_REAL* x, const CZ_REAL* y, const CZ_REAL* z, CZ_REAL a,
+                        const CZ_REAL* a_dev, CZ_REAL bb, const int* sz, const int* idx, const int* idx1, int g, const CZ_REAL* cf, CZ_REAL omg,
+                        int rb_ofst, double* res_dev, int probe) {
   ensure_init();
   if (!ctx.tune.fuse_fin || op < 0 || op > 2) return 0;
   if (op != 0 && (b_out == x || b_out == y || (op == 2 && b_out == z))) return 0;
@@ -440,13 +448,15 @@ int czhip_jacobi2_from_zero_made_async(const CZ_REAL* u_shape, CZ_REAL* w, CZ_RE
   Fin2 fin;
   fin.dst = res_dev;
   BSrc bs;
-  if (op != 0) bs.x = x, bs.y = y, bs.z = (op == 2) ? z : x, bs.out = b_out, bs.a = a, bs.b = bb;
+  if (op != 0) bs.x = x, bs.y = y, bs.z = (op == 2) ? z : x, bs.out = b_out, bs.a = a, bs.b = bb, bs.pa = a_dev;
   if (rb_ofst >= 0) {
     fin.single = 1;
     return launch_jacobi2<1>(u_shape, b_out, w, make_coef(cf, omg), bx, ba, nullptr, fin, rb_parity(g, idx, rb_ofst, 0), 1, probe != 0, nullptr, op ? &bs : nullptr, op) ? 1 : 0;
   }
   return launch_jacobi2<0>(u_shape, b_out, w, make_coef(cf, omg), bx, ba, nullptr, fin, 0, 1, probe != 0, nullptr, op ? &bs : nullptr, op) ? 1 : 0;
 }
+}  // namespace czhip_internal
+extern "C" {
 
 // One complete red-black SOR iteration (colour 0 then colour 1, cz_Poisson.cpp:205-209) in one pass over memory, u -> w.
 // res_dev[0] receives the iteration's sum dp^2 (both colours).  Same conventions as czhip_jacobi2_async.
@@ -1010,14 +1020,14 @@ int reserve_comm_cus(int k, int hard) {
   return k;
 }
 int comm_cus_reserved() { return ctx.cu_reserved; }
-void triad_async(REAL* z, const REAL* x, const REAL* y, REAL a, const int* sz, const int* idx, int g) {
-  launch_ewise<OP_TRIAD>(z, x, y, a, (REAL)0, make_box(sz, idx, g));
+void triad_async(REAL* z, const REAL* x, const REAL* y, REAL a, const int* sz, const int* idx, int g, const REAL* a_dev) {
+  launch_ewise<OP_TRIAD>(z, x, y, a, (REAL)0, make_box(sz, idx, g), a_dev);
 }
 void bicg1_async(REAL* p, const REAL* r, const REAL* q, REAL beta, REAL omg, const int* sz, const int* idx, int g) {
   launch_ewise<OP_BICG1>(p, r, q, beta, omg, make_box(sz, idx, g));
 }
-void bicg2_async(REAL* z, const REAL* x, const REAL* y, REAL a, REAL b, const int* sz, const int* idx, int g) {
-  launch_ewise<OP_BICG2>(z, x, y, a, b, make_box(sz, idx, g));
+void bicg2_async(REAL* z, const REAL* x, const REAL* y, REAL a, REAL b, const int* sz, const int* idx, int g, const REAL* a_dev, const REAL* b_dev) {
+  launch_ewise<OP_BICG2>(z, x, y, a, b, make_box(sz, idx, g), a_dev, b_dev);
 }
 void calc_ax_async(REAL* ap, const REAL* p, const int* sz, const int* idx, int g, const REAL* cf) {
   const Box bx = make_box(sz, idx, g);
@@ -1046,7 +1056,7 @@ void calc_ax_dots_async(REAL* ap, const REAL* p, const REAL* y, const int* sz, c
 }
 // z = a*x + y with dots_dev[0] = z.z, dots_dev[1] = z.w
 void triad_dots_async(REAL* z, const REAL* x, const REAL* y, const REAL* w, REAL a, const int* sz, const int* idx, int g,
-                      double* dots_dev) {
+                      double* dots_dev, const REAL* a_dev) {
   const Box b = make_box(sz, idx, g);
   if (b.empty) {
     HIP_CHECK(hipMemsetAsync(dots_dev, 0, 2 * sizeof(double), ctx.stream));
@@ -1056,6 +1066,7 @@ void triad_dots_async(REAL* z, const REAL* x, const REAL* y, const REAL* w, REAL
   ScopedTimer tm(LBL_EWISE);
   if (rows_ok(b, {z, x, y, w})) {
     EGeom e = make_egeom<VW>(b);
+    e.pa = a_dev;
     const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
     const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));
     ensure_partials((size_t)2 * gx * gy);
@@ -1063,12 +1074,19 @@ void triad_dots_async(REAL* z, const REAL* x, const REAL* y, const REAL* w, REAL
                        ctx.counter);
   } else {
     EGeom e = make_egeom<1>(b);
+    e.pa = a_dev;
     const unsigned gx = (unsigned)((e.Fend - e.F0 + 255) / 256);
     const unsigned gy = (unsigned)std::max(1, std::min(nplanes, (int)(4096 / gx)));
     ensure_partials((size_t)2 * gx * gy);
     hipLaunchKernelGGL((triad_dots_k<1>), dim3(gx, gy), dim3(256), 0, ctx.stream, z, x, y, w, a, e, nplanes, ctx.partials, dots_dev,
                        ctx.counter);
   }
+  HIP_CHECK(hipGetLastError());
+}
+// alpha (step 1) / omega (step 2) of BiCGSTAB from the dot products in dots_dev, into sc_dev[0..3] = alpha, omega, -alpha, -omega (bicg_scal_k)
+void bicg_scalar_async(int step, const double* dots_dev, REAL rho, REAL* sc_dev) {
+  if (step == 1) hipLaunchKernelGGL(bicg_scal_k<1>, dim3(1), dim3(1), 0, ctx.stream, dots_dev, rho, sc_dev);
+  else hipLaunchKernelGGL(bicg_scal_k<2>, dim3(1), dim3(1), 0, ctx.stream, dots_dev, rho, sc_dev);
   HIP_CHECK(hipGetLastError());
 }
 void dot1_async(const REAL* p, const int* sz, const int* idx, int g, double* dst_dev) {
