@@ -154,18 +154,17 @@ bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Pc
                  long long ncol) {
   int M = 0, tab_len = 0;
   if (!prep_pcr_reg_table<FINAL4>(g, &M, &tab_len)) return false;
-  const int v = ctx.tune.pcr_variant;
+  // ONE launch shape per (entries per lane, final systems, order), the measured one (profiles/r01/pcr_variants.txt at 512^3: FP32 8 waves x 2
+  // lines, FP64 and the longest lines 16 waves x 1 line; the lines of one diagonal: 4 waves).  Rounds 1-2 compiled four more shapes per case
+  // for CZHIP_PCR=2,variant -- 96 kernels per precision that nothing but that variable reached, 35 % of the library's code and build time.
 #define CZ_PCR_REG(M_)                                                                                                                \
   if (M == M_) {                                                                                                                      \
-    if (ORDER == 1) return try_pcr_reg_inst<M_, 4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
-    if (v == 161) return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
-    if (v == 81) return try_pcr_reg_inst<M_, 8, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);     \
-    if (v == 82) return try_pcr_reg_inst<M_, 8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);     \
-    if (v == 162) return try_pcr_reg_inst<M_, 16, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);   \
-    /* measured at 512^3 (profiles/r01/pcr_variants.txt): FP32 8 waves x 2 lines, FP64 16 waves x 1 line */                         \
-    if (sizeof(REAL) == 4 && M_ <= 8)                                                                                                 \
+    if constexpr (ORDER == 1)                                                                                                         \
+      return try_pcr_reg_inst<M_, 4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                \
+    else if constexpr (sizeof(REAL) == 4 && M_ <= 8)                                                                                  \
       return try_pcr_reg_inst<M_, 8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                \
-    return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                 \
+    else                                                                                                                              \
+      return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);               \
   }
   CZ_PCR_REG(2) CZ_PCR_REG(4) CZ_PCR_REG(8) CZ_PCR_REG(16)
 #undef CZ_PCR_REG
@@ -468,11 +467,7 @@ void launch_pcr_maf(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, con
 #define CZ_PCR_MAF(M_)                                                                 \
   if (M == M_) {                                                                       \
     if (order == 1) return go(pcr_line_reg_maf_k<M_, 1, 1, 1>, 1, 1);                   \
-    if (ctx.tune.pcr_variant == 161) return go(pcr_line_reg_maf_k<M_, 16, 1, 0>, 16, 1); \
-    if (ctx.tune.pcr_variant == 41) return go(pcr_line_reg_maf_k<M_, 4, 1, 0>, 4, 1);   \
-    if (ctx.tune.pcr_variant == 82) return go(pcr_line_reg_maf_k<M_, 8, 2, 0>, 8, 2);   \
-    if (ctx.tune.pcr_variant == 81) return go(pcr_line_reg_maf_k<M_, 8, 1, 0>, 8, 1);   \
-    /* measured at 512^3 FP32: 4 x 1 0.749 ms, 16 x 1 0.761, 8 x 1 0.885, 8 x 2 0.876 */  \
+    /* measured at 512^3 FP32: 4 x 1 0.749 ms, 16 x 1 0.761, 8 x 1 0.885, 8 x 2 0.876 (the other shapes are no longer compiled) */  \
     return go(pcr_line_reg_maf_k<M_, 4, 1, 0>, 4, 1);                                   \
   }
     CZ_PCR_MAF(2) CZ_PCR_MAF(4) CZ_PCR_MAF(8) CZ_PCR_MAF(16)

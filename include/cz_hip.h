@@ -246,8 +246,8 @@ int czhip_pair_maf_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const i
 int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int enable);
 /* line-SOR kernels (pcr*_): form 0 = one wave per line with the reference's arithmetic literally (a, c and d of the line reduced in LDS; every
  * variant but pcr_j_esa_; also the fall-back for lines whose coefficient table does not fit LDS), 1 = coefficient
- * table + right-hand side in LDS, 2 = table + right-hand side in registers (default); variant = waves*10 + lines per wave, 0 = default;
- * negative = keep.  All forms give the same bits. */
+ * table + right-hand side in LDS, 2 = table + right-hand side in registers (default); variant (form 1 only; form 2 has one measured shape per
+ * case since round 3) = waves*10 + lines per wave, 0 = default; negative = keep.  All forms give the same bits. */
 int czhip_set_pcr_mode(int form, int variant);
 /* the lexicographic line SOR (pcr_, pcr_esa_, pcr_eda_; reference: cz_solver.f90:666-878, one thread walking j, i): one_launch 1 = the whole
  * sweep in one launch, rows of lines handed from workgroup to workgroup (default), 0 = one launch per diagonal i+j; groups of threads per
