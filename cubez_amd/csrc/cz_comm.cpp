@@ -33,16 +33,13 @@
 #include <thread>
 #include <vector>
 
+#include "cz_config.h"
 #include "cz_internal.h"
 
-#define NCCL_CHECK(expr)                                                                              \
-  do {                                                                                                \
-    ncclResult_t r_ = (expr);                                                                         \
-    if (r_ != ncclSuccess) {                                                                          \
-      fprintf(stderr, "czhip: RCCL error %d (%s) at %s:%d: %s\n", (int)r_, ncclGetErrorString(r_), __FILE__, \
-              __LINE__, #expr);                                                                       \
-      exit(1);                                                                                        \
-    }                                                                                                 \
+#define NCCL_CHECK(expr)                                                                                                          \
+  do {                                                                                                                            \
+    ncclResult_t r_ = (expr);                                                                                                     \
+    if (r_ != ncclSuccess) cz_fatal(1, "czhip: RCCL error %d (%s) at %s:%d: %s\n", (int)r_, ncclGetErrorString(r_), __FILE__, __LINE__, #expr); \
   } while (0)
 
 namespace {
@@ -51,10 +48,10 @@ double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock
 
 // Seconds a collective may stay incomplete before the job is ended with a diagnostic: CZ_COMM_TIMEOUT, default 300 when CZ_COMM_DEBUG
 // is set (bench.py sets it for N > 1) and 120 for the LOCAL test transport, whose waits are host-side; 0 (or less) = wait for ever.
-double comm_timeout_s(bool local) {
-  if (const char* t = getenv("CZ_COMM_TIMEOUT")) return atof(t);
+double comm_timeout_s(const CzConfig& cfg, bool local) {
+  if (cfg.has(CZV_COMM_TIMEOUT)) return cfg.real(CZV_COMM_TIMEOUT, 0.0);
   if (local) return 120.0;
-  return getenv("CZ_COMM_DEBUG") ? 300.0 : 0.0;
+  return cfg.has(CZV_COMM_DEBUG) ? 300.0 : 0.0;
 }
 
 // ---- in-process world (LOCAL transport)
@@ -66,6 +63,7 @@ struct LocalWorld {
   long generation = 0;
   std::vector<CommCtx*> ranks;
   std::vector<double> red;
+  double wait_limit = 120.0;  // seconds a rank waits at a host-side barrier (comm_timeout_s at creation of the world)
   // every wait is bounded: ranks that issue different sequences of collectives (the failure of commit 24dd087's parent: bricks disagreeing
   // on the pass they run) end the process with the rank and the barrier number instead of blocking for ever
   void barrier(int rank = -1) {
@@ -76,14 +74,12 @@ struct LocalWorld {
       generation++;
       cv.notify_all();
     } else {
-      const double lim = comm_timeout_s(true);
+      const double lim = wait_limit;
       if (lim <= 0.0) {  // CZ_COMM_TIMEOUT=0: no bound
         cv.wait(lk, [&] { return generation != gen; });
       } else if (!cv.wait_for(lk, std::chrono::duration<double>(lim), [&] { return generation != gen; })) {
-        fprintf(stderr, "cz rank %d: LOCAL barrier #%ld: only %d of %d ranks arrived within %.0f s -- the ranks issue different collectives\n", rank,
+        cz_fatal_quick(3, "cz rank %d: LOCAL barrier #%ld: only %d of %d ranks arrived within %.0f s -- the ranks issue different collectives\n", rank,
                 gen, arrived, n, lim);
-        fflush(stderr);
-        _exit(3);
       }
     }
   }
@@ -109,9 +105,8 @@ struct Watch {
   std::thread th;
   std::atomic<bool> quit{false};
 
-  void start(int rank_, double limit_) {
-    rank = rank_, limit = limit_;
-    if (const char* d = getenv("CZ_COMM_DEBUG")) verbose = atoi(d);
+  void start(int rank_, double limit_, int verbose_) {
+    rank = rank_, limit = limit_, verbose = verbose_;
     if (limit <= 0.0) return;
     HIP_CHECK(hipGetDevice(&device));
     on = true;
@@ -146,10 +141,8 @@ struct Watch {
         q.pop_front();
       }
       if (!q.empty() && wall_s() - q.front().t > limit) {
-        fprintf(stderr, "cz rank %d: collective #%ld (%s) has not completed %.0f s after it was issued (last completed: #%ld, issued so far: #%ld) -- "
+        cz_fatal_quick(3, "cz rank %d: collective #%ld (%s) has not completed %.0f s after it was issued (last completed: #%ld, issued so far: #%ld) -- "
                         "the ranks are out of step or a peer is gone\n", rank, q.front().seq, q.front().what, limit, done, seq);
-        fflush(stderr);
-        _exit(3);
       }
     }
   }
@@ -295,6 +288,7 @@ struct CommCtx {
   ncclComm_t nccl = nullptr;      // halo exchanges
   ncclComm_t nccl_red = nullptr;  // all-reduces (== nccl when the job asked for one communicator)
   LocalWorld* world = nullptr;
+  CzConfig cfg;  // the environment as read when this communicator context was created (cz_config.h)
   double* h_red = nullptr;
   Pattern shallow, deep;   // depth 1 faces / depth 2 faces + edges
   const Pattern* cur = nullptr;  // LOCAL: pattern being exchanged (published for the neighbours)
@@ -392,7 +386,7 @@ void build_pattern(CommCtx* c, Pattern& p, int depth, bool edges) {
         const bool vec_rows = (nkp * c->eb) % 16 == 0;  // every padded k-row starts 16-byte aligned (hipMalloc'ed arrays)
         int kind = BOX_GENERIC;
         size_t cnt = (size_t)ext[0] * ext[1] * ext[2];
-        if (nz == 1 && dj != 0 && !getenv("CZ_COMM_PACK_J")) {
+        if (nz == 1 && dj != 0 && !c->cfg.has(CZV_COMM_PACK_J)) {
           kind = BOX_DIRECT;  // dep whole padded planes
           cnt = (size_t)dep * nkp * nip;
         } else if (nz == 1 && di != 0 && vec_rows) {
@@ -468,8 +462,7 @@ bool exchange(CommCtx* c, const Pattern& p, T* X, const int* skip, hipStream_t s
       for (int x = 0; x < q->nmsg; x++)
         if (q->dir[x][0] == -p.dir[m][0] && q->dir[x][1] == -p.dir[m][1] && q->dir[x][2] == -p.dir[m][2]) mm = x;
       if (mm < 0 || q->count[mm] != p.count[m] || q->peer[mm] != c->rank || q->direct[mm] != p.direct[m]) {
-        fprintf(stderr, "czhip: LOCAL transport: rank %d has no matching message from rank %d\n", c->rank, p.peer[m]);
-        exit(1);
+        cz_fatal(1, "czhip: LOCAL transport: rank %d has no matching message from rank %d\n", c->rank, p.peer[m]);
       }
       const T* src = q->direct[mm] ? (const T*)nb->cur_X + q->direct_send[mm] : (const T*)q->sendbuf + q->off[mm];
       T* dst = p.direct[m] ? X + p.direct_recv[m] : (T*)p.recvbuf + p.off[m];
@@ -493,6 +486,7 @@ CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], i
     return nullptr;
   }
   CommCtx* c = new CommCtx();
+  c->cfg = CzConfig::from_env();
   c->tr = boot.tr, c->rank = rank, c->nproc = nproc, c->eb = elem_bytes;
   c->nccl = boot.nccl, c->nccl_red = boot.nccl_red ? boot.nccl_red : boot.nccl, c->world = boot.world;
   for (int a = 0; a < 3; a++) c->size[a] = size[a], c->div[a] = div[a];
@@ -505,7 +499,7 @@ CommCtx* comm_create(int rank, int nproc, const int size[3], const int nID[6], i
     std::lock_guard<std::mutex> lk(c->world->mu);
     c->world->ranks[rank] = c;
   }
-  c->watch.start(rank, c->tr == T_RCCL ? comm_timeout_s(false) : 0.0);  // (the LOCAL transport bounds its own host-side waits)
+  c->watch.start(rank, c->tr == T_RCCL ? comm_timeout_s(c->cfg, false) : 0.0, c->cfg.num(CZV_COMM_DEBUG, 0));  // (the LOCAL transport bounds its own host-side waits)
   return c;
 }
 
@@ -615,8 +609,7 @@ int cz_comm_bootstrap(int rank, int nranks, const char* id_bytes) {
   // keeps RCCL from adding an order of its own between an exchange and an all-reduce that have nothing to do with each other.  Every rank
   // issues the operations of both communicators in the same program order (CZ::JACOBI / RBSOR / PBiCGSTAB), which is what concurrent
   // communicators need.  CZ_COMM_ONE_COMM=1 keeps everything on one communicator.
-  const char* one = getenv("CZ_COMM_ONE_COMM");
-  if (!(one && atoi(one) != 0)) {
+  if (!CzConfig::from_env().on(CZV_COMM_ONE_COMM, false)) {
     ncclComm_t red = nullptr;
     NCCL_CHECK(ncclCommSplit(comm, 0, rank, &red, nullptr));
     boot.nccl_red = red;
@@ -634,6 +627,7 @@ void cz_comm_shutdown(void) {
 void* cz_comm_local_world(int n) {
   LocalWorld* w = new LocalWorld();
   w->n = n;
+  w->wait_limit = comm_timeout_s(CzConfig::from_env(), true);
   w->ranks.assign(n, nullptr);
   w->red.assign((size_t)n * 16, 0.0);
   return w;

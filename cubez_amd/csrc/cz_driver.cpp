@@ -77,17 +77,15 @@ CZ::CZ() {
   HIP_CHECK(hipMemset(d_flag, 0, (2 + 2 * POLL_SLOTS) * sizeof(int)));
   HIP_CHECK(hipHostMalloc(&h_scal, 16 * sizeof(double), hipHostMallocDefault));
   HIP_CHECK(hipHostMalloc(&h_flag, 2 * POLL_SLOTS * sizeof(int), hipHostMallocDefault));
-  const char* ov = getenv("CZ_OVERLAP");
-  if (ov) overlap = atoi(ov);
-  if (const char* lg = getenv("CZ_LAG_REDUCE")) lag_reduce = atoi(lg);
-  if (const char* sk = getenv("CZ_TEST_SKEW")) sscanf(sk, "%d,%d", &skew_rank, &skew_ms);  // tests: "rank,milliseconds"
+  cfg = CzConfig::from_env();  // the environment as this driver was created in (cz_config.h); nothing below asks it again
+  overlap = cfg.num(CZV_OVERLAP, overlap);
+  lag_reduce = cfg.num(CZV_LAG_REDUCE, lag_reduce);
+  if (const char* sk = cfg.str(CZV_TEST_SKEW)) sscanf(sk, "%d,%d", &skew_rank, &skew_ms);  // tests: "rank,milliseconds"
 }
 
 CZ::~CZ() {
   czhip_sync();
-  // give the CUs reserved for the exchange stream back: the library context outlives this object, and a queue with a CU mask that is still
-  // alive at process exit crashed rocprofv3's finalisation (gpurun_out/probe_c, round 3)
-  if (comm_cus > 0) reserve_comm_cus(0, 0);
+  if (comm_cus > 0) reserve_comm_cus(0);  // the library context outlives this object
   REAL_TYPE* arrs[] = {WRK, WRK2, P, RHS, pcg_p, pcg_p_, pcg_r, pcg_r0, pcg_q, pcg_s, pcg_s_, pcg_t_, pvt, MSK};
   if (d_xc) (void)hipFree(d_xc);
   if (d_yc) (void)hipFree(d_yc);
@@ -326,7 +324,7 @@ int CZ::Setup(int argc, char** argv) {
     // (the MAF flavour of the pass needs a little more LDS -- the table of the k metric terms -- and is probed as well where it will run)
     const double mine = (pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE, cf[6], 0) && (!SW_maf || pair_probe(P, WRK, RHS, size, innerFidx, idx1, GUIDE, cf[6], 1))) ? 0.0 : 1.0;
     pairs_ok = comm_allreduce_max_host(comm, mine) == 0.0;
-    if (getenv("CZ_COMM_DEBUG")) {  // one line per rank on stderr: what a multi-GPU run decided
+    if (cfg.has(CZV_COMM_DEBUG)) {  // one line per rank on stderr: what a multi-GPU run decided
       int dev = -1;
       (void)hipGetDevice(&dev);
       fprintf(stderr,
@@ -334,6 +332,11 @@ int CZ::Setup(int argc, char** argv) {
               "lagged_reduce=%d comm_cus_per_xcd=%d\n",
               myRank, numProc, dev, G_div[0], G_div[1], G_div[2], size[0], size[1], size[2], head[0], head[1], head[2], nID[0], nID[1], nID[2],
               nID[3], nID[4], nID[5], (int)pairs_ok, n_shell, overlap, lag_reduce, comm_cus);
+      if (myRank == 0) {  // the switches in force (cz_config.h), once per job
+        std::string sw = cfg.describe(true);
+        for (char& ch : sw) if (ch == '\n') ch = ' ';
+        fprintf(stderr, "cz config: %s\n", sw.c_str());
+      }
     }
   }
   const bool bicg = ls_type == LS_BICGSTAB || ls_type == LS_BICGSTAB_MAF;
@@ -479,8 +482,7 @@ int CZ::Evaluate(int argc, char** argv) {
   if (debug_mode == 1) {  // :550-563
     int loc[3];
     // fileout_t_ has a body only in the reference's -D_aurora_=1 build (cz_utility.f90:33-44); here CZ_SPH=1 asks for the files
-    const char* sph = getenv("CZ_SPH");
-    const bool dump = sph && atoi(sph) != 0;
+    const bool dump = cfg.on(CZV_SPH, false);
     char fname[32];
     if (dump) {
       snprintf(fname, sizeof(fname), "p_%05d.sph", myRank);  // :553-554
@@ -572,15 +574,12 @@ void CZ::plan_overlap() {
   if (numProc > 1 && overlap) n_shell = pair_plan(innerFidx, nID, shell_boxes, interior, interior1);
   // CUs per XCD the sweeps leave to the exchange stream while an interior launch fills the chip (RCCL's send/recv kernels need CUs of their
   // own for as long as a message is in flight; reserve_comm_cus, cz_kernels.hip): CZ_COMM_CUS, default 2, through the launch geometry --
-  // at 512^3 FP32 the interior launch of the two-stage pass uses 30 of an XCD's 32 CUs anyway; CZ_COMM_CUS_MASK=1 enforces it with a CU
-  // mask instead (1.8x slower sweeps where the launch fills the remaining CUs in one round: profiles/r03/cu_reserve_cost.txt).  Every rank
+  // at 512^3 FP32 the interior launch of the two-stage pass uses 30 of an XCD's 32 CUs anyway (profiles/r03/cu_reserve_cost.txt).  Every rank
   // reserves alike (argv and environment are the job's), also a brick without a rank-internal face: the launch geometry depends on it.
   if (numProc > 1 && overlap) {
-    const char* cc = getenv("CZ_COMM_CUS");
-    const char* cm = getenv("CZ_COMM_CUS_MASK");
-    comm_cus = reserve_comm_cus(cc ? atoi(cc) : 2, (cm && atoi(cm) != 0) ? 1 : 0);
+    comm_cus = reserve_comm_cus(cfg.num(CZV_COMM_CUS, 2));
   } else {
-    reserve_comm_cus(0, 0);
+    reserve_comm_cus(0);
   }
   if (n_shell == 0) return;
   if (!comm_stream) {
@@ -619,8 +618,7 @@ bool CZ::pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int
   if (!comm_halo2(comm, dst, skip, comm_stream)) return false;
   HIP_CHECK(hipEventRecord(ev_comm, comm_stream));
   if (!pair_box_async(src, dst, B, size, interior, interior1, gc, cf, ac1, rb, rs, 0, skip, maf)) {
-    printf("error : interior launch refused after a successful probe\n");
-    exit(1);
+    cz_fatal(1, "error : interior launch refused after a successful probe\n");
   }
   HIP_CHECK(hipStreamWaitEvent(st, ev_comm, 0));
   pair_shell_fold_async(rs, rb >= 0 ? 1 : 0, skip, st);  // (behind ev_comm: the slabs have finished)
@@ -674,7 +672,7 @@ bool CZ::sweep_failed(const char* solver) {
 // What the ranks of a decomposed run must agree on is the sequence of collectives: the exchange depth (SINGLE against the fused kinds --
 // `pairs_ok`, all-reduced at set-up) and the iteration at which they stop (the poll below).  WHOLE against SPLIT and lag against no lag may
 // differ from brick to brick (a brick too thin to split): the same exchanges and all-reduces in the same order either way.
-CZ::PassPlan CZ::plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, bool converge_check, bool x_is_zero, bool rb) {
+CZ::PassPlan CZ::plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, bool converge_check, bool x_is_zero, bool rb, bool probe_only) {
   PassPlan p;
   p.maf = (s_type == LS_JACOBI_MAF || s_type == LS_SOR2SMA_MAF) ? 1 : 0;
   p.rb = rb ? 1 : 0;
@@ -685,8 +683,7 @@ CZ::PassPlan CZ::plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, 
   if (fused) {
     const bool mine = pair_probe(X, WRK, B, size, innerFidx, idx1, GUIDE, cf[6], p.maf) != 0;
     if (numProc > 1 && pairs_ok && !mine) {  // (pairs_ok was probed on P / WRK / RHS: same geometry, same alignment)
-      fprintf(stderr, "cz rank %d: the fused pass the ranks agreed on at set-up is refused for this solve\n", myRank);
-      exit(1);
+      cz_fatal(1, "cz rank %d: the fused pass the ranks agreed on at set-up is refused for this solve\n", myRank);
     }
     fused = numProc > 1 ? pairs_ok : mine;
   }
@@ -697,7 +694,8 @@ CZ::PassPlan CZ::plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, 
     p.buffers = p.lag ? 3 : 2;
     p.zero_start = (x_is_zero && numProc == 1 && !converge_check && !p.maf && (rb || itr_max >= 2)) ? 1 : 0;
   }
-  if (getenv("CZ_COMM_DEBUG") && numProc > 1 && (p.kind != last_plan.kind || p.lag != last_plan.lag || p.maf != last_plan.maf || p.rb != last_plan.rb || !plan_printed)) {
+  if (probe_only) return p;  // a question (bicg_fusable), not a solve: cz_info 7..9 and the debug line keep describing solves that ran
+  if (cfg.has(CZV_COMM_DEBUG) && numProc > 1 && (p.kind != last_plan.kind || p.lag != last_plan.lag || p.maf != last_plan.maf || p.rb != last_plan.rb || !plan_printed)) {
     static const char* const kinds[] = {"single sweeps", "fused pass, whole box", "fused pass, shell + interior (exchange overlapped)"};
     fprintf(stderr, "cz rank %d: %s plan: %s, exchange depth %d, lagged reduce %d, buffers %d, zero start %d, maf %d, comm CUs per XCD %d\n", myRank,
             rb ? "RBSOR" : "JACOBI", kinds[p.kind], p.depth, p.lag, p.buffers, p.zero_start, p.maf, p.comm_cus);
@@ -715,8 +713,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
   hipStream_t st = stream();
   const PassPlan plan = plan_pass(X, B, s_type, itr_max, converge_check, x_is_zero, false);
   if (made && !(plan.kind == PassPlan::WHOLE && plan.zero_start)) {  // (bicg_fusable asked the same questions before the update was withheld)
-    printf("error : the solve that was to make its right-hand side does not start with a whole fused pass from zero\n");
-    exit(1);
+    cz_fatal(1, "error : the solve that was to make its right-hand side does not start with a whole fused pass from zero\n");
   }
   const bool maf = plan.maf != 0;  // cz_Poisson.cpp:45-53
   const MafPtrs mp{d_xc, d_yc, d_zc, nullptr};
@@ -805,8 +802,7 @@ int CZ::JACOBI(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, doubl
         launched = czhip_jacobi2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ac1, d_res, res_normal, eps, itr,
                                        in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :58 + :67-77, twice
       if (!launched) {
-        printf("error : fused pass refused after a successful probe\n");
-        exit(1);
+        cz_fatal(1, "error : fused pass refused after a successful probe\n");
       }
       if (numProc > 1) {
         if (!Comm_S2(dst, skip)) return 0;  // :63, two layers once per pair
@@ -915,8 +911,7 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   hipStream_t st = stream();
   const PassPlan plan = plan_pass(X, B, s_type, itr_max, converge_check, x_is_zero, true);
   if (made && !(plan.kind == PassPlan::WHOLE && plan.zero_start)) {  // (see CZ::JACOBI)
-    printf("error : the solve that was to make its right-hand side does not start with a whole fused pass from zero\n");
-    exit(1);
+    cz_fatal(1, "error : the solve that was to make its right-hand side does not start with a whole fused pass from zero\n");
   }
   if (x_is_zero && !plan.zero_start) {  // the caller skipped its blas_clear_ and this solve does not take the zero as a literal: clear now
     const size_t nb = (size_t)(size[0] + 2 * gc) * (size[1] + 2 * gc) * (size[2] + 2 * gc) * sizeof(REAL_TYPE);
@@ -991,8 +986,7 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
                                : czhip_rbsor2_async(src, dst, B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res, res_normal, eps, itr,
                                                     in_kernel_check ? d_hist : nullptr, d_flag, d_flag + 1, skip);  // :205-209 (+ :218-230)
       if (!launched) {
-        printf("error : fused red-black iteration refused after a successful probe\n");
-        exit(1);
+        cz_fatal(1, "error : fused red-black iteration refused after a successful probe\n");
       }
       if (numProc > 1) {
         if (!Comm_S2(dst, skip)) return 0;  // :215
@@ -1302,11 +1296,10 @@ bool CZ::xx_shell_is_zero(const REAL_TYPE* xx) const { return xx == pcg_p_ || xx
 // make them (jacobi2p_k<BS>)?  Plain Jacobi or red-black SOR preconditioner on the whole-box fused pass with the literal zero start, one rank (a decomposed
 // solve reads the right-hand side in its ghost layer, where the operands are not valid), and the launcher takes it.  CZ_BICG_FUSE=0: never.
 bool CZ::bicg_fusable(int pc_type) {
-  const char* e = getenv("CZ_BICG_FUSE");
-  if (e && atoi(e) == 0) return false;
+  if (!cfg.on(CZV_BICG_FUSE, true)) return false;
   if ((pc_type != LS_JACOBI && pc_type != LS_SOR2SMA) || numProc != 1 || czhip_use_t2() == 0) return false;
   const bool rb = pc_type == LS_SOR2SMA;
-  const PassPlan plan = plan_pass(pcg_p_, pcg_p, pc_type, 8, false, true, rb);
+  const PassPlan plan = plan_pass(pcg_p_, pcg_p, pc_type, 8, false, true, rb, true);
   if (!(plan.kind == PassPlan::WHOLE && plan.zero_start)) return false;
   int idx1[6];
   for (int f = 0; f < 6; f++) idx1[f] = innerFidx[f];
@@ -1399,13 +1392,9 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
   const bool fuse = !maf && bicg_fusable(pc_type);
   bicg_fused = 0;
   // alpha / omega on the device between their dot products and their users (bicg_scalar_async): d_res[12..15] holds alpha, omega, -alpha, -omega
-  // as REALs.  CZ_BICG_FUSE=0: the host computes them from read-back dot products as in rounds 1-2 (and as the reference does).
+  // as REALs.  CZ_BICG_DEVSC=0: the host computes them from read-back dot products as in rounds 1-2 (and as the reference does).
   REAL_TYPE* const d_bs = reinterpret_cast<REAL_TYPE*>(d_res + 12);
-  bool devsc = true;
-  {
-    const char* e = getenv("CZ_BICG_FUSE");
-    if (e && atoi(e) == 0) devsc = false;
-  }
+  const bool devsc = cfg.on(CZV_BICG_DEVSC, true);
   bool pc_copy;  // Preconditioner() has no case for pc_type: it copies (cz_Poisson.cpp:282-321)
   switch (pc_type) {
     case LS_JACOBI: case LS_JACOBI_MAF: case LS_SOR2SMA: case LS_SOR2SMA_MAF: case LS_PCR_RB: case LS_PSOR: case LS_PSOR_MAF: case LS_PCR:
@@ -1415,10 +1404,7 @@ int CZ::PBiCGSTAB(double& res, REAL_TYPE* X, REAL_TYPE* B, double& flop, int s_t
     default:
       pc_copy = true;
   }
-  {
-    const char* e = getenv("CZ_BICG_FUSE");
-    if (e && atoi(e) == 0) pc_copy = false;  // (the copy is made: A/B and the bit-equality test)
-  }
+  if (!cfg.on(CZV_BICG_ALIAS, true)) pc_copy = false;  // (the copy is made: A/B and the bit-equality test)
 
   for (itr = 1; itr < ItrMax; itr++) {  // :373
     REAL_TYPE rho;

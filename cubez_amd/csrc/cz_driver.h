@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 
+#include "cz_config.h"
 #include "cz_internal.h"
 
 typedef CZ_REAL REAL_TYPE;  // cz_Define.h:28-37
@@ -71,6 +72,7 @@ class CZ {
   int bicg_fused = 0;            // vector updates of the last BiCGSTAB solve that were made inside the first pair of a preconditioner solve (cz_info 10)
   bool in_precond = false;       // inside Preconditioner: an unchecked solve does not drain the queue (the caller's next launch follows in stream order)
   int last_lag = 0;              // the last stationary solve ran its all-reduce + test one pass behind (cz_info)
+  CzConfig cfg;  // the environment as read when this object was created (cz_config.h)
   int skew_rank = -1, skew_ms = 0;  // CZ_TEST_SKEW=rank,ms: that rank sleeps before each look at the convergence flag (tests)
   void skew_wait() const;
   int lag_reduce = 1;            // CZ_LAG_REDUCE=0: residual all-reduce + test on the compute stream after every pass (no lag)
@@ -157,7 +159,7 @@ class CZ {
   void plan_overlap();
   bool pair_overlapped(REAL_TYPE* src, REAL_TYPE* dst, REAL_TYPE* B, const int* idx1, int rb, const int* skip, double* res_slot = nullptr,
                        const czhip_internal::MafPtrs* maf = nullptr);
-  PassPlan plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, bool converge_check, bool x_is_zero, bool rb);
+  PassPlan plan_pass(REAL_TYPE* X, REAL_TYPE* B, int s_type, int itr_max, bool converge_check, bool x_is_zero, bool rb, bool probe_only = false);
   bool Comm_SUM_1(double* host_val);
 
   int finish_stationary(int itr_max, int first_itr, bool converge_check, double& res);

@@ -18,6 +18,7 @@ struct Tuning {
                                          // workgroups per CU of the former (0: four); CZHIP_PSOR=one_launch[,wg_per_cu], czhip_set_psor
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
                                               // the balance model (pair_tj_model, cz_h_launch.h); CZHIP_T2=enable,threads,2,tj fixes them
+  int t2_kwin = -1;                               // two-stage pass: vectors per k window; -1 = chosen per launch, 0 = whole rows where they fit (CZHIP_T2_KWIN)
   int t2_map = 1;                                 // two-stage pass: equal shares of (segment, chunk) items per XCD (CZHIP_T2_MAP=0: whole-segment bands)
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };
@@ -34,6 +35,7 @@ struct Ctx {
   size_t pipe_ctl_cap = 0;
   unsigned long long* pipe_hb = nullptr;  // pcr_lex_wg_k: hand-off lines between strips ({sequence number | value} words)
   size_t pipe_hb_cap = 0;
+  std::string pipe_prof_file;    // CZHIP_PCR_PIPE_PROF (development aid, -DCZ_LEX_PROF builds)
   unsigned pipe_seq = 0;         // sequence numbers handed out so far (monotonic: a stale word never matches)
   REAL* pcr_tab = nullptr;      // pcr_coef_k's table for lines of pcr_tab_n unknowns (pcr_tab_pn stages)
   int pcr_tab_n = 0, pcr_tab_pn = 0, pcr_tab_final4 = -1;
@@ -58,10 +60,8 @@ struct Ctx {
   std::map<std::vector<double>, REAL*> bc_tabs;  // key: ix, jx, dh, org0, org1
   struct PairMap { int* dev = nullptr; long long nblk = 0; };
   std::map<long long, PairMap> pair_maps;        // workgroup id -> (segment, chunk) tables of the two-stage pass, key nseg << 32 | nchunk
-  int num_cu = 256;             // CUs the compute stream may use (= num_cu_total - 8 * cu_reserved)
-  int num_cu_total = 256;
-  int cu_reserved = 0;          // CUs per XCD the sweeps leave to the exchange stream (decomposed runs; reserve_comm_cus)
-  bool cu_masked = false;       // ... enforced by a CU mask on the compute stream's queue (hard form) instead of by the launch geometry
+  int num_cu = 256;
+  int cu_reserved = 0;          // CUs per XCD the sweeps leave to the exchange stream (decomposed runs; reserve_comm_cus): the launch geometry counts them out
   // optional per-launch HIP-event timing of the labelled kernels (bench.py roofline leg)
   bool timing = false;
   struct Ev { hipEvent_t a, b; int label; };
@@ -144,9 +144,8 @@ Box make_box(const int* sz, const int* idx, int g) {
   b.empty = b.ii1 < b.ii0 || b.jj1 < b.jj0 || b.kk1 < b.kk0;
   // the 7-point stencil reads one layer around the box: it must exist inside the padded array
   if (!b.empty && (g < 1 || b.ii0 < 1 || b.jj0 < 1 || b.kk0 < 1 || b.ii1 > b.nip - 2 || b.jj1 > b.njp - 2 || b.kk1 > b.nkp - 2)) {
-    fprintf(stderr, "czhip: index range (%d..%d, %d..%d, %d..%d) does not fit sz=(%d,%d,%d) g=%d\n", idx[0], idx[1], idx[2],
+    cz_fatal(1, "czhip: index range (%d..%d, %d..%d, %d..%d) does not fit sz=(%d,%d,%d) g=%d\n", idx[0], idx[1], idx[2],
             idx[3], idx[4], idx[5], sz[0], sz[1], sz[2], g);
-    exit(1);
   }
   return b;
 }

@@ -37,8 +37,7 @@ void launch_stencil_inst(const REAL* P, const REAL* B, REAL* OUT, const Coef& c,
   const long long nblk = (long long)nchunk * g.nseg;
   const size_t lds = (size_t)2 * (g.S + 2 * g.R) * sizeof(Vec<V>) + 18 * sizeof(double);
   if (lds > 160 * 1024) {
-    fprintf(stderr, "czhip: k-row of %d elements needs %zu bytes of LDS (>160 KiB)\n", b.nkp, lds);
-    exit(1);
+    cz_fatal(1, "czhip: k-row of %d elements needs %zu bytes of LDS (>160 KiB)\n", b.nkp, lds);
   }
   if (MODE == MODE_JACOBI || MODE == MODE_RB || MODE == MODE_AX) ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
@@ -83,8 +82,7 @@ template <int MODE>
 void launch_stencil_maf(const REAL* P, const REAL* B, REAL* OUT, REAL omg, const Box& b, int par, const int* skip, int* nblk_out,
                         const Fin& fin, const MafArgs& ma) {
   if (b.g != 2) {
-    fprintf(stderr, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2), cz_maf.f90:146-148)\n");
-    exit(1);
+    cz_fatal(1, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2), cz_maf.f90:146-148)\n");
   }
   Coef c;
   c.c1 = c.c2 = c.c3 = c.c4 = c.c5 = c.c6 = c.dd = (REAL)0;
@@ -107,9 +105,8 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 // ceil(band * nchunk / slots) rounds of that (tools/pair_lab sweeps, profiles/r02/pair_lab_sweep_*.txt: the model ranks the measured
 // times of both shapes and both precisions).  Returns the cost in units of plane steps; *tj_out the best chunk length.
 inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, bool balanced, int* tj_out) {
-  // (decomposed runs: cu_reserved CUs of every XCD stay free for the exchange stream -- by this count unless a CU mask enforces it, in which
-  // case num_cu is already the smaller number; reserve_comm_cus)
-  const int slots = std::max(1, ctx.num_cu / 8 - (ctx.cu_masked ? 0 : ctx.cu_reserved)) * wg_per_cu;
+  // (decomposed runs: cu_reserved CUs of every XCD stay free for the exchange stream; reserve_comm_cus)
+  const int slots = std::max(1, ctx.num_cu / 8 - ctx.cu_reserved) * wg_per_cu;
   double best = 1e300;
   int best_tj = std::min(16, nplanes);
   // (chunks from two planes up: on small grids, where one round of short chunks holds every item, the chain of plane steps of a workgroup is
@@ -282,8 +279,7 @@ void launch_pair_shell(const REAL* U, const REAL* B, REAL* W, const Coef& c, con
   for (int m = 0; m < n; m++) {
     const Box b = make_box(sz, boxes + 6 * m, g);
     if (b.empty || b.ii0 < 2 || b.jj0 < 2 || b.kk0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3 || b.kk1 > b.nkp - 3) {
-      fprintf(stderr, "czhip: pair_shell: box %d is empty or closer than two cells to the array edge\n", m);
-      exit(1);
+      cz_fatal(1, "czhip: pair_shell: box %d is empty or closer than two cells to the array edge\n", m);
     }
     ShellBox& d = s.b[m];
     d.i0 = b.ii0, d.j0 = b.jj0, d.k0 = b.kk0;

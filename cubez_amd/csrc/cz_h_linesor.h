@@ -244,7 +244,7 @@ bool try_pcr_lex_wg_inst(REAL* x, const REAL* msk, const REAL* rhs, const PcrGeo
   ScopedTimer tm(LBL_PCR);
   HIP_CHECK(hipMemsetAsync(ctx.pipe_ctl, 0, ctl_words * sizeof(unsigned), ctx.stream));
   long long* prof = nullptr;
-  static const char* prof_env = kLexProf ? getenv("CZHIP_PCR_PIPE_PROF") : nullptr;  // development aid (build with -DCZ_LEX_PROF): when each strip started / ended and how long it waited
+  const char* prof_env = (kLexProf && !ctx.pipe_prof_file.empty()) ? ctx.pipe_prof_file.c_str() : nullptr;  // development aid (build with -DCZ_LEX_PROF): when each strip started / ended and how long it waited
   if (prof_env) {
     HIP_CHECK(hipMalloc(&prof, (size_t)8 * nstrips * sizeof(long long)));
     HIP_CHECK(hipMemsetAsync(prof, 0, (size_t)8 * nstrips * sizeof(long long), ctx.stream));
@@ -410,8 +410,7 @@ void launch_pcr_variant(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, c
     if (!ok) ok = literal(g, accumulate);
   }
   if (!ok) {
-    fprintf(stderr, "czhip: line SOR: no kernel form took a k-line of %d unknowns (pn = %d)\n", b.kk1 - b.kk0 + 1, pn);
-    exit(1);
+    cz_fatal(1, "czhip: line SOR: no kernel form took a k-line of %d unknowns (pn = %d)\n", b.kk1 - b.kk0 + 1, pn);
   }
 }
 
@@ -435,8 +434,7 @@ void launch_pcr_rb(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, cons
   if (try_pcr_rb<2>(x, msk, rhs, g, omg, res_dev, accumulate, 80 * 1024)) return;
   if (try_pcr_rb<1>(x, msk, rhs, g, omg, res_dev, accumulate, 160 * 1024)) return;
   if (try_pcr_rb<4, 0, 0, 0, 1>(x, msk, rhs, g, omg, res_dev, accumulate, 0)) return;  // work arrays in global scratch: any length
-  fprintf(stderr, "czhip: pcr_rb: no kernel form took a k-line of %d unknowns\n", g.n);
-  exit(1);
+  cz_fatal(1, "czhip: pcr_rb: no kernel form took a k-line of %d unknowns\n", g.n);
 }
 
 // the MAF line solvers (pcr_rb_maf, pcr_maf and their _eda / _esa forms): literal kernel, order 0 = colour `sel`, 1 = lexicographic
@@ -490,8 +488,7 @@ void launch_pcr_maf(REAL* x, const REAL* msk, const REAL* rhs, const Box& b, con
     ok = one(make_pcr_geom(b, idx, pn, sel), accumulate);
   }
   if (!ok) {
-    fprintf(stderr, "czhip: pcr_*_maf: a k-line of %d unknowns does not fit the 160 KiB of LDS\n", b.kk1 - b.kk0 + 1);
-    exit(1);
+    cz_fatal(1, "czhip: pcr_*_maf: a k-line of %d unknowns does not fit the 160 KiB of LDS\n", b.kk1 - b.kk0 + 1);
   }
 }
 
@@ -503,11 +500,12 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
   g.kk0 = bx.kk0, g.nk = bx.kk1 - bx.kk0 + 1, g.ii0 = bx.ii0, g.ii1 = bx.ii1, g.jj0 = bx.jj0, g.jj1 = bx.jj1;
   g.nti = (bx.ii1 - bx.ii0 + PC_T) / PC_T, g.ntj = (bx.jj1 - bx.jj0 + PC_T) / PC_T;
   g.face_words = (long long)(g.nk + PC_T) * PC_T * kPsorColHW;
-  // the line streams read runs that start up to 2 (PC_T - 1) + 2 elements in front of a line and end up to 2 (PC_T - 1) + 48 behind it, on the
+  // the line streams read runs that start up to 2 (PC_T - 1) + 2 elements in front of a line and end up to 2 (PC_T - 1) + 2 NS behind it (the
+  // last prefetch of a thread with i + j = 0: element G (ngroups - 1) + NS + G - 1 <= nk + 2 (PC_T - 1) + 2 NS - 1, psor_col_k), on the
   // lines ii0-1 .. ii1+1 x jj0-1 .. jj1+1: all of it must lie inside the padded array
   const long long plane = (long long)bx.nkp * bx.nip, total = plane * bx.njp;
   const long long lo = (long long)bx.kk0 + (long long)(bx.ii0 - 1) * bx.nkp + (long long)(bx.jj0 - 1) * plane - (2 * (PC_T - 1) + 4);
-  const long long hi = (long long)bx.kk0 + (long long)(bx.ii1 + 1) * bx.nkp + (long long)(bx.jj1 + 1) * plane + g.nk + 2 * (PC_T - 1) + 48;
+  const long long hi = (long long)bx.kk0 + (long long)(bx.ii1 + 1) * bx.nkp + (long long)(bx.jj1 + 1) * plane + g.nk + 2 * (PC_T - 1) + 2 * kPsorNS;
   if (bx.ii0 < 1 || bx.jj0 < 1 || bx.kk0 < 1 || lo < 0 || hi >= total) return false;
   const int ncols = g.nti * g.ntj;
   constexpr int NC = 1;  // (two columns per workgroup were measured: one barrier for ten waves makes every step twice as long -- profiles/r03)

@@ -29,6 +29,10 @@
 constexpr int PC_T = 16;               // a column is PC_T x PC_T points of the (i, j) plane
 constexpr int PC_L = PC_T + 2;         // LDS row: i = -1 .. PC_T
 constexpr int kPsorColHW = sizeof(REAL) == 8 ? 2 : 1;  // hand-off words per value
+// steps per group (one run of G elements per line stream and group) and steps per loop body of psor_col_k; the launcher's read-extent guard
+// (try_psor_col) is derived from the same constants
+constexpr int kPsorG = sizeof(REAL) == 4 ? 8 : 4;
+constexpr int kPsorNG = 4, kPsorNS = kPsorNG * kPsorG;
 
 struct PsorColGeom {
   int nkp, nip, njp;
@@ -66,10 +70,10 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
   // steps per group: one run of G elements per stream and group.  FP32: 32-byte runs (two 16-byte loads back to back) -- a CU sustains only so
   // many line requests in flight, and with 16-byte runs every one of them fetched a line for 16 bytes: 1.42 -> 1.23 ms per 512^3 sweep
   // (profiles/r03/psor_one_launch_vs_tile_hyperplanes.txt); FP64 stays at 16 elements per loop body = one line (the flush period)
-  constexpr int G = sizeof(REAL) == 4 ? 8 : 4;
+  constexpr int G = kPsorG;
   constexpr int NCW = 4 * NC;                       // computing waves
   constexpr int HW = kPsorColHW;
-  constexpr int NG = 4, NS = NG * G;  // the loop bodies cover NG groups: register rings with compile-time indices
+  constexpr int NG = kPsorNG, NS = kPsorNS;  // the loop bodies cover NG groups: register rings with compile-time indices
   static_assert(NS <= 128 / (int)sizeof(REAL), "a loop body must not outrun the two-line output ring");
   __shared__ REAL sNEW[NC][2][PC_L * PC_L], sOLD[NC][2][PC_L * PC_L];
   // The new values go back to memory as WHOLE 128-byte lines: written 16 bytes at a time as they are produced, a line left the XCD's L2 before
@@ -247,7 +251,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
         }
         // ---- the lines completed in this loop body (NS steps <= EL: at most one per thread, two entries of the ring are never in doubt)
         flush_lines(G * (sg + NG) - 1 - i - j, false);
-        if (sh[2] != 0) break;  // a wait was given up (written before a barrier every thread has passed)
+        if (sh[2] != 0) break;  // a wait was given up (published by the taking wave before the LAST barrier of this body, see there)
       }
       flush_lines(g.nk - 1, true);  // what is left: the last, incomplete line
     } else if (wv == NCW) {
@@ -299,6 +303,10 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       const int hk0 = -hi - hj;  // = 1 - hc: the virtual thread's k at step 0
       unsigned long long rq[8][HW];
       REAL bq[8];
+      // A given-up wait is a private matter of this wave until the last step of the loop body it happened in: sh[2] is written only in front
+      // of that step's barrier, so every wave of the workgroup reads the same value behind it (written in mid-body, waves that had passed
+      // the body's last barrier but not yet looked could disagree with those that had, and the barrier counts would part -- ADVICE r3).
+      bool gave_up = false;
       auto ask = [&](int slot, int s) __attribute__((always_inline)) {  // what step s publishes: row hk(s) + hc of the face / element hk(s) of the line
         const int hk = s + hk0;
         const int r = min(max(hk + hc, 0), nrows - 1);
@@ -313,7 +321,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
         bool ok = true;
 #pragma unroll
         for (int w = 0; w < HW; w++) ok = ok && (unsigned)(rq[slot][w] >> 32) == seq;
-        if (need && !ok) {
+        if (need && !ok && !gave_up) {
           const unsigned long long* q = rin + ((size_t)(hk + hc) * PC_T + hc) * HW;
           do {
 #pragma unroll
@@ -322,7 +330,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
 #pragma unroll
             for (int w = 0; w < HW; w++) ok = ok && (unsigned)(rq[slot][w] >> 32) == seq;
             if (!ok && pipe_give_up(polls, t0, spin_limit, ctl)) {
-              sh[2] = 1;
+              gave_up = true;  // (the rest of this body runs on whatever the words hold: the sweep is void, its residual NaN)
               break;
             }
           } while (!ok);
@@ -342,6 +350,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           take((m & 1) ^ 1, m, s0 + m);
+          if (m == 7 && (s0 & (NS - 1)) == NS - 8 && __builtin_amdgcn_ballot_w64(gave_up) != 0ull && lane == 0) sh[2] = 1;
           lds_barrier();
         }
         if ((s0 & (NS - 1)) == NS - 8 && sh[2] != 0) break;  // (where the computing waves look)

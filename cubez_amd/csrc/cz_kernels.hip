@@ -22,8 +22,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <string>
 #include <vector>
 
+#include "cz_config.h"
 #include "cz_hip.h"
 #include "cz_internal.h"
 
@@ -123,31 +125,18 @@ namespace {
 #include "cz_h_linesor.h"
 }  // namespace
 
-namespace {
-// which CU a workgroup runs on: XCC id | HW_ID (gfx9: cu_id [11:8], sh_id [12], se_id [15:13]); spins a little so that every CU gets one
-__global__ void where_k(unsigned* out, long long spin_ticks) {
-  if (threadIdx.x == 0) {
-    unsigned xcc, hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    out[blockIdx.x] = ((xcc & 0xf) << 16) | (hw & 0xff00);
-  }
-  const long long t0 = (long long)wall_clock64();
-  while ((long long)wall_clock64() - t0 < spin_ticks) {
-  }
-}
-}  // namespace
-
-namespace czhip_internal {
-int reserve_comm_cus(int k, int hard);
-}
-
 // ============================================================================================================
 // Part 2: runtime
 // ============================================================================================================
 extern "C" {
 
 int czhip_real_bytes(void) { return (int)sizeof(REAL); }
+// every environment variable the library reads, with the value in force now (cz_config.h); the string lives until the next call on this thread
+const char* czhip_config_describe(int only_set) {
+  static thread_local std::string text;
+  text = CzConfig::from_env().describe(only_set != 0);
+  return text.c_str();
+}
 const char* czhip_arch(void) { return "gfx950"; }
 
 int czhip_init(int device) {
@@ -155,18 +144,15 @@ int czhip_init(int device) {
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0) {
-    fprintf(stderr, "czhip: no HIP device available (%s) -- this library has no CPU fallback\n", hipGetErrorString(e));
-    exit(1);
+    cz_fatal(1, "czhip: no HIP device available (%s) -- this library has no CPU fallback\n", hipGetErrorString(e));
   }
-  if (device < 0) {
-    const char* lr = getenv("LOCAL_RANK");
-    device = lr ? atoi(lr) % ndev : 0;
-  }
+  const CzConfig cfg = CzConfig::from_env();  // read once per context (cz_config.h)
+  if (device < 0) device = cfg.num(CZV_LOCAL_RANK, 0) % ndev;
   HIP_CHECK(hipSetDevice(device));
   ctx.device = device;
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
-  ctx.num_cu = ctx.num_cu_total = prop.multiProcessorCount;
+  ctx.num_cu = prop.multiProcessorCount;
   ctx.cu_reserved = 0;
   HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
   HIP_CHECK(hipMalloc(&ctx.scal_dev, 16 * sizeof(double)));
@@ -177,35 +163,36 @@ int czhip_init(int device) {
   ctx.ready = true;
   ensure_partials(65536);
   HIP_CHECK(hipMalloc(&ctx.shell_partials, (size_t)2 * 2048 * 6 * sizeof(double)));
-  if (const char* ff = getenv("CZHIP_FUSE_FIN")) ctx.tune.fuse_fin = atoi(ff);
-  if (const char* t2 = getenv("CZHIP_T2")) {  // "enable[,threads,mv,tj]"
+  ctx.tune.fuse_fin = cfg.num(CZV_FUSE_FIN, ctx.tune.fuse_fin);
+  if (const char* t2 = cfg.str(CZV_T2)) {  // "enable[,threads,mv,tj]"
     int en = 1, a = 0, b2 = 0, c2 = -1;
     const int n = sscanf(t2, "%d,%d,%d,%d", &en, &a, &b2, &c2);
     if (n >= 1) czhip_set_tuning2(n >= 2 ? a : 0, n >= 3 ? b2 : 0, n >= 4 ? c2 : -1, en);
   }
-  if (const char* mp = getenv("CZHIP_T2_MAP")) ctx.tune.t2_map = atoi(mp);
-  if (const char* pc = getenv("CZHIP_PCR")) {  // "fast[,variant]"
+  ctx.tune.t2_map = cfg.num(CZV_T2_MAP, ctx.tune.t2_map);
+  if (const char* pc = cfg.str(CZV_PCR)) {  // "fast[,variant]"
     int f = 1, v = 0;
     sscanf(pc, "%d,%d", &f, &v);
     ctx.tune.pcr_fast = f, ctx.tune.pcr_variant = v;
   }
-  if (const char* ar = getenv("CZHIP_T2_ROWS")) ctx.tune.t2_any_rows = atoi(ar) ? 1 : 0;
-  if (const char* pp = getenv("CZHIP_PCR_PIPE")) {  // "form[,seconds[,groups[,rows per thread]]]": form as Tuning::pcr_pipe; bound of the waits inside the kernel
+  ctx.tune.t2_any_rows = cfg.on(CZV_T2_ROWS, ctx.tune.t2_any_rows != 0) ? 1 : 0;
+  ctx.tune.t2_kwin = cfg.num(CZV_T2_KWIN, ctx.tune.t2_kwin);
+  if (const char* pp = cfg.str(CZV_PCR_PIPE)) {  // "form[,seconds[,groups[,rows per thread]]]": form as Tuning::pcr_pipe; bound of the waits inside the kernel
     int w = 1, rows = 0, q = 1;
     double sec = 2.0;
     sscanf(pp, "%d,%lf,%d,%d", &w, &sec, &rows, &q);
     ctx.tune.pcr_pipe = w, ctx.tune.pipe_spin_ticks = (long long)(sec * 1e8), ctx.tune.pcr_rows = rows, ctx.tune.pcr_q = q;
   }
-  if (const char* v = getenv("CZHIP_PSOR")) {  // "one_launch[,workgroups per CU]"
+  if (const char* v = cfg.str(CZV_PSOR)) {  // "one_launch[,workgroups per CU]"
     int one = 1, wg = 0;
     sscanf(v, "%d,%d", &one, &wg);
     ctx.tune.psor_col = one, ctx.tune.psor_wg_per_cu = wg;
   }
-  if (const char* v = getenv("CZHIP_PCR_WG_PER_CU")) ctx.tune.pcr_wg_per_cu = atoi(v);
-  if (const char* v = getenv("CZHIP_PCR_MAX_WG")) ctx.tune.pcr_max_wg = atoi(v);
-  if (const char* v = getenv("CZHIP_PCR_SLOTS")) ctx.tune.pcr_slots = atoi(v);
-  const char* tu = getenv("CZHIP_TUNING");  // "threads,m,tj,pf"
-  if (tu) {
+  ctx.tune.pcr_wg_per_cu = cfg.num(CZV_PCR_WG_PER_CU, ctx.tune.pcr_wg_per_cu);
+  ctx.tune.pcr_max_wg = cfg.num(CZV_PCR_MAX_WG, ctx.tune.pcr_max_wg);
+  ctx.tune.pcr_slots = cfg.num(CZV_PCR_SLOTS, ctx.tune.pcr_slots);
+  if (const char* pf = cfg.str(CZV_PCR_PIPE_PROF)) ctx.pipe_prof_file = pf;
+  if (const char* tu = cfg.str(CZV_TUNING)) {  // "threads,m,tj,pf"
     int a = 0, b = 0, c = 0, d = -1;
     if (sscanf(tu, "%d,%d,%d,%d", &a, &b, &c, &d) >= 2) czhip_set_tuning(a, b, c < 0 ? 0 : c, d);
   }
@@ -534,35 +521,10 @@ long long czhip_selftest_fastdiv(CZ_REAL d) {
   return (long long)h;
 }
 
-// Self-test of the hard form of the CU reservation of decomposed runs (reserve_comm_cus, CU mask): with k CUs per XCD set aside, where do the
-// workgroups of a launch on the library's compute stream run?  per_xcd[x] receives the number of distinct CUs of XCD x that ran one; returns their total.  The
-// reservation is undone before returning.
-int czhip_selftest_cu_reserve(int k, int* per_xcd) {
+// Measurement aid (tools/cu_reserve_cost.py): put the CU reservation of decomposed runs in force on this context by hand; returns what is in force.
+int czhip_set_comm_cus(int k) {
   ensure_init();
-  const int before = ctx.cu_reserved, before_hard = ctx.cu_masked ? 1 : 0;
-  czhip_internal::reserve_comm_cus(k, 1);
-  const int nwg = 8192;
-  unsigned* d = nullptr;
-  HIP_CHECK(hipMalloc(&d, nwg * sizeof(unsigned)));
-  hipLaunchKernelGGL(where_k, dim3(nwg), dim3(64), 0, ctx.stream, d, 2000LL);  // 20 us each
-  HIP_CHECK(hipGetLastError());
-  std::vector<unsigned> h(nwg);
-  HIP_CHECK(hipMemcpyAsync(h.data(), d, nwg * sizeof(unsigned), hipMemcpyDeviceToHost, ctx.stream));
-  HIP_CHECK(hipStreamSynchronize(ctx.stream));
-  HIP_CHECK(hipFree(d));
-  std::sort(h.begin(), h.end());
-  h.erase(std::unique(h.begin(), h.end()), h.end());
-  for (int x = 0; x < 8; x++) per_xcd[x] = 0;
-  for (unsigned key : h)
-    if ((key >> 16) < 8) per_xcd[key >> 16]++;
-  czhip_internal::reserve_comm_cus(before, before_hard);
-  return (int)h.size();
-}
-
-// Measurement aid (tools/cu_reserve_cost.py): put the reservation of decomposed runs in force on this context by hand; returns what is in force.
-int czhip_set_comm_cus(int k, int hard) {
-  ensure_init();
-  return czhip_internal::reserve_comm_cus(k, hard);
+  return czhip_internal::reserve_comm_cus(k);
 }
 
 // line-SOR kernel choice: form 0 = pcr_rb_k (the reference's arithmetic literally, pcr_rb only), 1 = table + d in LDS, 2 = table +
@@ -788,8 +750,7 @@ void psor_maf_(CZ_REAL* p, int* sz, int* idx, int* g, CZ_REAL* X, CZ_REAL* Y, CZ
   const Box bx = make_box(sz, idx, *g);
   if (bx.empty) return;
   if (bx.g != 2) {
-    fprintf(stderr, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2), cz_maf.f90:36-38)\n");
-    exit(1);
+    cz_fatal(1, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2), cz_maf.f90:36-38)\n");
   }
   const MafArgs ma = upload_xyz(sz, *g, X, Y, Z, nullptr);
   launch_psor(p, b, make_coef_omg(*omg), bx, ctx.scal_dev + 0, 0, nullptr, &ma);
@@ -861,8 +822,7 @@ void pcr_maf_dropin(int* sz, int* idx, int g, int pn, int order, int color, CZ_R
   const Box bx = make_box(sz, idx, g);
   if (bx.empty) return;
   if (bx.g != 2) {
-    fprintf(stderr, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2))\n");
-    exit(1);
+    cz_fatal(1, "czhip: the MAF kernels assume GUIDE = 2 (X(-1:sz+2))\n");
   }
   const MafArgs ma = upload_xyz(sz, g, XX, YY, ZZ, nullptr);
   launch_pcr_maf(x, msk, rhs, bx, idx, pn, order, color, omg, ctx.scal_dev + 0, 0, ma);
@@ -985,38 +945,20 @@ hipStream_t stream() {
 // Decomposed runs: the sweeps leave k CUs of every XCD to what the exchange stream launches while an interior sweep fills the chip -- shell
 // slabs, pack / unpack and above all RCCL's send/recv kernels, which need CUs of their own for as long as a message is in flight.  The
 // interior launch of the two-stage pass is sized to fill its slots in ONE round with workgroups that live as long as the launch
-// (pair_tj_model), so a stream priority alone frees nothing before the end.  Two mechanisms:
-//   soft (default)  the launch geometry: pair_tj_model counts num_cu/8 - k slots per XCD, so a one-round launch leaves k CUs of every XCD
-//                   without a workgroup (a 1024-thread workgroup with its ~130 KB of LDS takes a CU for itself), and launches of several
-//                   rounds free slots all the time anyway.  Costs nothing at 512^3 FP32, where the launch uses 30 of the 32 slots as it is.
-//   hard            a CU mask on the compute stream's queue (hipExtStreamCreateWithCUMask; bit i of the mask is CU i / 8 of XCD i % 8 on
-//                   this part: tools/cumask_lab.hip `reserve`, czhip_selftest_cu_reserve).  The reserved CUs are then out of reach of
-//                   every sweep -- and a launch that fills the remaining CUs in one round takes 1.8x as long (0.63 against 0.35 ms at
-//                   512^3 FP32 with k = 1 or 2, profiles/r03/cu_reserve_cost.txt): the dispatcher of a masked queue does not place one
-//                   workgroup on every CU the way it does without a mask.  Kept for measurements (CZ_COMM_CUS_MASK=1), not the default.
+// (pair_tj_model), so a stream priority alone frees nothing before the end.  The reservation is made through the launch geometry:
+// pair_tj_model counts num_cu/8 - k slots per XCD, so a one-round launch leaves k CUs of every XCD without a workgroup (a 1024-thread
+// workgroup with its ~130 KB of LDS takes a CU for itself), and launches of several rounds free slots all the time anyway.  Costs nothing at
+// 512^3 FP32, where the launch uses 30 of the 32 slots as it is (profiles/r03/cu_reserve_cost.txt).
+// (Rounds 3: a hardware-enforced form -- a CU mask on the compute stream's queue, hipExtStreamCreateWithCUMask -- was measured and removed in
+// round 4: one-round launches took 1.8x as long on a masked queue, and swapping the context's stream under live users (timer events, the
+// driver's cached stream, RCCL's enqueue state) ended two measurement runs in a hang.  tools/cumask_lab.hip keeps the experiment.)
 // Returns the reservation in force.
-int reserve_comm_cus(int k, int hard) {
+int reserve_comm_cus(int k) {
   ensure_init();
-  const int per_xcd = ctx.num_cu_total / 8;
-  if (ctx.num_cu_total % 8 != 0 || per_xcd < 4) k = 0;  // not the 8-XCD part this was measured on
+  const int per_xcd = ctx.num_cu / 8;
+  if (ctx.num_cu % 8 != 0 || per_xcd < 4) k = 0;  // not the 8-XCD part this was measured on
   k = std::max(0, std::min(k, per_xcd / 2));
-  if (k == 0) hard = 0;
-  if (k == ctx.cu_reserved && (hard != 0) == ctx.cu_masked) return k;
-  if ((hard != 0) != ctx.cu_masked || hard) {  // the stream changes
-    HIP_CHECK(hipStreamSynchronize(ctx.stream));
-    HIP_CHECK(hipStreamDestroy(ctx.stream));
-    if (!hard) {
-      HIP_CHECK(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
-    } else {
-      std::vector<uint32_t> mask((size_t)(ctx.num_cu_total + 31) / 32, 0u);
-      for (int i = 0; i < ctx.num_cu_total; i++)
-        if (i / 8 < per_xcd - k) mask[(size_t)i / 32] |= 1u << (i % 32);
-      HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx.stream, (uint32_t)mask.size(), mask.data()));
-    }
-  }
   ctx.cu_reserved = k;
-  ctx.cu_masked = hard != 0;
-  ctx.num_cu = ctx.num_cu_total - (hard ? 8 * k : 0);  // what a launch can occupy at all
   return k;
 }
 int comm_cus_reserved() { return ctx.cu_reserved; }

@@ -19,19 +19,17 @@
 #include <string>
 #include <vector>
 
+#include "cz_config.h"
 #include "cz_hip.h"
 
-static std::string id_file() {
-  const char* f = getenv("CZ_COMM_ID_FILE");
-  if (f) return f;
-  const char* port = getenv("MASTER_PORT");
-  return std::string("/tmp/cz_comm_id.") + (port ? port : "0");
+static std::string id_file(const CzConfig& cfg) {
+  if (cfg.has(CZV_COMM_ID_FILE)) return cfg.str(CZV_COMM_ID_FILE);
+  return std::string("/tmp/cz_comm_id.") + (cfg.has(CZV_MASTER_PORT) ? cfg.str(CZV_MASTER_PORT) : "0");
 }
 
 int main(int argc, char* argv[]) {
-  int myRank = 0, nproc = 1;
-  if (getenv("RANK")) myRank = atoi(getenv("RANK"));
-  if (getenv("WORLD_SIZE")) nproc = atoi(getenv("WORLD_SIZE"));
+  const CzConfig cfg = CzConfig::from_env();  // the launcher's variables and the switches, read once (cz_config.h)
+  const int myRank = cfg.num(CZV_RANK, 0), nproc = cfg.num(CZV_WORLD_SIZE, 1);
 
   if (argc != 7 && argc != 8 && argc != 10 && argc != 11) {  // main.cpp:19-31
     if (myRank == 0) {
@@ -51,14 +49,14 @@ int main(int argc, char* argv[]) {
   if (nproc > 1) {
     const int nb = cz_comm_unique_id_bytes();
     std::vector<char> id(nb);
-    const std::string path = id_file();
+    const std::string path = id_file(cfg);
     // The record: job key, creation time, id.  Job key: $CZ_JOB_ID, else MASTER_ADDR:MASTER_PORT -- values every rank of a job shares
     // whatever started it (one launcher, a wrapper script per rank, several nodes with the file on a shared file system).  A file a dead job
     // left behind on the same address and port is told apart by its age: rank 0 stamps the record, a reader takes a record only when the
     // stamp is not older than its own start minus a minute (ranks of one job start together; set CZ_JOB_ID where that does not hold).
     char key[256];
-    if (getenv("CZ_JOB_ID")) snprintf(key, sizeof(key), "%s", getenv("CZ_JOB_ID"));
-    else snprintf(key, sizeof(key), "%s:%s", getenv("MASTER_ADDR") ? getenv("MASTER_ADDR") : "-", getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    if (cfg.has(CZV_JOB_ID)) snprintf(key, sizeof(key), "%s", cfg.str(CZV_JOB_ID));
+    else snprintf(key, sizeof(key), "%s:%s", cfg.has(CZV_MASTER_ADDR) ? cfg.str(CZV_MASTER_ADDR) : "-", cfg.has(CZV_MASTER_PORT) ? cfg.str(CZV_MASTER_PORT) : "0");
     const long long started = (long long)time(nullptr);
     std::vector<char> rec(sizeof(key) + sizeof(long long) + nb, 0);
     bool ok = true;
@@ -103,10 +101,7 @@ int main(int argc, char* argv[]) {
 
   cz_handle* cz = cz_create();
   cz_set_debug(cz, 1);  // main.cpp:38-42: debug mode is hard-wired on
-  {
-    const char* pf = getenv("CZ_PROFILE");  // profiling.txt (cz_Evaluate.cpp:506-545) unless CZ_PROFILE=0
-    cz_set_profile(cz, pf ? atoi(pf) : 1);
-  }
+  cz_set_profile(cz, cfg.num(CZV_PROFILE, 1));  // profiling.txt (cz_Evaluate.cpp:506-545) unless CZ_PROFILE=0
   if (0 == cz_evaluate(cz, argc, argv)) {  // main.cpp:45-52
     if (myRank == 0) printf("\n\tSolver error.\n\n");
     cz_destroy(cz);

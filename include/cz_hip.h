@@ -265,14 +265,13 @@ int czhip_set_psor(int one_launch, int wg_per_cu);
  * workgroups the device keeps resident; a ring forced small with few workgroups cannot, and the sweep then ends as described above. */
 int czhip_set_pcr_lex_limits(int wg_per_cu, int max_wg, int slots);
 int czhip_use_t2(void);
+/* Every environment variable the library and the cz command line read (one table, cubez_amd/csrc/cz_config.h), one per line: NAME=value where set,
+ * NAME (unset; default ...) otherwise; only_set != 0 lists the former only.  The string lives until the next call on the calling thread. */
+const char* czhip_config_describe(int only_set);
 /* Decomposed runs keep k CUs of every XCD free of the sweeps (CZ_COMM_CUS, default 2) so that RCCL's send/recv kernels run while an interior
- * sweep fills the chip: through the launch geometry (default) or, with CZ_COMM_CUS_MASK=1, a CU mask on the compute stream.  Self-test of the
- * mask: with k CUs set aside, per_xcd[0..7] = the CUs of each XCD a launch on the compute stream ran on (expected 32 - k each); returns
- * their total. */
-int czhip_selftest_cu_reserve(int k, int* per_xcd);
-/* measurement aid: put that reservation in force by hand, hard = 1 with the CU mask (the driver does it itself in decomposed runs and undoes
- * it in single-domain ones at set-up); returns the reservation in force */
-int czhip_set_comm_cus(int k, int hard);
+ * sweep fills the chip -- through the launch geometry (the launches count those CUs out).  Measurement aid: put that reservation in force by
+ * hand (the driver does it itself in decomposed runs and undoes it in single-domain ones at set-up); returns the reservation in force. */
+int czhip_set_comm_cus(int k);
 /* self-test: numerators (of 2^32) whose quotient by d in the two-stage pass differs from the IEEE division (expected 0); -1 = divisor not eligible */
 long long czhip_selftest_fastdiv(CZ_REAL d);
 

@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 # the oracle's bit-exactness contract is the single-thread one (SURVEY.md finding 2/3)
 os.environ.setdefault("OMP_NUM_THREADS", "1")
+# a fatal exit inside the library (cz_fatal, cz_internal.h) ends this very process, and the stderr pytest captured dies with it: the library
+# appends the message to this file as well, so a test run that ends without a summary leaves the reason behind
+_fatal_dir = os.path.join(ROOT, "gpurun_out")
+os.makedirs(_fatal_dir, exist_ok=True)
+os.environ.setdefault("CZ_FATAL_LOG", os.path.join(_fatal_dir, "cz_fatal.log"))
 
 
 def pytest_configure(config):

@@ -37,3 +37,22 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(lib, "_LOADED", {})
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lib.load("f32")
+
+
+def test_a_fatal_exit_of_the_library_leaves_a_line(tmp_path):
+    """Every fatal exit inside the library goes through cz_fatal (cz_internal.h): message on stderr, appended to $CZ_FATAL_LOG, streams
+    flushed, exit code 1.  Without a GPU the first such exit is czhip_init's "no HIP device" -- which is also the statement that the
+    library has no CPU fallback.  (With a GPU present the call succeeds: the check is then that nothing is logged.)"""
+    import subprocess
+    import sys
+    log = tmp_path / "fatal.log"
+    env = dict(os.environ, CZ_FATAL_LOG=str(log))
+    code = "import sys; sys.path.insert(0, %r); import cubez_amd; print('rc', cubez_amd.load('f32').czhip_init(0), flush=True)" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    if os.path.exists("/dev/kfd") and r.returncode == 0:
+        assert "rc 0" in r.stdout and not log.exists()
+        return
+    assert r.returncode == 1, (r.returncode, r.stdout, r.stderr)
+    assert "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr
+    text = log.read_text()
+    assert "no HIP device available" in text and "exit 1" in text

@@ -190,20 +190,32 @@ def _fused_equals_unfused(prec, gsz, pc, monkeypatch):
     fused pass from zero: that pass makes its right-hand side from their operands and stores it (jacobi2p_k<BS>).  Same operations on the
     same values: history and field of the solve equal those of the solve with the updates launched (CZ_BICG_FUSE=0), bit for bit."""
     from cubez_amd import CZ
+    # every switch of the iteration alone and all together (ADVICE r3: one switch used to turn three changes off at once, so a regression
+    # could not be localised): made right-hand sides, alpha / omega on the device, p_ / s_ aliased where the preconditioner is a copy,
+    # SpMV folded into the last pass of the preconditioner solve
+    names = ("CZ_BICG_FUSE", "CZ_BICG_DEVSC", "CZ_BICG_ALIAS", "CZ_BICG_SPMV")
+    combos = {"all": {}, "none": {k: "0" for k in names}}
+    combos.update({f"no_{k[8:].lower()}": {k: "0"} for k in names})
     out = {}
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("CZ_BICG_FUSE", fuse)
+    for tag, env in combos.items():
+        for k in names:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         cz = CZ(prec, quiet=True)
         assert cz.setup(list(gsz) + ["pbicgstab", 40, 0.8, pc]) == 1
         itr = cz.solve()
-        out[fuse] = (itr, cz.res, list(cz.history()), cz.field().tobytes(), cz.info()["bicg_fused"])
+        out[tag] = (itr, cz.res, list(cz.history()), cz.field().tobytes(), cz.info()["bicg_fused"])
         cz.close()
-    assert out["0"][4] == 0
-    n = len(out["1"][2])
-    assert out["1"][4] in (0, 2 * n - 1), out["1"][4]  # all or nothing: every update but the first iteration's copy
+    for k in names:
+        monkeypatch.delenv(k, raising=False)
+    assert out["none"][4] == 0 and out["no_fuse"][4] == 0
+    n = len(out["all"][2])
+    assert out["all"][4] in (0, 2 * n - 1), out["all"][4]  # all or nothing: every update but the first iteration's copy
     if pc in ("jacobi", "sor2sma") and gsz in ((64, 64, 64), (128, 128, 128)):
-        assert out["1"][4] == 2 * n - 1  # shapes the two-stage pass is known to take
-    assert out["1"][:4] == out["0"][:4]
+        assert out["all"][4] == 2 * n - 1  # shapes the two-stage pass is known to take
+    for tag in combos:
+        assert out[tag][:4] == out["none"][:4], tag
 
 
 def test_convergence_stops_at_the_reference_iteration():
