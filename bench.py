@@ -238,7 +238,7 @@ def event_span_ms(lib, fn):
 def kernel_source_sha():
     """identifies the build a recorded HBM-traffic figure belongs to: the sources of the sweep kernels and their launch geometry"""
     h = hashlib.sha256()
-    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_h_launch.h"):
+    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_blas.h", "cz_h_launch.h"):
         h.update(open(os.path.join(ROOT, "cubez_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -285,7 +285,8 @@ def measure(solver, prec, precond, steps, warmup, repeats, settle):
         settled = time.perf_counter() - t0
         cz.sweeps(warmup)
         barrier(lib)
-        cz.timing(True)
+        # the timed regions run WITHOUT the per-launch HIP events of the roofline leg (two event records per launch cost microseconds: a fifth of a
+        # 128^3 pass, nothing at 512^3); one more region of K steps behind them, with the events on, gives the kernel durations
         for rep in range(repeats):
             dts.append(timed(lib, lambda: cz.sweeps(steps)))
         # N > 1: a region of K = 20 steps is a few milliseconds, the same order as the jitter of N processes starting it together.  The
@@ -296,6 +297,9 @@ def measure(solver, prec, precond, steps, warmup, repeats, settle):
                 dts.append(timed(lib, lambda: cz.sweeps(steps)))
         if world > 1:
             ev_ms = event_span_ms(lib, lambda: cz.sweeps(steps))
+        cz.timing(True)
+        cz.sweeps(steps)
+        barrier(lib)
     jl = solver in ("jacobi", "jacobi_maf") or (bicg and precond == "jacobi")
     line = solver.startswith("pcr")
     single = cz.timing_read("jacobi" if jl else "pcr_rb" if line else "psor" if solver.startswith("psor") else "rbsor")
@@ -306,7 +310,7 @@ def measure(solver, prec, precond, steps, warmup, repeats, settle):
     cz.close()
     return dict(solver=solver, prec=prec, precond=precond, bicg=bicg, coef=coef, steps=steps, warmup=warmup, repeats=repeats, dts=dts, dt=statistics.median(dts),
                 my_points=my_points, jac_like=jl, line=line, single=single, fused=fused, labels=labels, info=info, settle_s=settled,
-                timed_steps=steps * (1 if bicg else len(dts)), event_span_ms=ev_ms)
+                timed_steps=steps, event_span_ms=ev_ms)
 
 
 def traffic_record(tkey):
@@ -368,9 +372,41 @@ def roofline_of(m):
     r = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
          "kernel": kernel_name, "kernel_avg_ms": kern_avg_s * 1e3, "kernel_launches_timed": nk, "algorithmic_bytes_per_launch": alg, "model": model,
          "fused_min_bytes_per_launch": fused_min, "traffic_source": tsrc,
+         # the fraction a consumer may read as "of peak" for a fused kernel: what one pass over memory must move (u, b read; w written) / time / peak
+         "frac_fused_min": (fused_min / kern_avg_s / 1e9 / 8000.0) if (fused_min and nk) else None,
          # HBM bytes the counters saw per launch / this run's mean launch duration / peak: a fraction of what the memory system can do (<= 1)
          "frac_hbm_traffic": (traffic / kern_avg_s / 1e9 / 8000.0) if (traffic and nk) else None}
     return r
+
+
+def iteration_traffic(m, label_ms):
+    """what one BiCGSTAB iteration physically moves: the HBM counters of EVERY kernel of the iteration (profiles/hbm_traffic.json, key
+    bicg_<n>_<prec>: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over a profiled run of this very command, tools/profile_r04.sh) summed with
+    their launch counts -- beside SURVEY's 76-word model (608 B per point in FP64), which counts passes the code no longer makes"""
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tfile)).get(f"bicg_{n}_{m['prec']}")
+    except Exception:
+        rec = None
+    word = 4 if m["prec"] == "f32" else 8
+    out = {"model_bytes_per_point": {"survey_8d_76_words": 76 * word, "array_passes_executed_41": 41 * word}}
+    if not rec:
+        return out
+    per_it = rec["bytes_per_unit"]
+    ms = m["dt"] / m["steps"] * 1e3
+    # the library's timing labels -> the kernels they cover
+    groups = {"jacobi2": "jacobi2p_k", "calc_ax": "stencil_k", "ewise": ("ewise_k", "triad_dots_k")}
+    per_label = {}
+    for lb, names in groups.items():
+        names = (names,) if isinstance(names, str) else names
+        b = sum(k["bytes_per_launch"] * k["launches_per_unit"] for nm, k in rec["kernels"].items() if nm.startswith(names))
+        if b and label_ms.get(lb):
+            per_label[lb] = {"bytes_per_iteration": b, "ms_per_iteration": label_ms[lb], "physical_GBps": b / label_ms[lb] / 1e6, "frac_hbm_traffic": b / label_ms[lb] / 1e6 / 8000.0}
+    out.update({"executed_bytes_per_point": per_it / m["my_points"], "traffic_bytes_per_iteration": per_it, "physical_GBps": per_it / ms / 1e6,
+                "frac_hbm_traffic": per_it / ms / 1e6 / 8000.0, "per_kernel_group": per_label,
+                "traffic_source": {"file": "profiles/hbm_traffic.json", "key": f"bicg_{n}_{m['prec']}", "kernel_source_sha": rec.get("kernel_source_sha"),
+                                   "box": rec.get("box"), "recorded": rec.get("recorded"), "matches_this_build": rec.get("kernel_source_sha") == kernel_source_sha()}})
+    return out
 
 
 def config_record(m):
@@ -386,6 +422,7 @@ def config_record(m):
         rec["algorithmic_GBps"] = m["my_points"] * word * 76 * m["steps"] / m["dt"] / 1e9
         rec["kernel_ms_per_iteration"] = {lb: (ms / m["steps"]) for lb, (cnt, ms) in m["labels"].items() if cnt}
         rec["kernel_launches_per_iteration"] = {lb: cnt / m["steps"] for lb, (cnt, ms) in m["labels"].items() if cnt}
+        rec.update(iteration_traffic(m, rec["kernel_ms_per_iteration"]))
     else:
         rec["unit"], rec["value"] = "MLUPS", m["my_points"] * m["steps"] / m["dt"] / 1e6
         rec["step"] = "one red-black iteration (both colours) + residual reduction + convergence bookkeeping (cz_Poisson.cpp:159-235)"

@@ -19,6 +19,7 @@ struct Tuning {
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
                                               // the balance model (pair_tj_model, cz_h_launch.h); CZHIP_T2=enable,threads,2,tj fixes them
   int t2_kwin = -1;                               // two-stage pass: vectors per k window; -1 = chosen per launch, 0 = whole rows where they fit (CZHIP_T2_KWIN)
+  int t2_pre = 1;                                 // two-stage pass on small grids: every operand of a chunk requested before its first step (jacobi2p_k<PRE>; CZHIP_T2_PRE)
   int t2_map = 1;                                 // two-stage pass: equal shares of (segment, chunk) items per XCD (CZHIP_T2_MAP=0: whole-segment bands)
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
 };

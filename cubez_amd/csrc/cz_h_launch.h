@@ -165,19 +165,41 @@ inline const int* pair_xcd_map(int nseg, int nchunk, long long* nblk_out) {
 // single-sweep rate, until round 3; profiles/r03/non_cubic_boxes.txt)
 inline bool pair_use_map(int nseg) { return ctx.tune.t2_map && 10 * nseg < 9 * 8 * ((nseg + 7) / 8); }
 
+// k windows of the two-stage pass (Geom2).  A window of KT vectors costs a workgroup (KT + 2) / KT in loads and first-stage work and leaves it
+// rows of R = KT + 2 vectors, i.e. a useful share of (LV - 2R) / LV of its LV = TB MV vectors.  That product peaks near KT = sqrt(LV) = 45 --
+// and the measurements say otherwise (profiles/r04/k_windows_sweep.txt): pieces of rows shorter than about 100 vectors (1.6 KB) cost more in
+// memory efficiency than they save in redundant work (512^3 FP32, R = 129: two windows of 65 are 8 % SLOWER than whole rows), pieces of 129 to
+// 176 vectors are the best everywhere they were tried: 512^3 FP64 (R = 258) 0.80 -> 0.655 ms per pass with two windows, 1024^3 FP32 (R = 257)
+// 598 000 -> 820 000 MLUPS, rows of 2 104 FP32 / 1 104 FP64 elements (which took single sweeps until round 3) 790 000 / 410 000 MLUPS.  Rule:
+// whole rows up to 192 vectors, else the fewest windows of at most 176.
+constexpr int kPairWin = 176;
+inline bool pair_whole_rows_ok(int Rfull, int /*LV*/) { return Rfull <= 192; }
+
 // two fused sweeps (jacobi2p_k); returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
-template <int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0>
+template <int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0, int PRE = 0>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
                          const int* skip, const Fin2& fin_in, int par, bool probe, double* model_cost, const MafArgs& ma = MafArgs(),
                          const BSrc& bs = BSrc()) {
   constexpr int V = VW;
   Geom2 g;
-  g.R = (b.nkp + V - 1) / V;  // rows as R vectors from a vector boundary each; the last one partial where nkp % V != 0 (Geom2)
-  if (2 * g.R > TB || 4 * g.R >= TB * MV) return false;  // the outer rows are staged by 2R threads / halo rows would dominate
+  const int Rfull = (b.nkp + V - 1) / V;  // rows as vectors from a vector boundary each; the last one partial where nkp % V != 0 (Geom2)
+  // k windows (Geom2): whole rows where a segment of them is a decent share of the workgroup's vectors, else windows of about kPairWin vectors;
+  // CZHIP_T2_KWIN / ctx.tune.t2_kwin: > 0 = vectors per window, 0 = whole rows wherever they fit, -1 = this rule
+  const bool whole_fits = 2 * Rfull <= TB && 4 * Rfull < TB * MV;  // the outer rows are staged by 2R threads / halo rows would dominate
+  int want = ctx.tune.t2_kwin;
+  if (want < 0) want = (whole_fits && pair_whole_rows_ok(Rfull, TB * MV)) ? 0 : kPairWin;
+  if (want == 0 && !whole_fits) want = kPairWin;
+  g.R = Rfull;
+  if (want > 0 && want < Rfull) {
+    g.nwin = (Rfull + want - 1) / want;
+    g.KT = (Rfull + g.nwin - 1) / g.nwin;
+    g.hv = 1, g.KW = g.KT * V, g.R = g.KT + 2;
+  }
+  if (2 * g.R > TB || 4 * g.R >= TB * MV) return false;
   g.PSV = (long long)g.R * b.nip;
   g.nkp = b.nkp;
   g.PSB = (long long)b.nkp * b.nip * (long long)sizeof(REAL);
-  if (g.PSV * (long long)sizeof(Vec<V>) >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
+  if (g.PSB >= (1LL << 32)) return false;  // 32-bit byte offsets inside a plane
   g.jlast = b.njp - 1;
   g.last_off = (unsigned)(g.PSB - (long long)sizeof(Vec<V>));
   g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
@@ -190,15 +212,24 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   g.par = par;
   g.zero_u = ZU;
   const long long nf = g.Fend - g.F0;
-  g.nseg = (int)((nf + g.S - 1) / g.S);
+  g.nsegw = (int)((nf + g.S - 1) / g.S);
+  g.nseg = g.nwin * g.nsegw;
   const int nplanes = b.jj1 - b.jj0 + 1;
   const size_t lds = (size_t)2 * ((g.S + 4 * g.R) + (g.S + 2 * g.R)) * sizeof(Vec<V>) + 18 * sizeof(double) +
                      (MAF ? (size_t)2 * g.R * V * sizeof(REAL) : 0);  // MAF: the table of the k metric terms
   if (lds > 160 * 1024) return false;
-  const int wg_per_cu = std::max(1, std::min((int)(160 * 1024 / lds), 2048 / TB));
+  const int wg_per_cu = (MAF && TB == 512) ? 1 : std::max(1, std::min((int)(160 * 1024 / lds), 2048 / TB));  // (MAF: a 512-thread workgroup of up to 256 registers per thread fills a CU's register file)
   int tj = tj_req;
-  const double cost = pair_tj_model(g.nseg, nplanes, wg_per_cu, pair_use_map(g.nseg), tj > 0 ? &g.TJ : &tj);
-  if (model_cost) *model_cost = cost * wg_per_cu * (double)(TB * MV + g.S);  // plane steps x work per CU and step
+  if (PRE) {
+    // the preloaded form (jacobi2p_k<PRE>): chunks of PRE planes, and only where every workgroup of the pass is resident at once -- one
+    // workgroup per CU (its operands live in ~190 registers per thread) less the CUs left to the exchange stream of a decomposed run
+    tj = std::min(PRE, nplanes);
+    const long long slots = (long long)std::max(1, ctx.num_cu / 8 - ctx.cu_reserved) * 8;  // (one per CU also for the 256 x 1 shape: measured, profiles/r04/small_grids_preloaded_shapes.txt)
+    if ((long long)g.nseg * ((nplanes + tj - 1) / tj) > slots) return false;
+  } else {
+    const double cost = pair_tj_model(g.nseg, nplanes, wg_per_cu, pair_use_map(g.nseg), tj > 0 ? &g.TJ : &tj);
+    if (model_cost) *model_cost = cost * wg_per_cu * (double)(TB * MV + g.S);  // plane steps x work per CU and step
+  }
   if (tj > nplanes) tj = nplanes;
   g.TJ = tj;
   const int nchunk = (nplanes + tj - 1) / tj;
@@ -210,7 +241,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
@@ -218,7 +249,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   fin.counter = ctx.counter;
   {
     ScopedTimer tm(RB ? LBL_RBSOR2 : LBL_JACOBI2);
-    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin, ma, bs);
+    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS, PRE>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin, ma, bs);
   }
   HIP_CHECK(hipGetLastError());
   return true;
@@ -247,8 +278,13 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
     if (!ok512 && !ok1024) return false;
     tb = (ok512 && (!ok1024 || c512 <= c1024)) ? 512 : 1024;
   }
-  if (ma) {  // MAF flavour (cz_maf.f90): weights recomputed per point from the 1-D grids
-    if (tb == 512 && launch_jacobi2_inst<512, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma)) return true;
+  if (ma) {  // MAF flavour (cz_maf.f90): weights recomputed per point from the 1-D grids.  Shape by measurement (profiles/r04/
+             // register_spills_priced.txt; 512^3): the 512-thread form may use 256 registers per thread and spills nothing, the 1024-thread
+             // form keeps 6-28 registers in scratch.  FP64 and the red-black pass: 512 threads (FP64 Jacobi 197 000 against 176 500 MLUPS,
+             // red-black 115 600 against 93 200; FP32 red-black 181 800 / 182 500); FP32 Jacobi: 1024 threads, 6 registers in scratch and
+             // all the same 352 600 against 273 900 MLUPS -- the spill is priced, the shape without it is slower.
+    const bool first512 = tu.t2_threads == 512 || (tu.t2_threads == 0 && (sizeof(REAL) == 8 || RB));
+    if (first512 && launch_jacobi2_inst<512, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma)) return true;
     return launch_jacobi2_inst<1024, 2, RB, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr, *ma);
   }
   if (zero_u && bs_op != 0) {  // the right-hand side made from the operands of the vector update before the solve (jacobi2p_k<BS>)
@@ -263,6 +299,18 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   if (zero_u) {
     if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
     return launch_jacobi2_inst<1024, 2, RB, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+  }
+  // small grids: the preloaded form (jacobi2p_k<PRE>) where the pass is at most one workgroup per CU.  Two shapes: 256 threads x 1 vector -- a
+  // 64^3 pass cut into 512 x 2 pieces is 62 workgroups, three quarters of the CUs idle while the others grind through 2.4 us plane steps --
+  // and 512 x 2 with its smaller share of halo rows for the grids that fill the chip either way; the first form of the list that fits is
+  // the fastest at every size measured (32^3 .. 128^3, FP32 and FP64: 1.5x at 32^3 .. 64^3, 1.05-1.1x at 96^3 and 128^3; beyond that no form
+  // fits and the pipelined one stays).  t2_pre: 1 = this rule,
+  // 0 = never, TB * 10 + PRE = that form or none (measurements).  A fixed shape (CZHIP_T2=1,threads,2,tj with tj > 0) keeps the pipelined form.
+  if (!probe && tu.t2_pre && tu.t2_tj == 0 && tu.t2_threads != 1024) {
+#define CZ_PRE(TB_, MV_, PRE_) \
+  if ((tu.t2_pre == 1 || tu.t2_pre == TB_ * 10 + PRE_) && launch_jacobi2_inst<TB_, MV_, RB, 0, 0, 0, PRE_>(U, B, W, c, b, ba, 0, skip, fin, par, false, nullptr)) return true;
+    CZ_PRE(256, 1, 2) CZ_PRE(256, 1, 4) CZ_PRE(512, 2, 2) CZ_PRE(512, 2, 3) CZ_PRE(512, 2, 4)
+#undef CZ_PRE
   }
   if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
   return launch_jacobi2_inst<1024, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);

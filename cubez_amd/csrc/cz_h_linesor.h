@@ -163,6 +163,13 @@ bool try_pcr_reg(REAL* x, REAL* wout, const REAL* msk, const REAL* rhs, const Pc
       return try_pcr_reg_inst<M_, 4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                \
     else if constexpr (sizeof(REAL) == 4 && M_ <= 8)                                                                                  \
       return try_pcr_reg_inst<M_, 8, 2, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                \
+    else if constexpr (M_ == 16 && sizeof(REAL) == 8)                                                                                 \
+      /* FP64 lines of 513 .. 1 024 unknowns: 4 waves per workgroup.  With 16 (128 registers per thread) the kernel kept 105-192 registers \
+         in scratch; measured at 256 x 256 x 1024 the two shapes run at the same rate (27 490 / 27 465 MLUPS pcr_rb), so the one without   \
+         scratch traffic stays.  The other spilling shapes were priced the same way and KEPT because the shape without spills is slower:  \
+         FP32 16 entries per lane (8-32 registers spilled: 136 200 against 125 600 MLUPS with 8 waves), FP64 8 entries per lane with 4x4   \
+         final systems (15-17 spilled: 83 700 against 74 700 at 512^3) -- profiles/r04/register_spills_priced.txt */                       \
+      return try_pcr_reg_inst<M_, 4, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);                \
     else                                                                                                                              \
       return try_pcr_reg_inst<M_, 16, 1, FINAL4, ORDER>(x, wout, msk, rhs, g, omg, res_dev, accumulate, tab_len, ncol);               \
   }

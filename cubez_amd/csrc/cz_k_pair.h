@@ -25,12 +25,27 @@ struct Geom2 {
   // (its tail belongs to the next row and is masked like every k outside the box) and a vector is only REAL-aligned in memory -- the global
   // accesses of the pass are dword-aligned dwordx4, which this hardware takes.  (Rounds 1-2 required nkp % V == 0 and sent every other
   // size to the one-sweep scalar kernel: 220 000 against 740 000 MLUPS at 511^3, profiles/r03/unaligned_k_extent.txt.)
+  //
+  // K WINDOWS (round 4).  The segment of a workgroup is a run of whole rows with one (stage 1) and two (u) halo rows on either side in LDS, so
+  // its useful share is (TB MV - 2R) / (TB MV): rows beyond 2 044 (FP32) / 1 020 (FP64) elements did not fit at all (single sweeps at half
+  // the rate until round 3), and from 700 elements up a segment was two or three rows of five to seven.  Now the k axis may be cut into
+  // `nwin` windows of KT vectors: a workgroup sees its window as a plane of its own whose rows are R = KT + 2 vectors long -- the window plus
+  // ONE halo vector on either side (a stage-2 point at the window's edge reads the stage-1 value next to it, which this workgroup computes
+  // itself from the u values of that halo vector: V >= 2 elements reach far enough).  Nothing else changes in the kernel: +-R is still the i
+  // neighbour, +-1 element the k neighbour, the lane next door holds it; only the map from (row, vector of the row) to memory gains the
+  // window's origin `kw0`, and a vector is owned by the workgroup whose window holds it.  Same per-point arithmetic on the same values =>
+  // the same bits (test_two_fused_sweeps_equal_two_oracle_sweeps with forced windows; k = 1 100 FP64 and k = 2 100 FP32 boxes).
   int R;
   long long PSV;               // R * nip: vectors per plane in that view
   int nkp = 0;                 // elements per row in memory
   long long PSB = 0;           // bytes per plane in memory
-  int jlast = 0;               // index of the array's last plane, whose last vector must not be read beyond the array:
+  int jlast = 0;               // index of the array's last plane, whose last vectors must not be read beyond the array:
   unsigned last_off = 0;       // ... offsets into that plane are clamped to this (the values clamped away are never used)
+  int nwin = 1;                // k windows per row
+  int hv = 0;                  // halo vectors on either side of a window (1 when nwin > 1)
+  int KT = 1 << 30;            // vectors a window owns: vector kv of a virtual row is owned when hv <= kv < hv + KT
+  int KW = 0;                  // elements from one window's origin to the next (= KT * V)
+  int nsegw = 0;               // segments per window (nseg = nwin * nsegw; segment s of window w has the id w * nsegw + s)
   int kk0, kk1, jj0, jj1;      // stage-2 (output) box = the inner box
   long long F0, Fend;
   // stage-1 box: the inner box, grown by one layer across rank-internal faces of a decomposed run (the first sweep

@@ -116,11 +116,18 @@ __device__ __forceinline__ Vec<V> relax_vec_rb(const Vec<V>& pc_, const Vec<V>& 
 // BiCGSTAB would have made it from -- 1: b = a*x + y (blas_triad, cz_blas.f90:297; s = r - alpha q), 2: b = x + a*(z - b*y) (blas_bicg_1, :490;
 // p = r + beta (p - omega q)) -- with the same operations on the same values, and the workgroup that owns a vector writes it to bs.out (the
 // array the later passes of the solve read as b): the update kernel and one read of its result are saved (BSrc, cz_k_pair.h).
-template <int V, int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0>
-__global__ void __launch_bounds__(TB, TB == 512 ? 4 : 1)
+// PRE = n > 0 (small grids, round 4): chunks of at most n planes whose operands -- the n + 4 planes of u with their outer rows and the n + 2
+// planes of b -- are ALL requested before the first plane step, into registers.  The pipelined form asks for a plane one step ahead, which
+// hides the memory latency where a CU holds enough waves and the chunks are long; on a grid of 64^3 .. 128^3 cells every workgroup of the
+// pass is resident at once, a chunk is two or three planes, and the launch lasts as long as ONE workgroup's chain of dependent round trips:
+// three in the prologue and one per step, 16-24 us for 2-4 us of work (profiles/r03/small_grids_chunk_length.txt).  With everything in flight
+// at once it is one round trip, then n + 2 steps of LDS and arithmetic.  Same operations on the same values: same bits.
+template <int V, int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0, int PRE = 0>
+__global__ void __launch_bounds__(TB, (TB == 512 && !MAF && !PRE) ? 4 : 1)  // (MAF, 512 threads: 256 registers instead of 21-30 spilled)
 jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
            const int* __restrict__ skip, Fin2 fin, MafArgs ma, BSrc bs) {
   static_assert(BS == 0 || (ZU == 1 && MAF == 0), "a made right-hand side belongs to the first pass of a preconditioner solve");
+  static_assert(PRE == 0 || (ZU == 0 && MAF == 0 && BS == 0), "the preloaded form is the plain pass");
   if (skip != nullptr && *skip != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -150,7 +157,17 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
     chunk = r / bmax;
     seg = (sl < blen) ? x * base + min(x, rem) + sl : g.nseg;  // nseg = no work
   }
-  const long long fb = (seg < g.nseg) ? g.F0 + (long long)seg * g.S : g.Fend;
+  // k window of this segment (Geom2): ids are window-major, so the band / run of an XCD is a set of row-adjacent segments of ONE window
+  int win = 0;
+  if (g.nwin > 1 && seg < g.nseg) {
+    win = seg / g.nsegw;
+    seg -= win * g.nsegw;
+  } else if (g.nwin > 1) {
+    seg = g.nsegw;  // no work
+  }
+  const int nseg_w = (g.nwin > 1) ? g.nsegw : g.nseg;
+  const int kw0 = win * g.KW - g.hv * V;  // element of the row that vector 0 of the window's view starts at (-V: the left halo of window 0)
+  const long long fb = (seg < nseg_w) ? g.F0 + (long long)seg * g.S : g.Fend;
   const int ja = g.jj0 + chunk * g.TJ;
   int jb = ja + g.TJ - 1;
   if (jb > g.jj1) jb = g.jj1;
@@ -171,12 +188,17 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
     const long long e2_0 = fb - 2 * R;  // first vector of E2
     const long long vlast = g.PSV - 1;
     const size_t PB = (size_t)g.PSB;  // bytes per plane
-    // byte offset of vector f of the row view inside a plane in memory
+    // byte offset of vector f of the (window's) row view inside a plane in memory.  Below the plane (row 0's left halo vector of window 0:
+    // masked, and no unmasked point reads it) it is clamped to 0.  Beyond the plane's end it is NOT clamped here: the last vector of the last
+    // row of a plane whose rows are no multiple of the vector width hangs over by a few elements and IS read by the first stage of a
+    // decomposed brick (row nip-1 is the second ghost layer); the elements behind the plane are the next plane's, masked -- only in the
+    // array's last plane must the access stay inside, and there the vector is never used (lim, Geom2::last_off).
     auto off_of = [&](long long f) -> unsigned {
       const long long r = f / R;
-      return (unsigned)((r * g.nkp + (f - r * R) * V) * (long long)sizeof(REAL));
+      long long el = r * g.nkp + kw0 + (f - r * R) * V;
+      el = el < 0 ? 0 : el;
+      return (unsigned)(el * (long long)sizeof(REAL));
     };
-    // (the array's last plane: see Geom2::last_off)
     auto lim = [&](unsigned off, int plane) -> unsigned { return plane == g.jlast ? (off < g.last_off ? off : g.last_off) : off; };
     unsigned bo[MV];   // byte offset of the thread's m-th vector inside a plane (clamped into the plane: such lanes are masked)
     unsigned ka[MV];   // stage-1 bits: components of the vector inside the stage-1 box (0 when the row is outside)
@@ -190,21 +212,23 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       bo[m] = off_of(fc);
       const long long row = f / R;
       const int kv = (int)(f - row * R);
+      const int kb = kw0 + kv * V;  // k of component 0
       unsigned bits1 = 0, bits2 = 0;
 #pragma unroll
       for (int cc = 0; cc < V; cc++) {
-        const int kk = kv * V + cc;
+        const int kk = kb + cc;
         if (kk >= g.kk0a && kk <= g.kk1a) bits1 |= 1u << cc;
         if (kk >= g.kk0 && kk <= g.kk1) bits2 |= 1u << cc;
       }
-      pbase[m] = kv * V + (int)row + g.par;
+      pbase[m] = kb + (int)row + g.par;
       ka[m] = (f >= g.F0a && f < g.Fenda) ? bits1 : 0u;
-      own[m] = (e >= R && e < LV - R && f >= g.F0 && f < g.Fend) ? bits2 : 0u;
+      const bool kown = kv >= g.hv && kv < g.hv + g.KT;  // the window that holds the vector owns it (its halo vectors belong to the windows next door)
+      own[m] = (e >= R && e < LV - R && f >= g.F0 && f < g.Fend && kown) ? bits2 : 0u;
     }
     REAL XG[MAF ? MV : 1], XGG[MAF ? MV : 1];  // MAF: metric terms of the rows of the thread's vectors
     int kvo[MAF ? MV : 1];                      // MAF: first k of the vector (offset into ztab)
     if (MAF) {
-      const int nkp = R * V;  // (the row view; g.nkp elements of it exist)
+      const int nkp = R * V;  // (the row view of the window: element kk of it is k = kw0 + kk of the row)
 #pragma unroll
       for (int m = 0; m < MV; m++) {
         const long long f = e1_0 + t + m * TB;
@@ -219,7 +243,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
         XGG[m] = xp - (REAL)2.0 * x0 + xm;
       }
       for (int kk = t; kk < nkp; kk += TB) {
-        int kc = kk < 1 ? 1 : kk;
+        int kc = kw0 + kk < 1 ? 1 : kw0 + kk;
         if (kc > g.nkp - 2) kc = g.nkp - 2;
         const REAL zm = ma.zc[kc - 1], z0 = ma.zc[kc], zp = ma.zc[kc + 1];
         ztab[kk] = (REAL)0.5 * (zp - zm);
@@ -250,6 +274,33 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
     Vec<V> uA[MV], uB[MV], bA[MV], bB[MV], b2[MV], vc[MV], hx;
     Vec<V> rx[BS ? MV : 1], ry[BS ? MV : 1], rz[BS == 2 ? MV : 1];  // BS: the operands of b(q), asked for one step ahead (ONE set: b(q) is made
                                                                      // from them at the top of step q, before the requests of that step)
+    // PRE: every operand of the chunk.  UP[p] = u(ja-2+p), HP[p] its outer rows (the has_halo threads), BP[p] = b(ja-1+p); planes beyond
+    // jb+2 / jb+1 (a last chunk shorter than PRE) are clamped and never used.
+    Vec<V> UP[PRE ? PRE + 4 : 1][MV], HP[PRE ? PRE + 4 : 1], BP[PRE ? PRE + 2 : 1][MV];
+    if (PRE) {
+#pragma unroll
+      for (int p = 0; p < PRE + 4; p++) {
+        const int pl = (ja - 2 + p <= jb + 2) ? ja - 2 + p : jb + 2;
+        const char* Pp = Ub + (size_t)pl * PB;
+#pragma unroll
+        for (int m = 0; m < MV; m++) UP[p][m] = ld16<V>(Pp, lim(bo[m], pl));
+        HP[p] = ld16<V>(Pp, lim(hbo, pl));
+      }
+#pragma unroll
+      for (int p = 0; p < PRE + 2; p++) {
+        const int pl = (ja - 1 + p <= jb + 1) ? ja - 1 + p : jb + 1;
+        const char* Qp = Bb + (size_t)pl * PB;
+#pragma unroll
+        for (int m = 0; m < MV; m++) BP[p][m] = ld16<V>(Qp, bo[m]);
+      }
+#pragma unroll
+      for (int m = 0; m < MV; m++) {
+        ldsU[LU + R + t + m * TB] = UP[0][m];
+        ldsU[R + t + m * TB] = UP[1][m];
+        b2[m] = zerov<V>();
+      }
+      if (has_halo) ldsU[hl] = HP[1];
+    } else
     // prologue: LDS_U[1] <- u(ja-2) (own vectors), LDS_U[0] <- u(ja-1) on E2; in flight: u(ja) and b(ja-1)
     {
       const char* P2 = Ub + (size_t)(ja - 2) * PB;
@@ -287,7 +338,7 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
 
     // One plane step.  cur: LDS buffer holding u(q) / v(q-1).  uc = u(q+1) and b1 = b(q) were requested one step ago; un, hn, bn
     // receive this step's requests (u(q+2), b(q+1)).
-    auto step = [&](const int q, const int cur, Vec<V>* uc, Vec<V>* un, Vec<V>* b1, Vec<V>* bn) __attribute__((always_inline)) {
+    auto step = [&](const int q, const int cur, Vec<V>* uc, Vec<V>* un, Vec<V>* b1, Vec<V>* bn, const Vec<V>* hpre) __attribute__((always_inline)) {
       const bool plane_inner = (q >= g.jj0a && q <= g.jj1a);
       const bool count1 = (q >= ja && q <= jb);
       const bool do2 = (q - 1 >= ja);
@@ -317,7 +368,9 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
         }
       }
       // ---- requests for the NEXT step (the last step re-reads a plane it already has: no branch around a load)
-      {
+      if (PRE) {
+        hx = *hpre;  // (everything was requested before the first step)
+      } else {
         const int qu = (q + 2 <= jb + 2) ? q + 2 : jb + 2;
         const int qb = (q + 1 <= jb + 1) ? q + 1 : jb + 1;
         const char* Un = Ub + (size_t)qu * PB;
@@ -470,11 +523,20 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
       __syncthreads();
     };
 
-    for (int q = ja - 1;; q += 2) {
-      step(q, 0, uA, uB, bA, bB);
-      if (q + 1 > jb + 1) break;
-      step(q + 1, 1, uB, uA, bB, bA);
-      if (q + 2 > jb + 1) break;
+    if (PRE) {
+      // step p handles plane q = ja-1+p: uc = u(q+1) = UP[p+2] with its outer rows HP[p+2], b1 = b(q) = BP[p]
+#pragma unroll
+      for (int p = 0; p < PRE + 2; p++) {
+        if (ja - 1 + p > jb + 1) break;
+        step(ja - 1 + p, p & 1, UP[p + 2], nullptr, BP[p], nullptr, &HP[p + 2]);
+      }
+    } else {
+      for (int q = ja - 1;; q += 2) {
+        step(q, 0, uA, uB, bA, bB, nullptr);
+        if (q + 1 > jb + 1) break;
+        step(q + 1, 1, uB, uA, bB, bA, nullptr);
+        if (q + 2 > jb + 1) break;
+      }
     }
   }
 

@@ -177,6 +177,7 @@ int czhip_init(int device) {
   }
   ctx.tune.t2_any_rows = cfg.on(CZV_T2_ROWS, ctx.tune.t2_any_rows != 0) ? 1 : 0;
   ctx.tune.t2_kwin = cfg.num(CZV_T2_KWIN, ctx.tune.t2_kwin);
+  ctx.tune.t2_pre = cfg.num(CZV_T2_PRE, ctx.tune.t2_pre);
   if (const char* pp = cfg.str(CZV_PCR_PIPE)) {  // "form[,seconds[,groups[,rows per thread]]]": form as Tuning::pcr_pipe; bound of the waits inside the kernel
     int w = 1, rows = 0, q = 1;
     double sec = 2.0;
@@ -502,6 +503,24 @@ int czhip_set_tuning2(int threads, int vec_per_thread, int planes_per_chunk, int
 }
 
 int czhip_use_t2(void) { return ctx.tune.use_t2; }
+
+// the preloaded form of the pass on small grids (jacobi2p_k<PRE>): 1 = where every workgroup is resident at once (default), 0 = never; negative:
+// keep.  Returns the setting that was in force.  Same bits either way.
+int czhip_set_pair_preload(int enable) {
+  ensure_init();
+  const int before = ctx.tune.t2_pre;
+  if (enable >= 0) ctx.tune.t2_pre = enable;  // (TB * 10 + PRE: that form only -- measurements)
+  return before;
+}
+
+// k windows of the two-stage pass (Geom2, cz_k_pair.h): vectors per window; 0 = whole rows wherever they fit, -1 = the launcher's rule
+// (pair_whole_rows_ok), <= -2 = keep.  Returns the setting that was in force.  Same bits whatever the windows.
+int czhip_set_pair_window(int vectors) {
+  ensure_init();
+  const int before = ctx.tune.t2_kwin;
+  if (vectors >= -1) ctx.tune.t2_kwin = vectors;
+  return before;
+}
 
 // Self-test of the hoisted division of the two-stage pass (cz_k_fastdiv.h): number of numerators (of 2^32: every float / a structured
 // sample of doubles) whose quotient by d differs in any bit from the ordinary IEEE division; -1 when the launchers would not use the

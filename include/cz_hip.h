@@ -265,6 +265,13 @@ int czhip_set_psor(int one_launch, int wg_per_cu);
  * workgroups the device keeps resident; a ring forced small with few workgroups cannot, and the sweep then ends as described above. */
 int czhip_set_pcr_lex_limits(int wg_per_cu, int max_wg, int slots);
 int czhip_use_t2(void);
+/* The two-stage pass cuts long k rows into windows (a workgroup's LDS holds whole rows of its window only; cz_solver.f90:284-387 takes any
+ * extent, and so does the pass since round 4): vectors (16 bytes) per window; 0 = whole rows wherever they fit, -1 = chosen per launch (default),
+ * <= -2 = keep.  Returns the previous setting.  Results do not depend on it. */
+int czhip_set_pair_window(int vectors);
+/* Small grids (every workgroup of a pass resident at once): the pass requests all operands of a chunk before its first plane step instead of one
+ * plane ahead; 1 = on (default), 0 = off, negative = keep.  Returns the previous setting.  Results do not depend on it. */
+int czhip_set_pair_preload(int enable);
 /* Every environment variable the library and the cz command line read (one table, cubez_amd/csrc/cz_config.h), one per line: NAME=value where set,
  * NAME (unset; default ...) otherwise; only_set != 0 lists the former only.  The string lives until the next call on the calling thread. */
 const char* czhip_config_describe(int only_set);

@@ -239,13 +239,28 @@ T2_BOXES = [((40, 36, 60), None), ((33, 70, 124), None), ((130, 20, 252), None),
             ((24, 20, 28), (1, 24, 1, 20, 1, 28)), ((64, 9, 60), None), ((96, 40, 508), None),
             # row lengths that are no multiple of the vector width (round 3: the pass takes them; nk + 4 = 65, 127, 130, 257, 63, 511)
             ((40, 36, 61), None), ((33, 50, 123), None), ((70, 20, 126), None), ((29, 31, 253), None),
-            ((24, 20, 59), (1, 24, 1, 20, 1, 59)), ((31, 23, 507), None)]
+            ((24, 20, 59), (1, 24, 1, 20, 1, 59)), ((31, 23, 507), None),
+            # rows beyond what a segment of whole rows holds (round 4: the pass cuts k into windows; VERDICT r3 missing 2): 1 104 and 2 104 elements
+            ((9, 7, 1100), None), ((7, 6, 2100), None)]
 T2_TUNINGS = [(512, 2, 32), (512, 2, 5), (512, 2, 7), (512, 2, 16), (-2, 2, 0), (1024, 2, 16), (1024, 2, 11), (1024, 2, 4)]  # (-2, 2, 0): shape and chunk chosen by the library
+
+
+@pytest.fixture(params=[-1, 6, 17], ids=["rule", "win6", "win17"])
+def kwin(request):
+    """k windows of the two-stage pass (Geom2): the launcher's rule (whole rows where a segment of them is a decent share of a workgroup, else
+    windows of 64 vectors), and windows of 6 / 17 vectors forced on every box -- 3 to 90 windows per row, partial last windows, windows that
+    start at no multiple of anything.  Results must not depend on it."""
+    hs = [_hip(p) for p in ("f32", "f64")]
+    for h in hs:
+        h.lib.czhip_set_pair_window(request.param)
+    yield request.param
+    for h in hs:
+        h.lib.czhip_set_pair_window(-1)
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("box", T2_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in T2_BOXES])
-def test_two_fused_sweeps_equal_two_oracle_sweeps(prec, box):
+def test_two_fused_sweeps_equal_two_oracle_sweeps(prec, box, kwin):
     """czhip_jacobi2_async (temporal blocking) == two applications of the oracle's jacobi, bit for bit; both residuals."""
     (ni, nj, nk), idx = box
     sz = [ni, nj, nk]
@@ -283,7 +298,7 @@ def test_two_fused_sweeps_equal_two_oracle_sweeps(prec, box):
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("box", T2_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in T2_BOXES])
-def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
+def test_fused_red_black_iteration_equals_two_colour_calls(prec, box, kwin):
     """czhip_rbsor2_async (both colours in one pass, out of place) == psor2sma_core colour 0 + colour 1 of the oracle."""
     (ni, nj, nk), idx = box
     sz = [ni, nj, nk]
@@ -320,7 +335,7 @@ def test_fused_red_black_iteration_equals_two_colour_calls(prec, box):
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("box", [(40, 36, 60), (33, 50, 123), (29, 31, 253), (70, 20, 126)], ids=lambda b: "x".join(map(str, b)))
 @pytest.mark.parametrize("rb", [-1, 0, 1], ids=["jacobi_pair", "rb_ofst0", "rb_ofst1"])
-def test_first_pass_of_a_preconditioner_solve_from_a_literal_zero(prec, box, rb):
+def test_first_pass_of_a_preconditioner_solve_from_a_literal_zero(prec, box, rb, kwin):
     """czhip_jacobi2_from_zero_made_async: the start vector is not read (a literal zero) and the right-hand side is read (op 0) or made on the
     way from the operands of blas_triad_ (op 1) / blas_bicg_1_ (op 2) and stored.  == the vector update launched on its own, then the pass on a
     cleared start vector; output field and stored right-hand side bit for bit.  Rows that are no multiple of the vector width included."""
@@ -438,7 +453,7 @@ def test_maf_random_boxes_vs_oracle(prec, box):
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("box", T2_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in T2_BOXES])
-def test_maf_two_stage_pass_equals_two_oracle_sweeps(prec, box):
+def test_maf_two_stage_pass_equals_two_oracle_sweeps(prec, box, kwin):
     """czhip_pair_maf_async (VERDICT r1 "missing" 6: the MAF flavour of the two-stage pass, cz_maf.f90:131-438) on stretched grids ==
     two jacobi_maf sweeps / colour 0 + colour 1 of psor2sma_core_maf of the oracle, bit for bit, in every kernel shape."""
     (ni, nj, nk), idx = box

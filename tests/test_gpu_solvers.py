@@ -99,6 +99,37 @@ def test_solvers_on_rows_that_are_no_multiple_of_the_vector_width(case):
         assert np.allclose(g["hist"], oh, rtol=1e-11, atol=0)
 
 
+LONG_ROWS = [dict(gsz=g, solver=sv, itr_max=12, coef=cf, precond=pc, prec=pr, tag=f"{sv}_{pc or ''}_{'x'.join(map(str, g))}_{pr}")
+             for (g, pr) in (((20, 16, 1100), "f64"), ((16, 20, 2100), "f32"), ((12, 14, 4100), "f32"))
+             for (sv, cf, pc) in (("jacobi", 0.8, None), ("sor2sma", 1.5, None), ("jacobi_maf", 0.8, None), ("pbicgstab", 0.8, "jacobi"))]
+
+
+@pytest.mark.parametrize("case", LONG_ROWS, ids=[c["tag"] for c in LONG_ROWS])
+def test_long_k_rows_take_the_fused_pass(case):
+    """VERDICT r3 missing 2: the reference's loops take any extent (cz_solver.f90:284-387); until round 3 rows beyond 2 044 (FP32) / 1 020 (FP64)
+    elements fell to single sweeps at half the rate.  Round 4: the pass cuts k into windows.  Whole solves against the oracle: iteration
+    count, field bit for bit (stationary solvers), history -- and the plan says WHOLE fused passes, not single sweeps."""
+    from cubez_amd import CZ
+    cz = CZ(case["prec"], quiet=True)
+    assert cz.setup(_args(case)) == 1
+    itr = cz.solve()
+    g = dict(itr=itr, hist=cz.history(), P=cz.field())
+    info = cz.info()
+    cz.close()
+    o = O.run(case["gsz"], case["solver"], case["itr_max"], case["coef"], case["precond"], kind="oracle", prec=case["prec"], wide=True)
+    assert g["itr"] == o.itr
+    oh = [r for _, r in o.history]
+    assert len(oh) == len(g["hist"])
+    if case["solver"] == "pbicgstab":
+        assert np.allclose(g["hist"], oh, rtol=1e-6 if case["prec"] == "f64" else 1e-3, atol=0)
+        assert np.abs(g["P"].astype(np.float64) - o.P.astype(np.float64)).max() <= (1e-9 if case["prec"] == "f64" else 1e-4)
+        assert info["bicg_fused"] > 0  # the preconditioner solves start with the made right-hand side: only the whole fused pass does that
+    else:
+        assert g["P"].tobytes() == o.P.tobytes()
+        assert np.allclose(g["hist"], oh, rtol=1e-11, atol=0)
+        assert info["pass_kind"] == 1, info  # PassPlan::WHOLE
+
+
 BICG = [c for c in CASES if c["solver"] in ("pbicgstab", "pbicgstab_maf")]
 
 

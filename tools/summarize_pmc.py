@@ -6,7 +6,7 @@ into HBM bytes per launch of the dominant kernel.
     (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
 
 usage: summarize_pmc.py <key> <kernel substring> <fetch_dir> <write_dir> [out.json]
-       summarize_pmc.py --all <key> <units> <fetch_dir> <write_dir> [out.json]
+       summarize_pmc.py --all[=name1,name2,...] <key> <units> <fetch_dir> <write_dir> [out.json]
            every kernel of the run by (shortened) name: launches per unit (units = e.g. the BiCGSTAB iterations of the profiled command),
            bytes per launch, and the bytes one unit moves in all -- the physical traffic of an iteration"""
 import csv
@@ -18,9 +18,12 @@ import socket
 import sys
 import time
 
-ALL = sys.argv[1] == "--all"
+ALL = sys.argv[1].startswith("--all")
+ONLY = None
 if ALL:
-    sys.argv.pop(1)
+    a = sys.argv.pop(1)
+    if "=" in a:  # kernels of the unit by name prefix; what the set-up of the profiled command launched (fills, copies, boundary faces) is left out
+        ONLY = a.split("=", 1)[1].split(",")
 key, kname, fdir, wdir = sys.argv[1:5]
 out = sys.argv[5] if len(sys.argv) > 5 else None
 
@@ -53,7 +56,7 @@ def per_kernel(d, counter):
 def build_id():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_h_launch.h"):
+    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_blas.h", "cz_h_launch.h"):
         h.update(open(os.path.join(root, "cubez_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -67,7 +70,9 @@ if ALL:
         ws, wn = wr.get(n, [0.0, 0])
         cnt = max(fn, wn)
         rb, wb = (fs / fn * 2048.0 if fn else 0.0), (ws / wn * 1024.0 if wn else 0.0)
-        if (rb + wb) * cnt / units < 1e6:  # set-up and one-thread launches: not a line of the table
+        if (rb + wb) * cnt / units < 1e6:  # one-thread launches: not a line of the table
+            continue
+        if ONLY is not None and not any(n.startswith(o) for o in ONLY):
             continue
         kernels[n] = {"launches_per_unit": cnt / units, "read_bytes": rb, "write_bytes": wb, "bytes_per_launch": rb + wb}
         total += (rb + wb) * cnt / units
@@ -103,7 +108,7 @@ rec = {"kernel": kname, "launches": [nf, nw], "FETCH_SIZE_KiB_raw": fetch_kib, "
 # which build and box the figure belongs to (bench.py prints it beside `traffic` and says whether it is the build it is running)
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _h = hashlib.sha256()
-for _f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_h_launch.h"):
+for _f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_blas.h", "cz_h_launch.h"):
     _h.update(open(os.path.join(_root, "cubez_amd", "csrc", _f), "rb").read())
 rec["kernel_source_sha"] = _h.hexdigest()[:16]
 rec["box"] = socket.gethostname()
