@@ -18,7 +18,7 @@ enum CzVar {
   // ---- launcher (one process per GPU; set by torch.distributed.run, srun, a wrapper script ...)
   CZV_RANK, CZV_WORLD_SIZE, CZV_LOCAL_RANK, CZV_MASTER_ADDR, CZV_MASTER_PORT, CZV_JOB_ID, CZV_COMM_ID_FILE,
   // ---- driver (CZ)
-  CZV_COMM_DEBUG, CZV_OVERLAP, CZV_LAG_REDUCE, CZV_COMM_CUS, CZV_BICG_FUSE, CZV_BICG_DEVSC, CZV_BICG_ALIAS, CZV_BICG_SPMV, CZV_MULTIPASS, CZV_SPH, CZV_PROFILE, CZV_TEST_SKEW,
+  CZV_COMM_DEBUG, CZV_OVERLAP, CZV_LAG_REDUCE, CZV_COMM_CUS, CZV_BICG_FUSE, CZV_BICG_DEVSC, CZV_BICG_ALIAS, CZV_SPH, CZV_PROFILE, CZV_TEST_SKEW,
   // ---- transport (cz_comm.cpp)
   CZV_COMM_TIMEOUT, CZV_COMM_PACK_J, CZV_COMM_ONE_COMM,
   // ---- kernels (czhip_init)
@@ -50,8 +50,6 @@ inline const CzVarDef* cz_var_defs() {
       {"CZ_BICG_FUSE", "1", "BiCGSTAB: the vector updates that make a preconditioner solve's right-hand side are made by its first pass"},
       {"CZ_BICG_DEVSC", "1", "BiCGSTAB: alpha and omega made on the device behind their dot products (one host wait per iteration)"},
       {"CZ_BICG_ALIAS", "1", "BiCGSTAB without a preconditioner: the solves read p and s themselves instead of cleared-and-copied p_, s_"},
-      {"CZ_BICG_SPMV", "1", "BiCGSTAB + Jacobi: q = A p_ / t_ = A s_ (with their dot products) computed by the last pass of the preconditioner solve"},
-      {"CZ_MULTIPASS", "1", "small grids: several fused passes per launch with a grid-wide barrier between them (every workgroup resident)"},
       {"CZ_SPH", "0", "write p_%05d.sph / e_%05d.sph like the reference's -D_aurora_=1 build (cz_utility.f90:17-47)"},
       {"CZ_PROFILE", "1", "cz command line: write profiling.txt (cz_Evaluate.cpp:506-545)"},
       {"CZ_TEST_SKEW", "", "test aid \"rank,milliseconds\": that rank sleeps before every look at the convergence flag"},

@@ -551,7 +551,7 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
     HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 256, ctx.stream));
   }
   ensure_partials((size_t)ncols);
-  const int per_cu = ctx.tune.psor_wg_per_cu > 0 ? std::min(ctx.tune.psor_wg_per_cu, 8) : 1;  // (what a CU holds: registers and 70 KB of LDS per column)
+  const int per_cu = ctx.tune.psor_wg_per_cu > 0 ? std::min(ctx.tune.psor_wg_per_cu, 8) : (ma ? 1 : 2);  // (what a CU holds: 12 waves of <= 168 registers and 2 x 71 KB of LDS)
   const int ntickets = ctx.psor_ntickets;
   const unsigned nblk = (unsigned)std::min(ntickets, ctx.num_cu * per_cu);
   const unsigned seq = ++ctx.psor_seq;

@@ -58,9 +58,17 @@ __device__ __forceinline__ void pc_load(const REAL* __restrict__ p, REAL* o) {
 // CU holds one workgroup: ten waves spread over the four SIMDs as 3, 3, 2, 2 and fit the 3 waves per SIMD that ~150 registers allow, two
 // workgroups of six waves (2, 2, 1, 1 each) do not.
 constexpr int psor_col_threads(int nc) { return nc * PC_T * PC_T + 128; }
+// Round 4: TWO workgroups per CU.  The timeline of round 3 (profiles/r03/psor_col_per_column_timeline_512_f32.txt) shows what bounded the sweep
+// besides the chain: one column per CU = 256 columns in flight of 1 024, four rounds of ~245 us (540 steps x 0.45 us) = 0.98 ms whatever
+// the chain does.  A step is latency (one barrier, one LDS round trip, one division), so two independent columns share a CU almost for
+// free -- if their registers fit: 12 waves per CU = 3 per SIMD = 168 registers per thread.  The kernel had 203: the ring of the OLD-halo
+// line (32 registers in every computing thread, used by 32 of 256) moved to the idle half of the taking wave.
+#ifndef PSOR_MIN_WAVES
+#define PSOR_MIN_WAVES 3
+#endif
 
 template <int MAF, int NC>
-__global__ void __launch_bounds__(psor_col_threads(NC))
+__global__ void __launch_bounds__(psor_col_threads(NC), MAF ? 2 : PSOR_MIN_WAVES)  // (MAF: 30-50 registers more; one column per CU as before)
 psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom g, const int* __restrict__ order, int ntickets, unsigned* ctl,
            unsigned long long* faces, unsigned seq, long long spin_limit, double* partials, double* dst, int accumulate, unsigned* counter,
            const int* __restrict__ skip, MafArgs ma, long long* prof) {
@@ -136,14 +144,6 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       const int gic = min(gi, g.ii1 + 1), gjc = min(gj, g.jj1 + 1);
       REAL* line = P + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;  // element k = 0 of this thread's line
       const REAL* bline = B + (size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj;
-      // the OLD halo, served by lanes 0..31 of wave 0 as virtual threads (hi, hj) of the plane: (16, lane) and (lane - 16, 16)
-      const bool halo_wave = (wv & 3) == 0;
-      const bool is_halo = tc < 32;
-      const int hi = (tc < 16) ? PC_T : (tc & 15), hj = (tc < 16) ? (tc & 15) : PC_T;
-      const int hli = (hi + 1) + PC_L * (hj + 1);
-      const int hgi = is_halo ? min(I0 + hi, g.ii1 + 1) : g.ii0, hgj = is_halo ? min(J0 + hj, g.jj1 + 1) : g.jj0;
-      const REAL* hline = P + (size_t)g.kk0 + (size_t)hgi * si + (size_t)hgj * sj;  // (other threads: one common line, never used)
-      const int hk0 = -hi - hj;  // the virtual thread's k at step 0
       // this line's place in the grid of 128-byte memory lines: element k sits at position phi + k (P is 256-byte aligned)
       const int phi = (int)((((size_t)g.kk0 + (size_t)gic * si + (size_t)gjc * sj) + (reinterpret_cast<size_t>(P) / sizeof(REAL))) % EL);
       int next_line = 0;  // lines of this thread's row stored so far (line n holds the positions n EL .. n EL + EL - 1)
@@ -181,30 +181,27 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       }
       // ---- line streams.  Group `grp` covers the steps s = G grp .. G grp + G - 1, i.e. this thread's k = kb .. kb + G - 1 with
       // kb = G grp - i - j.  The loop body is unrolled over NG = 4 groups, so that the streams live in register rings with compile-time
-      // indices and nothing in flight is ever copied: pbuf[G q + u] = p_old(kb + u) of group slot q, bbuf likewise b, hbuf the halo lane's
-      // line (hbuf[m + 2] is what it publishes at step m).  A group uses its own slot and the first two entries of the next; when it is
+      // indices and nothing in flight is ever copied: pbuf[G q + u] = p_old(kb + u) of group slot q, bbuf likewise b.  A group uses its own slot and the first two entries of the next; when it is
       // done its slot is asked for again, for the group NG groups ahead -- three groups (12 steps) before the first use.  Every load is
       // unconditional: elements before k = -1 or behind k = nk belong to the neighbouring rows of the padded array (the launcher makes sure
       // they exist) and are never used; k = -1 and k = nk ARE the boundary values the first / last point needs.
-      REAL pbuf[NS], bbuf[NS], hbuf[NS];
+      REAL pbuf[NS], bbuf[NS];
 #pragma unroll
       for (int q = 0; q < NG; q++) {
         pc_load<G>(line + (G * q - i - j), &pbuf[G * q]);
         pc_load<G>(bline + (G * q - i - j), &bbuf[G * q]);
-        pc_load<G>(hline + (G * q + hk0), &hbuf[G * q]);
       }
       REAL prev_new = line[-1];  // new value of k - 1 of the first point: the low boundary
       // (consumed here, once: a loop-carried register that starts life as a load makes the compiler wait for ALL loads in flight -- the
       // streams asked for twelve steps ahead -- at every use inside the loop)
       asm volatile("" : "+v"(prev_new));
-      // What the planes hold for step s + 1 is published in step s: the new value of this thread's k (read as i-1 / j-1 next door), its old
-      // value two points ahead (read as i+1 / j+1), and -- wave 0 -- the OLD halo.
-      auto publish = [&](int nxt, REAL nv, REAL old2, REAL hv) __attribute__((always_inline)) {
+      // What the planes hold for step s + 1 is published in step s: the new value of this thread's k (read as i-1 / j-1 next door) and its old
+      // value two points ahead (read as i+1 / j+1); the halos of both planes come from the taking wave.
+      auto publish = [&](int nxt, REAL nv, REAL old2) __attribute__((always_inline)) {
         sNEW[cs][nxt][li] = nv;
         sOLD[cs][nxt][li] = old2;
-        if (halo_wave && is_halo) sOLD[cs][nxt][hli] = hv;  // old value two points ahead of the virtual thread's k
       };
-      publish(0, (REAL)0, pbuf[1], hbuf[1]);  // step -1: nothing is computed, the planes of step 0 are published
+      publish(0, (REAL)0, pbuf[1]);  // step -1: nothing is computed, the planes of step 0 are published
       lds_barrier();
 
       for (int sg = 0; sg < ngroups; sg += NG) {
@@ -241,13 +238,12 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
               prev_new = nv;
             }
             if (active) sOUT[cs][(phi + k) % (2 * EL)][tc] = nv;
-            publish(nxt, nv, pbuf[(m + 2) % NS], hbuf[(m + 2) % NS]);
+            publish(nxt, nv, pbuf[(m + 2) % NS]);
             lds_barrier();
           }
           // ---- this group's slot of the rings is free: ask for the runs NG groups ahead
           pc_load<G>(line + kb + NS, &pbuf[G * q]);
           pc_load<G>(bline + kb + NS, &bbuf[G * q]);
-          pc_load<G>(hline + (G * grp + hk0) + NS, &hbuf[G * q]);
         }
         // ---- the lines completed in this loop body (NS steps <= EL: at most one per thread, two entries of the ring are never in doubt)
         flush_lines(G * (sg + NG) - 1 - i - j, false);
@@ -301,8 +297,18 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       const int hgi = takes ? min(max(I0 + hi, g.ii0 - 1), g.ii1 + 1) : g.ii0, hgj = takes ? min(max(J0 + hj, g.jj0 - 1), g.jj1 + 1) : g.jj0;
       const REAL* hline = P + (size_t)g.kk0 + (size_t)hgi * si + (size_t)hgj * sj;
       const int hk0 = -hi - hj;  // = 1 - hc: the virtual thread's k at step 0
+      // Lanes 32..63 (NC = 1: otherwise idle): the OLD halo, i = 16 / j = 16 of the planes -- old values of the column on the high side or of
+      // the boundary, which the last row / column of computing threads reads as i+1 / j+1.  Virtual threads (16, v) and (v - 16, 16), v = lane
+      // - 32; at step s such a thread's own k is s - hi - hj and it publishes, like every thread, the old value two points ahead.
+      static_assert(NC == 1, "the OLD halo rides on the idle half of the taking wave");
+      const int ov = lane & 31;
+      const bool olds = lane >= 32;
+      const int ohi = (ov < 16) ? PC_T : (ov & 15), ohj = (ov < 16) ? (ov & 15) : PC_T;
+      const int ohli = (ohi + 1) + PC_L * (ohj + 1);
+      const REAL* oline = P + (size_t)g.kk0 + (size_t)min(I0 + ohi, g.ii1 + 1) * si + (size_t)min(J0 + ohj, g.jj1 + 1) * sj;
+      const int ok0 = 2 - ohi - ohj;
       unsigned long long rq[8][HW];
-      REAL bq[8];
+      REAL bq[8], oq[8];
       // A given-up wait is a private matter of this wave until the last step of the loop body it happened in: sh[2] is written only in front
       // of that step's barrier, so every wave of the workgroup reads the same value behind it (written in mid-body, waves that had passed
       // the body's last barrier but not yet looked could disagree with those that had, and the barrier counts would part -- ADVICE r3).
@@ -314,6 +320,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
 #pragma unroll
         for (int w = 0; w < HW; w++) rq[slot][w] = __hip_atomic_load(q + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bq[slot] = hline[min(max(hk, -1), g.nk)];
+        oq[slot] = oline[min(max(s + ok0, -1), g.nk)];
       };
       auto take = [&](int nxt, int slot, int s) __attribute__((always_inline)) {
         const int hk = s + hk0;
@@ -340,6 +347,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
         if (sizeof(REAL) == 8) rv = (REAL)__longlong_as_double((long long)((rq[slot][0] & 0xffffffffull) | (rq[slot][HW - 1] << 32)));
         else rv = (REAL)__uint_as_float((unsigned)(rq[slot][0] & 0xffffffffull));
         if (takes) sNEW[cs][nxt][hli] = need ? rv : bq[slot];  // (a face lane outside its range publishes something nobody reads)
+        if (olds) sOLD[cs][nxt][ohli] = oq[slot];
         ask(slot, s + 8);
       };
 #pragma unroll

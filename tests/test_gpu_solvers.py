@@ -222,9 +222,8 @@ def _fused_equals_unfused(prec, gsz, pc, monkeypatch):
     same values: history and field of the solve equal those of the solve with the updates launched (CZ_BICG_FUSE=0), bit for bit."""
     from cubez_amd import CZ
     # every switch of the iteration alone and all together (ADVICE r3: one switch used to turn three changes off at once, so a regression
-    # could not be localised): made right-hand sides, alpha / omega on the device, p_ / s_ aliased where the preconditioner is a copy,
-    # SpMV folded into the last pass of the preconditioner solve
-    names = ("CZ_BICG_FUSE", "CZ_BICG_DEVSC", "CZ_BICG_ALIAS", "CZ_BICG_SPMV")
+    # could not be localised): made right-hand sides, alpha / omega on the device, p_ / s_ aliased where the preconditioner is a copy
+    names = ("CZ_BICG_FUSE", "CZ_BICG_DEVSC", "CZ_BICG_ALIAS")
     combos = {"all": {}, "none": {k: "0" for k in names}}
     combos.update({f"no_{k[8:].lower()}": {k: "0"} for k in names})
     out = {}
