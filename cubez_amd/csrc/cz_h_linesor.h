@@ -557,11 +557,15 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
   const unsigned seq = ++ctx.psor_seq;
   ScopedTimer tm(LBL_PSOR);
   HIP_CHECK(hipMemsetAsync(ctx.psor_ctl, 0, 2 * sizeof(unsigned), ctx.stream));  // ticket and error word ([2]: sticky "a sweep gave up")
+  // (steps ahead of their use at which the face words are asked for: psor_col_k, AH)
   if (ma)
-    hipLaunchKernelGGL((psor_col_k<1, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
+    hipLaunchKernelGGL((psor_col_k<1, NC, 4>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
                        ctx.psor_faces, seq, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, *ma, nullptr);
+  else if (sizeof(REAL) == 4 && g.nk > 300)
+    hipLaunchKernelGGL((psor_col_k<0, NC, 8>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
+                       ctx.psor_faces, seq, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs(), nullptr);
   else
-    hipLaunchKernelGGL((psor_col_k<0, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
+    hipLaunchKernelGGL((psor_col_k<0, NC, 4>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
                        ctx.psor_faces, seq, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs(), nullptr);
   HIP_CHECK(hipGetLastError());
   return true;

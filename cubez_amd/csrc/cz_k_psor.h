@@ -67,7 +67,7 @@ constexpr int psor_col_threads(int nc) { return nc * PC_T * PC_T + 128; }
 #define PSOR_MIN_WAVES 3
 #endif
 
-template <int MAF, int NC>
+template <int MAF, int NC, int AH_>
 __global__ void __launch_bounds__(psor_col_threads(NC), MAF ? 2 : PSOR_MIN_WAVES)  // (MAF: 30-50 registers more; one column per CU as before)
 psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom g, const int* __restrict__ order, int ntickets, unsigned* ctl,
            unsigned long long* faces, unsigned seq, long long spin_limit, double* partials, double* dst, int accumulate, unsigned* counter,
@@ -307,8 +307,18 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       const int ohli = (ohi + 1) + PC_L * (ohj + 1);
       const REAL* oline = P + (size_t)g.kk0 + (size_t)min(I0 + ohi, g.ii1 + 1) * si + (size_t)min(J0 + ohj, g.jj1 + 1) * sj;
       const int ok0 = 2 - ohi - ohj;
-      unsigned long long rq[8][HW];
-      REAL bq[8], oq[8];
+      // AH: how many steps ahead of their use the face words (and the halo values) are asked for.  A word can only be there when the column on the
+      // low side is 16 steps (the skew of a column) + 1 (its feeding wave) + AH steps ahead, plus the time a write-through store takes to
+      // become visible: a request that comes back without this sweep's number is repeated at the step of its use, with the whole memory
+      // latency exposed, so a column settles that far behind the one it follows -- the ask-ahead distance is part of EVERY hop of the chain
+      // (62 hops at 512^3).  Round 3 asked 8 steps ahead (3.6 us at 0.45 us per step).  Measured (profiles/r04/psor_what_bounds_it.txt): 4 steps
+      // ahead shorten the chain -- 256^3 FP32 0.408 -> 0.366 ms, 512^3 FP64 2.14 -> 2.01, MAF 1.88 -> 1.82 -- but at 512^3 FP32, where most
+      // columns run long after the ones they depend on, 1.8 us no longer covers a load under full memory traffic: 1.22 -> 1.27 ms.  The launcher
+      // picks 8 for FP32 boxes of more than 300 points along k and 4 otherwise.
+      constexpr int AH = AH_;
+      static_assert(AH == 2 || AH == 4 || AH == 8, "ring of request slots with compile-time indices");
+      unsigned long long rq[AH][HW];
+      REAL bq[AH], oq[AH];
       // A given-up wait is a private matter of this wave until the last step of the loop body it happened in: sh[2] is written only in front
       // of that step's barrier, so every wave of the workgroup reads the same value behind it (written in mid-body, waves that had passed
       // the body's last barrier but not yet looked could disagree with those that had, and the barrier counts would part -- ADVICE r3).
@@ -348,16 +358,16 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
         else rv = (REAL)__uint_as_float((unsigned)(rq[slot][0] & 0xffffffffull));
         if (takes) sNEW[cs][nxt][hli] = need ? rv : bq[slot];  // (a face lane outside its range publishes something nobody reads)
         if (olds) sOLD[cs][nxt][ohli] = oq[slot];
-        ask(slot, s + 8);
+        ask(slot, s + AH);
       };
 #pragma unroll
-      for (int m = -1; m < 7; m++) ask(m & 7, m);
-      take(0, 7, -1);  // step -1
+      for (int m = -1; m < AH - 1; m++) ask(m & (AH - 1), m);
+      take(0, AH - 1, -1);  // step -1
       lds_barrier();
       for (int s0 = 0; s0 < G * ngroups; s0 += 8) {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-          take((m & 1) ^ 1, m, s0 + m);
+          take((m & 1) ^ 1, m & (AH - 1), s0 + m);
           if (m == 7 && (s0 & (NS - 1)) == NS - 8 && __builtin_amdgcn_ballot_w64(gave_up) != 0ull && lane == 0) sh[2] = 1;
           lds_barrier();
         }

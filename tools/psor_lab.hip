@@ -158,8 +158,8 @@ int main(int argc, char** argv) {
     seq++;
     HIP_CHECK(hipEventRecord(e0, 0));
     HIP_CHECK(hipMemsetAsync(ctl, 0, 256, 0));
-    if (maf) hipLaunchKernelGGL((psor_col_k<1, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, 0, P2, B, c, q, d_order, ntickets, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
-    else hipLaunchKernelGGL((psor_col_k<0, NC>), dim3(nblk), dim3(psor_col_threads(NC)), 0, 0, P2, B, c, q, d_order, ntickets, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
+    if (maf) hipLaunchKernelGGL((psor_col_k<1, NC, 4>), dim3(nblk), dim3(psor_col_threads(NC)), 0, 0, P2, B, c, q, d_order, ntickets, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
+    else hipLaunchKernelGGL((psor_col_k<0, NC, (sizeof(REAL) == 4 ? 8 : 4)>), dim3(nblk), dim3(psor_col_threads(NC)), 0, 0, P2, B, c, q, d_order, ntickets, ctl, faces, seq, 200000000LL, partials, dst + 1, 0, counter, nullptr, ma, prof);
     HIP_CHECK(hipEventRecord(e1, 0));
     HIP_CHECK(hipEventSynchronize(e1));
     HIP_CHECK(hipGetLastError());
