@@ -187,7 +187,8 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   // CZHIP_T2_KWIN / ctx.tune.t2_kwin: > 0 = vectors per window, 0 = whole rows wherever they fit, -1 = this rule
   const bool whole_fits = 2 * Rfull <= TB && 4 * Rfull < TB * MV;  // the outer rows are staged by 2R threads / halo rows would dominate
   int want = ctx.tune.t2_kwin;
-  if (want < 0) want = (whole_fits && pair_whole_rows_ok(Rfull, TB * MV)) ? 0 : kPairWin;
+  if (want < 0) want = (whole_fits && (pair_whole_rows_ok(Rfull, TB * MV) || BS)) ? 0 : kPairWin;  // (BS: the pass that makes its right-hand side reads
+                                                                                                     // three or four arrays; the halo vectors of two windows cost it 6-8 % at 512^3 FP64)
   if (want == 0 && !whole_fits) want = kPairWin;
   g.R = Rfull;
   if (want > 0 && want < Rfull) {

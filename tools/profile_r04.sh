@@ -34,7 +34,7 @@ if [ $what = pmc64 ] || [ $what = all ]; then
     rocprofv3 --pmc $c -d $O/pmc_bicg_$c --output-format csv -- python3 bench.py --solver pbicgstab --prec f64 --no-cpu-baseline --steps 6 --warmup 2 --repeats 1 --settle 0 > $O/pmc_bicg_$c.log 2>&1 || exit 1
     rocprofv3 --pmc $c -d $O/pmc_jac64_$c --output-format csv -- python3 bench.py --prec f64 $PMCARGS > $O/pmc_jac64_$c.log 2>&1 || exit 1
   done
-  python3 tools/summarize_pmc.py '--all=jacobi2p_k,stencil_k<2, 512, 2, 0, 2,ewise_k,triad_dots_k' bicg_512_f64 8 $O/pmc_bicg_FETCH_SIZE $O/pmc_bicg_WRITE_SIZE $O/hbm_traffic.json > $O/hbm_bicg.txt || exit 1
+  python3 tools/summarize_pmc.py '--all=jacobi2p_k;stencil_k<2, 512, 2, 0, 2;ewise_k;triad_dots_k' bicg_512_f64 8 $O/pmc_bicg_FETCH_SIZE $O/pmc_bicg_WRITE_SIZE $O/hbm_traffic.json > $O/hbm_bicg.txt || exit 1
   python3 tools/summarize_pmc.py jacobi2_512_f64 jacobi2p_k $O/pmc_jac64_FETCH_SIZE $O/pmc_jac64_WRITE_SIZE $O/hbm_traffic.json > $O/hbm_jac64.txt || exit 1
   rm -rf $O/pmc_bicg_*/*/*.db $O/pmc_jac64_*  # (the counter csv of the BiCGSTAB passes stays for re-summarising)
   cat $O/hbm_bicg.txt $O/hbm_jac64.txt

@@ -6,7 +6,7 @@ into HBM bytes per launch of the dominant kernel.
     (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
 
 usage: summarize_pmc.py <key> <kernel substring> <fetch_dir> <write_dir> [out.json]
-       summarize_pmc.py --all[=name1,name2,...] <key> <units> <fetch_dir> <write_dir> [out.json]
+       summarize_pmc.py --all[=name1;name2;...] <key> <units> <fetch_dir> <write_dir> [out.json]
            every kernel of the run by (shortened) name: launches per unit (units = e.g. the BiCGSTAB iterations of the profiled command),
            bytes per launch, and the bytes one unit moves in all -- the physical traffic of an iteration"""
 import csv
@@ -23,7 +23,7 @@ ONLY = None
 if ALL:
     a = sys.argv.pop(1)
     if "=" in a:  # kernels of the unit by name prefix; what the set-up of the profiled command launched (fills, copies, boundary faces) is left out
-        ONLY = a.split("=", 1)[1].split(",")
+        ONLY = a.split("=", 1)[1].split(";")  # (";": kernel names contain commas)
 key, kname, fdir, wdir = sys.argv[1:5]
 out = sys.argv[5] if len(sys.argv) > 5 else None
 
