@@ -14,6 +14,7 @@ struct Tuning {
   int t2_any_rows = 1;               // the two-stage pass takes row lengths that are no multiple of the vector width (CZHIP_T2_ROWS)
   int pcr_fast = 2, pcr_variant = 0;  // CZHIP_PCR=fast[,variant]: fast 0 = the per-line kernel (pcr_rb_k), 1 = table in LDS + d in LDS
                                       // (pcr_rb2_k; variant = NW*10+L), 2 = table in LDS + d in registers (pcr_line_reg_k)
+  int psor_ahead = 0;                    // psor_col_k: steps ahead at which face words are asked for (0: the launcher's rule; 4, 8: measurements)
   int psor_col = 1, psor_wg_per_cu = 0;  // psor / psor_maf: 1 = the sweep in one launch (psor_col_k), 0 = a launch per tile hyperplane (psor_tile_k);
                                          // workgroups per CU of the former (0: four); CZHIP_PSOR=one_launch[,wg_per_cu], czhip_set_psor
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by

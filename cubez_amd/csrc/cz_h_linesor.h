@@ -561,7 +561,7 @@ bool try_psor_col(REAL* p, const REAL* b, const Coef& c, const Box& bx, double* 
   if (ma)
     hipLaunchKernelGGL((psor_col_k<1, NC, 4>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
                        ctx.psor_faces, seq, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, *ma, nullptr);
-  else if (sizeof(REAL) == 4 && g.nk > 300)
+  else if ((sizeof(REAL) == 4 && g.nk > 300 && ctx.tune.psor_ahead == 0) || ctx.tune.psor_ahead == 8)
     hipLaunchKernelGGL((psor_col_k<0, NC, 8>), dim3(nblk), dim3(psor_col_threads(NC)), 0, ctx.stream, p, b, c, g, ctx.psor_order, ntickets, ctx.psor_ctl,
                        ctx.psor_faces, seq, ctx.tune.pipe_spin_ticks, ctx.partials, res_dev, accumulate, ctx.counter, skip, MafArgs(), nullptr);
   else

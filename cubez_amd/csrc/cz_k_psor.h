@@ -316,7 +316,9 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       // columns run long after the ones they depend on, 1.8 us no longer covers a load under full memory traffic: 1.22 -> 1.27 ms.  The launcher
       // picks 8 for FP32 boxes of more than 300 points along k and 4 otherwise.
       constexpr int AH = AH_;
-      static_assert(AH == 2 || AH == 4 || AH == 8, "ring of request slots with compile-time indices");
+      static_assert(AH == 2 || AH == 4 || AH == 8 || AH == 16, "ring of request slots with compile-time indices");  // (16 was measured: 1.38 ms at 512^3 FP32 -- the hops dominate)
+      constexpr int UB = AH > 8 ? AH : 8;  // steps per unrolled loop body (a multiple of the ring, a divisor of NS)
+      static_assert(NS % UB == 0, "the give-up flag is published at the last step of a loop body of the computing waves");
       unsigned long long rq[AH][HW];
       REAL bq[AH], oq[AH];
       // A given-up wait is a private matter of this wave until the last step of the loop body it happened in: sh[2] is written only in front
@@ -364,14 +366,14 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       for (int m = -1; m < AH - 1; m++) ask(m & (AH - 1), m);
       take(0, AH - 1, -1);  // step -1
       lds_barrier();
-      for (int s0 = 0; s0 < G * ngroups; s0 += 8) {
+      for (int s0 = 0; s0 < G * ngroups; s0 += UB) {
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
+        for (int m = 0; m < UB; m++) {
           take((m & 1) ^ 1, m & (AH - 1), s0 + m);
-          if (m == 7 && (s0 & (NS - 1)) == NS - 8 && __builtin_amdgcn_ballot_w64(gave_up) != 0ull && lane == 0) sh[2] = 1;
+          if (m == UB - 1 && (s0 & (NS - 1)) == NS - UB && __builtin_amdgcn_ballot_w64(gave_up) != 0ull && lane == 0) sh[2] = 1;
           lds_barrier();
         }
-        if ((s0 & (NS - 1)) == NS - 8 && sh[2] != 0) break;  // (where the computing waves look)
+        if ((s0 & (NS - 1)) == NS - UB && sh[2] != 0) break;  // (where the computing waves look)
       }
     }
     __syncthreads();

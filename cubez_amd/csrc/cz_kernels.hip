@@ -581,7 +581,8 @@ double czhip_set_pcr_lex_timeout(double seconds) {
 int czhip_set_psor(int one_launch, int wg_per_cu) {
   ensure_init();
   if (one_launch >= 0) ctx.tune.psor_col = one_launch ? 1 : 0;
-  if (wg_per_cu >= 0) ctx.tune.psor_wg_per_cu = wg_per_cu;
+  if (wg_per_cu >= 0) ctx.tune.psor_wg_per_cu = wg_per_cu % 100;  // (+ 100 x ask-ahead distance: 4 or 8 -- measurements; 0: the launcher's rule)
+  if (wg_per_cu >= 0) ctx.tune.psor_ahead = wg_per_cu / 100;
   return 0;
 }
 
