@@ -581,9 +581,17 @@ double czhip_set_pcr_lex_timeout(double seconds) {
 int czhip_set_psor(int one_launch, int wg_per_cu) {
   ensure_init();
   if (one_launch >= 0) ctx.tune.psor_col = one_launch ? 1 : 0;
-  if (wg_per_cu >= 0) ctx.tune.psor_wg_per_cu = wg_per_cu % 100;  // (+ 100 x ask-ahead distance: 4 or 8 -- measurements; 0: the launcher's rule)
-  if (wg_per_cu >= 0) ctx.tune.psor_ahead = wg_per_cu / 100;
+  if (wg_per_cu >= 0) ctx.tune.psor_wg_per_cu = wg_per_cu;
   return 0;
+}
+
+// psor_col_k: how many steps ahead of their use the face words of the columns before are asked for (4 | 8; 0 = the launcher's rule: 8 for FP32
+// boxes of more than 300 points along k, else 4; profiles/r04/psor_what_bounds_it.txt).  Returns the previous setting.  Same bits either way.
+int czhip_set_psor_ahead(int steps) {
+  ensure_init();
+  const int before = ctx.tune.psor_ahead;
+  if (steps == 0 || steps == 4 || steps == 8) ctx.tune.psor_ahead = steps;
+  return before;
 }
 
 // pcr_lex_wg_k launch limits (test aid; negative: keep, 0: the launcher's choice): workgroups per CU, workgroups in all, lines per hand-off

@@ -260,6 +260,9 @@ double czhip_set_pcr_lex_timeout(double seconds);
  * in one launch (default), 0 = one launch per tile hyperplane; workgroups per CU of the former (0 = chosen by the launcher).  Negative = keep.
  * Same bits either way; the waits of the one-launch form are bounded by czhip_set_pcr_lex_timeout, a lost hand-off gives a NaN residual. */
 int czhip_set_psor(int one_launch, int wg_per_cu);
+/* ... and how many steps ahead of their use a column asks for the face values of the columns before it (4 | 8; 0 = chosen per launch).  Returns
+ * the previous setting.  Measurement aid; same bits either way. */
+int czhip_set_psor_ahead(int steps);
 /* Launch limits of the one-launch sweep (test aid; negative = keep, 0 = chosen per launch): workgroups per CU, workgroups in all, lines per
  * hand-off ring between two rows (rounded up to a power of two).  The launcher's own ring size lets the sweep finish however few of its
  * workgroups the device keeps resident; a ring forced small with few workgroups cannot, and the sweep then ends as described above. */

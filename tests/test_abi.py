@@ -56,3 +56,26 @@ def test_a_fatal_exit_of_the_library_leaves_a_line(tmp_path):
     assert "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr
     text = log.read_text()
     assert "no HIP device available" in text and "exit 1" in text
+
+
+def test_the_configuration_table_is_complete_and_read_in_one_place():
+    """cz_config.h: every environment variable the library reads is a row of one table, read by one function; czhip_config_describe lists them
+    with the values in force (no GPU needed).  And nothing else in the library asks the environment (cz_fatal's CZ_FATAL_LOG aside)."""
+    import subprocess
+    h = ctypes.CDLL(lib.lib_path("f32"))
+    h.czhip_config_describe.restype = ctypes.c_char_p
+    os.environ["CZ_COMM_CUS"] = "3"
+    try:
+        text = h.czhip_config_describe(0).decode()
+        only = h.czhip_config_describe(1).decode()
+    finally:
+        os.environ.pop("CZ_COMM_CUS")
+    assert "CZ_COMM_CUS=3" in text and "CZ_COMM_CUS=3" in only
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CZ_OVERLAP", "CZ_LAG_REDUCE", "CZ_BICG_FUSE", "CZ_BICG_DEVSC", "CZ_BICG_ALIAS", "CZHIP_T2", "CZHIP_T2_KWIN",
+                 "CZHIP_T2_PRE", "CZHIP_PSOR", "CZHIP_PCR_PIPE", "CZ_COMM_TIMEOUT", "CZ_FATAL_LOG"):
+        assert name in text, name
+    assert "CZ_COMM_CUS_MASK" not in text  # the CU-mask path was removed in round 4
+    src = os.path.join(ROOT, "cubez_amd", "csrc")
+    hits = subprocess.run(["grep", "-rn", "getenv(", src], capture_output=True, text=True).stdout.splitlines()
+    hits = [l for l in hits if not l.split(":", 2)[2].lstrip().startswith("//")]
+    assert len(hits) == 2 and any("cz_config.h" in l for l in hits) and any("cz_internal.h" in l for l in hits), hits

@@ -32,8 +32,9 @@ for spec in sys.argv[1:]:
             a = [int(v) for v in env["CZHIP_T2"].split(",")] + [0, 0, 0]
             assert cz.lib.czhip_set_tuning2(a[1] if a[1] else -2, a[2], a[3], a[0]) == 0
         if env.get("CZHIP_PSOR"):
-            a = [int(v) for v in env["CZHIP_PSOR"].split(",")] + [0]
+            a = [int(v) for v in env["CZHIP_PSOR"].split(",")] + [0, 0]  # one_launch, workgroups per CU, ask-ahead steps
             cz.lib.czhip_set_psor(a[0], a[1])
+            cz.lib.czhip_set_psor_ahead(a[2])
         if "CZHIP_T2_PRE" in env:
             cz.lib.czhip_set_pair_preload(int(env["CZHIP_T2_PRE"]))
         if "CZHIP_T2_KWIN" in env:
@@ -89,6 +90,7 @@ for spec in sys.argv[1:]:
         cz.lib.czhip_set_pair_preload(1)
         cz.lib.czhip_set_pair_window(-1)
         cz.lib.czhip_set_psor(1, 0)
+        cz.lib.czhip_set_psor_ahead(0)
         cz.close()
     finally:
         for k, v in old.items():
