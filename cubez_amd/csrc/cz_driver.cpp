@@ -951,11 +951,22 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
     copy_shell_async(WRK2, X, size, innerFidx, gc);
     buf[2] = WRK2;
   }
+  // Round 4: TWO iterations per pass over memory (rb4_k) where the whole inner box is one launch of one rank with constant coefficients.
+  // Every fused launch is remembered (first iteration, iterations, source buffer) so that the state at the converged iteration can be
+  // produced exactly, as in CZ::JACOBI: a converged FIRST iteration of such a pass is re-run alone from the pass's untouched input.
+  struct Launch {
+    int first_itr, niter, src;
+  };
+  std::vector<Launch> launches;
+  const bool rb4 = plan.kind == PassPlan::WHOLE && numProc == 1 && !maf &&
+                   czhip_rbsor4_async(X, WRK, B, size, innerFidx, gc, cf, ip, ac1, d_res, 0.0, 0.0, 0, nullptr, nullptr, nullptr, nullptr, 1) != 0;
+  rb4_passes = 0;
   hipEvent_t ev[POLL_SLOTS];
   int npoll = 0;
   bool stop = false;
-  int itr;
-  for (itr = 1; itr <= itr_max && !stop; itr++) {
+  int itr = 1;
+  while (itr <= itr_max && !stop) {
+    int done = 1;
     const bool in_kernel_check = converge_check && numProc == 1;
     REAL_TYPE* src = buf[cur];
     REAL_TYPE* dst = buf[(cur + 1) % nbuf];
@@ -976,6 +987,13 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
         if (!Comm_SUM_dev(d_res, 1, skip)) return 0;
         czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
+    } else if (plan.kind == PassPlan::WHOLE && rb4 && itr + 1 <= itr_max && !(plan.zero_start && itr == 1)) {
+      if (!czhip_rbsor4_async(src, dst, B, size, innerFidx, gc, cf, ip, ac1, d_res, res_normal, eps, itr, in_kernel_check ? d_hist : nullptr, d_flag,
+                              d_flag + 1, skip, 0)) {  // :205-209 twice (+ :218-230 for both iterations)
+        cz_fatal(1, "error : the two-iteration red-black pass refused after a successful probe\n");
+      }
+      done = 2;
+      rb4_passes++;
     } else if (plan.kind == PassPlan::WHOLE) {
       const int launched = (plan.zero_start && itr == 1)  // start vector identically zero (preconditioner), the right-hand side made on the way or read
                                ? pass_from_zero_made(src, dst, B, made ? made->op : 0, made ? made->x : nullptr, made ? made->y : nullptr,
@@ -1014,12 +1032,16 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
         czhip_check_async(d_res, res_normal, eps, itr, d_hist, d_flag, d_flag + 1);
       }
     }
-    flop += (maf ? 66.0 : 18.0) * npts();
+    flop += (maf ? 66.0 : 18.0) * npts() * done;
     if (fused) {
+      launches.push_back({itr, done, cur});
       cur = (cur + 1) % nbuf;
       n_fused++;
     }
-    if (converge_check && itr % POLL_EVERY == 0 && itr < itr_max) {
+    const int last_done = itr + done - 1;
+    const bool poll_now = last_done / POLL_EVERY > (itr - 1) / POLL_EVERY;  // a multiple of POLL_EVERY iterations was completed by this launch
+    itr += done;
+    if (converge_check && poll_now && last_done < itr_max) {
       const int slot = npoll % POLL_SLOTS;
       if (npoll >= POLL_SLOTS) HIP_CHECK(hipEventDestroy(ev[slot]));
       if (plan.lag) {  // the same flag on every rank: after the tests of all iterations issued so far (see CZ::JACOBI)
@@ -1043,10 +1065,25 @@ int CZ::RBSOR(double& res, REAL_TYPE* X, REAL_TYPE* B, const int itr_max, double
   last_lag = plan.lag;
   const int ret = finish_stationary(itr_max, 1, converge_check, res);
   if (n_fused > 0) {
-    // out-of-place iterations: the iterate of iteration k is in buf[k % nbuf] (launches after convergence were no-ops, or -- lagged
-    // mode -- wrote the third buffer)
-    const int n_exec = converge_check ? (ret > itr_max ? itr_max : ret) : itr_max;
-    const int fb = n_exec % nbuf;
+    // out-of-place iterations: which buffer holds the iterate of the last executed iteration?  (launches after convergence were no-ops,
+    // or -- lagged mode -- wrote the third buffer)
+    const Launch* last = &launches.back();
+    if (converge_check && ret <= itr_max) {  // converged at iteration `ret`: the launch that contains it
+      for (const Launch& l : launches)
+        if (ret >= l.first_itr && ret < l.first_itr + l.niter) {
+          last = &l;
+          break;
+        }
+      if (last->niter == 2 && ret == last->first_itr) {
+        // the first iteration of a two-iteration pass converged: the pass wrote iteration n+2 into its destination; its source is untouched,
+        // so one fused iteration from it reproduces the converged iterate (exactly what the sequential loop holds)
+        if (!czhip_rbsor2_async(buf[last->src], buf[(last->src + 1) % nbuf], B, size, innerFidx, idx1, gc, cf, ip, ac1, d_res + 4, 0.0, 0.0, 0, nullptr,
+                                nullptr, nullptr, nullptr)) {
+          cz_fatal(1, "error : fused red-black iteration refused after a successful probe\n");
+        }
+      }
+    }
+    const int fb = (last->src + 1) % nbuf;
     if (fb != 0) {
       if (X == P) {
         REAL_TYPE* t = P;
@@ -1755,6 +1792,7 @@ int cz_info(const cz_handle* h, int what) {
     case 3: return c.overlap;
     case 4: return c.last_lag;
     case 10: return c.bicg_fused;
+    case 11: return c.rb4_passes;
     case 5: return comm_transport_ranks(c.comm);
     case 6: return c.comm_cus;
     case 7: return c.last_plan.kind;

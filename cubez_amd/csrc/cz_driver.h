@@ -69,6 +69,7 @@ class CZ {
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_shell = nullptr, ev_src = nullptr, ev_comm = nullptr, ev_int = nullptr, ev_chk[2] = {nullptr, nullptr};
   bool pairs_ok = true;          // decomposed runs: EVERY brick can run the fused pass (agreed at set-up; the exchange pattern depends on it)
+  int rb4_passes = 0;            // two-iteration red-black passes (rb4_k) of the last RBSOR solve (cz_info 11)
   int bicg_fused = 0;            // vector updates of the last BiCGSTAB solve that were made inside the first pair of a preconditioner solve (cz_info 10)
   bool in_precond = false;       // inside Preconditioner: an unchecked solve does not drain the queue (the caller's next launch follows in stream order)
   int last_lag = 0;              // the last stationary solve ran its all-reduce + test one pass behind (cz_info)

@@ -20,6 +20,7 @@ struct Tuning {
   int t2_threads = 0, t2_mv = 2, t2_tj = 0;  // two-stage pass: threads per workgroup and planes per chunk, 0 = chosen per launch by
                                               // the balance model (pair_tj_model, cz_h_launch.h); CZHIP_T2=enable,threads,2,tj fixes them
   int t2_kwin = -1;                               // two-stage pass: vectors per k window; -1 = chosen per launch, 0 = whole rows where they fit (CZHIP_T2_KWIN)
+  int rb4 = 1, rb4_kwin = 0, rb4_tj = 0;          // two red-black iterations per pass (rb4_k) in single-domain runs; vectors per k window / planes per chunk (0: the launcher's rule); CZHIP_RB4
   int t2_pre = 1;                                 // two-stage pass on small grids: every operand of a chunk requested before its first step (jacobi2p_k<PRE>; CZHIP_T2_PRE)
   int t2_map = 1;                                 // two-stage pass: equal shares of (segment, chunk) items per XCD (CZHIP_T2_MAP=0: whole-segment bands)
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches
@@ -73,9 +74,9 @@ struct Ctx {
 };
 thread_local Ctx ctx;  // one context per host thread (= per rank; LOCAL transport runs ranks as threads)
 
-enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_SHELL, LBL_PSOR, LBL_COUNT };
+enum { LBL_JACOBI = 0, LBL_RBSOR, LBL_AX, LBL_RK, LBL_REDUCE, LBL_EWISE, LBL_DOT, LBL_JACOBI2, LBL_RBSOR2, LBL_PCR, LBL_SHELL, LBL_PSOR, LBL_RBSOR4, LBL_COUNT };
 static_assert(LBL_COUNT <= 16, "Ctx::t_acc / t_cnt hold 16 labels");
-const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb", "pair_shell", "psor"};
+const char* const kLabelNames[LBL_COUNT] = {"jacobi", "rbsor", "calc_ax", "calc_rk", "reduce", "ewise", "dot", "jacobi2", "rbsor2", "pcr_rb", "pair_shell", "psor", "rbsor4"};
 
 struct ScopedTimer {
   bool on;

@@ -104,7 +104,7 @@ void reduce_partials(int n, double* dst, int accumulate, const int* skip) {
 // the un-overlapped prologue); each XCD serves its band of segments with num_cu/8 * wg_per_cu resident workgroups, so a launch takes
 // ceil(band * nchunk / slots) rounds of that (tools/pair_lab sweeps, profiles/r02/pair_lab_sweep_*.txt: the model ranks the measured
 // times of both shapes and both precisions).  Returns the cost in units of plane steps; *tj_out the best chunk length.
-inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, bool balanced, int* tj_out) {
+inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, bool balanced, int* tj_out, double extra = 3.5) {
   // (decomposed runs: cu_reserved CUs of every XCD stay free for the exchange stream; reserve_comm_cus)
   const int slots = std::max(1, ctx.num_cu / 8 - ctx.cu_reserved) * wg_per_cu;
   double best = 1e300;
@@ -117,7 +117,7 @@ inline double pair_tj_model(int nseg, int nplanes, int wg_per_cu, bool balanced,
     if (tj > 2 && (nplanes + tj - 2) / (tj - 1) == nchunk) continue;  // a shorter chunk gives the same count: not a candidate
     // items of the busiest XCD: a band of whole segments, or an eighth of all items with the balanced table (pair_xcd_map)
     const long long items = balanced ? ((long long)nseg * nchunk + 7) / 8 : (long long)((nseg + 7) / 8) * nchunk;
-    const double cost = (double)((items + slots - 1) / slots) * (tj + 3.5);
+    const double cost = (double)((items + slots - 1) / slots) * (tj + extra);
     if (cost < best) best = cost, best_tj = tj;
   }
   *tj_out = best_tj;
@@ -315,6 +315,73 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   }
   if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
   return launch_jacobi2_inst<1024, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+}
+
+// TWO red-black iterations per pass (rb4_k, cz_k_rb4.h): single-domain boxes, constant coefficients.  Returns false when the geometry does not suit
+// the kernel (the caller then runs two fused iterations, jacobi2p_k<RB = 1>).  The k axis is cut into windows of about kRb4Win vectors whatever
+// the row length: the six halo rows of a segment must stay a small share of the 1 024 vectors a workgroup holds.
+constexpr int kRb4Win = VW == 4 ? 48 : 28;  // measured at 512^3 (profiles/r04/rb4_two_iterations_per_pass.txt): FP32 three windows of 43 vectors, FP64 ten of 26
+bool launch_rb4(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const int* skip, const Fin2& fin_in, int par, bool probe) {
+  constexpr int V = VW, TB = 1024;
+  if (!ctx.tune.rb4 || !ctx.tune.fuse_fin) return false;
+  if (!rows_ok(b, {U, B, W}) || !fastdiv_ok(c.dd)) return false;
+  if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
+  Geom2 g;
+  const int Rfull = (b.nkp + V - 1) / V;
+  const int hv = V == 4 ? 1 : 2;  // four stages reach three elements beyond a window
+  int want = ctx.tune.rb4_kwin > 0 ? ctx.tune.rb4_kwin : kRb4Win;
+  g.R = Rfull;
+  if (Rfull > want + 2 * hv) {
+    g.nwin = (Rfull + want - 1) / want;
+    g.KT = (Rfull + g.nwin - 1) / g.nwin;
+    g.hv = hv, g.KW = g.KT * V, g.R = g.KT + 2 * hv;
+  }
+  if (2 * g.R > TB || 8 * g.R > TB) return false;  // at least a quarter of the workgroup's vectors must be its own
+  g.PSV = (long long)g.R * b.nip;
+  g.nkp = b.nkp;
+  g.PSB = (long long)b.nkp * b.nip * (long long)sizeof(REAL);
+  if (g.PSB >= (1LL << 32)) return false;
+  g.jlast = b.njp - 1;
+  g.last_off = (unsigned)(g.PSB - (long long)sizeof(Vec<V>));
+  g.kk0 = b.kk0, g.kk1 = b.kk1, g.jj0 = b.jj0, g.jj1 = b.jj1;
+  g.F0 = (long long)b.ii0 * g.R;
+  g.Fend = (long long)(b.ii1 + 1) * g.R;
+  g.kk0a = b.kk0, g.kk1a = b.kk1, g.jj0a = b.jj0, g.jj1a = b.jj1, g.F0a = g.F0, g.Fenda = g.Fend;
+  g.S = TB - 6 * g.R;
+  g.par = par;
+  g.zero_u = 0;
+  const long long nf = g.Fend - g.F0;
+  g.nsegw = (int)((nf + g.S - 1) / g.S);
+  g.nseg = g.nwin * g.nsegw;
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  const size_t lds = ((size_t)2 * g.R + (size_t)2 * (TB + 2 * g.R) + (size_t)6 * TB) * sizeof(Vec<V>) + 18 * sizeof(double);
+  if (lds > 160 * 1024) return false;
+  int tj = 0;
+  pair_tj_model(g.nseg, nplanes, 1, pair_use_map(g.nseg), &tj, 7.5);  // (six redundant planes and a longer prologue per chunk)
+  if (ctx.tune.rb4_tj > 0) tj = ctx.tune.rb4_tj;
+  if (tj > nplanes) tj = nplanes;
+  g.TJ = tj;
+  const int nchunk = (nplanes + tj - 1) / tj;
+  g.band = 1;
+  g.map = nullptr;
+  long long nblk = 8LL * ((g.nseg + 7) / 8) * nchunk;
+  if (probe) return true;
+  if (pair_use_map(g.nseg)) g.map = pair_xcd_map(g.nseg, nchunk, &nblk);
+  ensure_partials((size_t)2 * nblk);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rb4_k<V, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  Fin2 fin = fin_in;
+  fin.counter = ctx.counter;
+  fin.single = 0;
+  {
+    ScopedTimer tm(LBL_RBSOR4);
+    hipLaunchKernelGGL((rb4_k<V, TB>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
+  }
+  HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 // the shell boxes of a decomposed brick, all in one launch (pair_shell_k); boxes: n x (ist,ied,jst,jed,kst,ked), 1-based

@@ -1,0 +1,226 @@
+// cz_k_rb4.h -- part of cz_kernels.hip (ONE translation unit per precision; included inside its anonymous namespace after cz_k_pair2.h):
+// rb4_k, TWO complete red-black SOR iterations (colour 0, colour 1, colour 0, colour 1; cz_solver.f90:404-493 four times,
+// cz_Poisson.cpp:205-209 twice) per pass over memory.  Single-domain runs, constant coefficients.
+// ------------------------------------------------------------------------------------------------------------
+// Why: the fused red-black iteration (jacobi2p_k<RB = 1>) is bound by memory -- 5.1 TB/s of real traffic with the vector ALU 61 % busy
+// (profiles/r03/pmc_jacobi2p_512_f32_rb_SQ.txt): a stage evaluates only the active colour.  Four stages per pass halve the bytes per
+// iteration.  Round 3 modelled this at 1.16 x and did not build it because eight plane buffers with whole-row halos left 4.9 rows per
+// segment; with the k windows of round 4 (Geom2) a row of the workgroup's view is ~34 vectors whatever the grid, and the budget closes:
+//     fields      u on E4 = own segment +- 4 rows, f1 (after colour 0) on E3, f2 (after colour 1) on E2, f3 on E1, f4 = output on the segment
+//     threads     one per vector of E3 (TB = LV = S + 6R: every thread evaluates stage 1; stages 2 and 3 on all of E3 as well -- what lies
+//                 outside their sets is never read by a valid point -- stage 4 on the owned vectors)
+//     LDS         u: 2 x (LV + 2R), f1..f3: 2 x LV each (E3 coordinates), one barrier per plane step   = 133 KB for R = 34
+//     k windows   KT vectors + hv halo vectors per side; four stages reach 3 elements beyond a window: hv = 1 (FP32), 2 (FP64)
+//     planes      stage s at step q works on plane q - s + 1: f1(q) from u(q-1..q+1), f2(q-1) from f1, f3(q-2), f4(q-3) -> W
+// Same per-point operations on the same values as four psor2sma_core_ calls => the same bits (relax_vec_rb is the stage of jacobi2p_k).
+// Both residuals are produced (iteration n+1 = stages 1 + 2, iteration n+2 = stages 3 + 4); if the FIRST of the two iterations converges
+// the driver re-runs that single iteration from the untouched input (out of place, like the Jacobi pair).
+// ------------------------------------------------------------------------------------------------------------
+template <int V, int TB>
+__global__ void __launch_bounds__(TB, 1)
+rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
+      const int* __restrict__ skip, Fin2 fin) {
+  if (skip != nullptr && *skip != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const int R = g.R;
+  constexpr int LV = TB;      // E3: own segment +- three rows (S = LV - 6R); one vector per thread
+  const int LU = LV + 2 * R;  // E4
+  // (R vectors of padding in front of the u buffers and behind the last field buffer: stages 2 and 3 are evaluated on all of E3 and read
+  // +-R beyond their sets -- inside the allocation, never used)
+  Vec<V>* ldsU = reinterpret_cast<Vec<V>*>(smem) + R;   // 2 buffers of LU vectors: plane p in buffer p & 1
+  Vec<V>* ldsF = ldsU + (size_t)2 * LU;                  // f1, f2, f3: [field][plane & 1][LV]
+  double* wsum = reinterpret_cast<double*>(ldsF + (size_t)6 * LV + R);
+
+  // ---- workgroup -> (window, segment, chunk): as jacobi2p_k
+  const int lb = blockIdx.x;
+  const int nblk = gridDim.x;
+  int seg, chunk;
+  if (g.map != nullptr) {
+    seg = g.map[2 * lb];
+    chunk = g.map[2 * lb + 1];
+  } else {
+    const int x = lb & 7, r = lb >> 3;
+    const int base = g.nseg >> 3, rem = g.nseg & 7, bmax = base + (rem ? 1 : 0);
+    const int blen = base + (x < rem ? 1 : 0);
+    const int sl = r % bmax;
+    chunk = r / bmax;
+    seg = (sl < blen) ? x * base + min(x, rem) + sl : g.nseg;  // nseg = no work
+  }
+  int win = 0;
+  if (seg < g.nseg) {
+    win = seg / g.nsegw;
+    seg -= win * g.nsegw;
+  } else {
+    seg = g.nsegw;
+  }
+  const int kw0 = win * g.KW - g.hv * V;
+  const long long fb = (seg < g.nsegw) ? g.F0 + (long long)seg * g.S : g.Fend;
+  const int ja = g.jj0 + chunk * g.TJ;
+  int jb = ja + g.TJ - 1;
+  if (jb > g.jj1) jb = g.jj1;
+
+  double acc1 = 0.0, acc2 = 0.0;
+  const HoistedDiv dv{fastdiv_init(c.dd)};
+
+  if (ja <= jb && fb < g.Fend) {
+    const long long e3_0 = fb - 3 * (long long)R;  // first vector of E3
+    const long long vlast = g.PSV - 1;
+    const size_t PB = (size_t)g.PSB;
+    auto off_of = [&](long long f) -> unsigned {  // (see jacobi2p_k: clamped below the plane, not beyond it; `lim` for the array's last plane)
+      if (f < 0) f = 0;
+      if (f > vlast) f = vlast;
+      const long long r = f / R;
+      long long el = r * g.nkp + kw0 + (f - r * R) * V;
+      el = el < 0 ? 0 : el;
+      return (unsigned)(el * (long long)sizeof(REAL));
+    };
+    auto lim = [&](unsigned off, int plane) -> unsigned { return plane == g.jlast ? (off < g.last_off ? off : g.last_off) : off; };
+    auto pl = [&](int p) -> int { return p < 0 ? 0 : (p > g.jlast ? g.jlast : p); };  // planes beyond the array are never used: clamped
+    // this thread's vector
+    const long long f = e3_0 + t;
+    const unsigned bo = off_of(f);
+    unsigned inbox = 0;  // components inside the inner box (every stage updates only those)
+    unsigned own = 0;    // ... of a vector this workgroup owns (stores, residual counts)
+    int pbase;
+    {
+      const long long fc = f < 0 ? 0 : f;
+      const long long row = fc / R;
+      const int kv = (int)(fc - row * R);
+      const int kb = kw0 + kv * V;
+      unsigned bits = 0;
+#pragma unroll
+      for (int cc = 0; cc < V; cc++) {
+        const int kk = kb + cc;
+        if (kk >= g.kk0 && kk <= g.kk1) bits |= 1u << cc;
+      }
+      pbase = kb + (int)row + g.par;
+      const bool rows_in = f >= g.F0 && f < g.Fend;
+      inbox = rows_in ? bits : 0u;
+      const bool kown = kv >= g.hv && kv < g.hv + g.KT;
+      own = (t >= 3 * R && t < LV - 3 * R && rows_in && kown) ? bits : 0u;
+    }
+    // the outer rows of E4: the first R threads stage the lower one, the last R threads the upper one
+    const bool has_halo = (t < R) || (t >= TB - R);
+    const int hl = (t < R) ? t : (LV + R + (t - (TB - R)));  // index inside an LDS u buffer (E4 coordinates)
+    const unsigned hbo = off_of(has_halo ? (fb - 4 * (long long)R + hl) : f);
+    const char* Ub = reinterpret_cast<const char*>(U);
+    const char* Bb = reinterpret_cast<const char*>(B);
+    char* Wb = reinterpret_cast<char*>(W);
+
+    // ---- prologue: the first step is q0 = ja - 3 (stage 1 on plane ja - 3): LDS u(q0 - 1) own, u(q0) on E4; in flight u(q0 + 1), b(q0)
+    const int q0 = ja - 3;
+    Vec<V> uA, uB, bA, bB, hx;
+    {
+      const Vec<V> t2 = ld16<V>(Ub + (size_t)pl(q0 - 1) * PB, lim(bo, pl(q0 - 1)));
+      const Vec<V> t1 = ld16<V>(Ub + (size_t)pl(q0) * PB, lim(bo, pl(q0)));
+      const Vec<V> h1 = ld16<V>(Ub + (size_t)pl(q0) * PB, lim(hbo, pl(q0)));
+      uA = ld16<V>(Ub + (size_t)pl(q0 + 1) * PB, lim(bo, pl(q0 + 1)));
+      bA = ld16<V>(Bb + (size_t)pl(q0) * PB, lim(bo, pl(q0)));
+      ldsU[(size_t)((q0 - 1) & 1) * LU + R + t] = t2;
+      ldsU[(size_t)(q0 & 1) * LU + R + t] = t1;
+      if (has_halo) ldsU[(size_t)(q0 & 1) * LU + hl] = h1;
+    }
+    Vec<V> bq1 = zerov<V>(), bq2 = zerov<V>(), bq3 = zerov<V>();  // b of the planes of stages 2, 3, 4
+    __syncthreads();
+
+    const int w0 = t & ~63;  // first lane of the wave
+    // one stage: the field `fin_` (centre plane p in LDS buffer `cur`, own vector of plane p-1 in `prv`, plane p+1 in `nxt`) -> the stage's result
+    auto stage = [&](const Vec<V>* cur, const Vec<V>* prv, int x, const Vec<V>& nxt, const Vec<V>& bb, int p, int colour, unsigned msk, unsigned cnt,
+                     double& acc) __attribute__((always_inline)) -> Vec<V> {
+      const int xw = x - (t - w0);
+      const Vec<V> pc = lds_ld<V>(cur + x);
+      const Vec<V> im = lds_ld<V>(cur + x - R);
+      const Vec<V> ip = lds_ld<V>(cur + x + R);
+      const Vec<V> pm = lds_ld<V>(prv + x);
+      const REAL elo = reinterpret_cast<const REAL*>(cur)[(long long)xw * V - 1];
+      const REAL ehi = reinterpret_cast<const REAL*>(cur)[(long long)(xw + 64) * V];
+      const REAL kl = lane_shr1(elo, pc.v[V - 1]);
+      const REAL kr = lane_shl1(ehi, pc.v[0]);
+      const bool sc = ((pbase + p + colour) & 1) != 0;
+      const Vec<V> z = zerov<V>();
+      return relax_vec_rb<V>(pc, im, ip, pm, nxt, kl, kr, bb, z, z, sc, msk, cnt, acc,
+                             [&](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL, REAL) {
+                               const REAL ss = c.c1 * ipv + c.c2 * imv + c.c3 * pnv + c.c4 * pmv + c.c5 * kp1 + c.c6 * km1;
+                               return (dv(ss - bv) - pp) * c.omg;
+                             });
+    };
+
+    // One plane step q.  uc = u(q+1) and b1 = b(q) were requested one step ago; un / bn receive this step's requests.
+    auto step = [&](const int q, Vec<V>& uc, Vec<V>& un, Vec<V>& b1, Vec<V>& bn) __attribute__((always_inline)) {
+      {
+        const int qu = pl(q + 2 <= jb + 4 ? q + 2 : jb + 4), qb = pl(q + 1 <= jb + 3 ? q + 1 : jb + 3);
+        hx = ld16<V>(Ub + (size_t)pl(q + 1) * PB, lim(hbo, pl(q + 1)));
+        un = ld16<V>(Ub + (size_t)qu * PB, lim(bo, qu));
+        bn = ld16<V>(Bb + (size_t)qb * PB, lim(bo, qb));
+      }
+      // planes of the four stages and whether they lie in the inner box (outside it a stage leaves the plane alone)
+      const int p1 = q, p2 = q - 1, p3 = q - 2, p4 = q - 3;
+      const Vec<V>* cU = ldsU + (size_t)(p1 & 1) * LU + R;  // u(p1) in E3 coordinates (index t)
+      const Vec<V>* pU = ldsU + (size_t)((p1 - 1) & 1) * LU + R;
+      Vec<V>* F1 = ldsF;
+      Vec<V>* F2 = ldsF + (size_t)2 * LV;
+      Vec<V>* F3 = ldsF + (size_t)4 * LV;
+      // ---- stage 1: f1(p1), colour 0, every vector of E3
+      Vec<V> v1;
+      if (p1 >= g.jj0 && p1 <= g.jj1) v1 = stage(cU, pU, t, uc, b1, p1, 0, inbox, (p1 >= ja && p1 <= jb) ? own : 0u, acc1);
+      else v1 = lds_ld<V>(cU + t);
+      // (a wave that lies wholly outside the set of a stage -- E2 for stage 2, E1 for stage 3 -- skips it: nothing valid reads its result)
+      const bool in2 = w0 + 63 >= R && w0 < LV - R, in3 = w0 + 63 >= 2 * R && w0 < LV - 2 * R;
+      // ---- stage 2: f2(p2), colour 1, from f1(p2 - 1) [LDS], f1(p2) [LDS], f1(p1) [v1]
+      Vec<V> v2;
+      if (in2 && p2 >= g.jj0 && p2 <= g.jj1) v2 = stage(F1 + (size_t)(p2 & 1) * LV, F1 + (size_t)((p2 - 1) & 1) * LV, t, v1, bq1, p2, 1, inbox, (p2 >= ja && p2 <= jb) ? own : 0u, acc1);
+      else v2 = lds_ld<V>(F1 + (size_t)(p2 & 1) * LV + t);
+      // ---- stage 3: f3(p3), colour 0
+      Vec<V> v3;
+      if (in3 && p3 >= g.jj0 && p3 <= g.jj1) v3 = stage(F2 + (size_t)(p3 & 1) * LV, F2 + (size_t)((p3 - 1) & 1) * LV, t, v2, bq2, p3, 0, inbox, (p3 >= ja && p3 <= jb) ? own : 0u, acc2);
+      else v3 = lds_ld<V>(F2 + (size_t)(p3 & 1) * LV + t);
+      // ---- stage 4: f4(p4) = the output, colour 1, owned vectors of the chunk's planes.  Whole waves: the k neighbours travel by lane
+      // shifts, and the lane next to the first owned vector of a window holds a halo vector -- it owns nothing but must take part.
+      if (p4 >= ja && __builtin_amdgcn_ballot_w64(own != 0) != 0ull) {
+        const Vec<V> o = stage(F3 + (size_t)(p4 & 1) * LV, F3 + (size_t)((p4 - 1) & 1) * LV, t, v3, bq3, p4, 1, own, own, acc2);
+        char* Wq = Wb + (size_t)p4 * PB;
+        if (own == (1u << V) - 1) {
+          st16<V>(Wq, bo, o);
+        } else if (own != 0) {
+          REAL* wp = reinterpret_cast<REAL*>(Wq + bo);
+#pragma unroll
+          for (int cc = 0; cc < V; cc++)
+            if (own & (1u << cc)) wp[cc] = o.v[cc];
+        }
+      }
+      // ---- publish: f1(p1), f2(p2), f3(p3) and the next u centre plane u(q+1) with its outer rows
+      F1[(size_t)(p1 & 1) * LV + t] = v1;
+      F2[(size_t)(p2 & 1) * LV + t] = v2;
+      F3[(size_t)(p3 & 1) * LV + t] = v3;
+      Vec<V>* nU = ldsU + (size_t)((p1 + 1) & 1) * LU;
+      nU[R + t] = uc;
+      if (has_halo) nU[hl] = hx;
+      bq3 = bq2, bq2 = bq1, bq1 = b1;  // (b1 is complete: stage 1 used it)
+      __syncthreads();
+    };
+    // (the planes a stage publishes before its first needed one are pass-through copies or garbage that no later stage reads: stage s first
+    // matters at plane ja - (4 - s), which it reaches at step ja - 3 + 2 (s - 1) ... every field buffer a valid point reads was written by
+    // a step of this loop)
+    for (int q = q0;; q += 2) {
+      step(q, uA, uB, bA, bB);
+      if (q + 1 > jb + 3) break;
+      step(q + 1, uB, uA, bB, bA);
+      if (q + 2 > jb + 3) break;
+    }
+  }
+
+  // ---- residuals of the two iterations: per-workgroup partials, finalised by the last workgroup (see jacobi2p_k)
+  __syncthreads();
+  const double s1 = block_sum<TB>(acc1, wsum);
+  __syncthreads();
+  const double s2 = block_sum<TB>(acc2, wsum);
+  int* last_flag = reinterpret_cast<int*>(wsum + 16);
+  if (t == 0) {
+    __hip_atomic_store(&partials[lb], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[nblk + lb], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = arrive_and_test_last(fin.counter, nblk);
+  }
+  __syncthreads();
+  if (*last_flag) pair_finalize<TB>(partials, nblk, fin, wsum);
+}

@@ -42,6 +42,7 @@ namespace {
 #include "cz_k_stencil.h"
 #include "cz_k_pair.h"
 #include "cz_k_pair2.h"
+#include "cz_k_rb4.h"
 #include "cz_k_linesor.h"
 #include "cz_k_psor.h"
 #include "cz_k_blas.h"
@@ -178,6 +179,11 @@ int czhip_init(int device) {
   ctx.tune.t2_any_rows = cfg.on(CZV_T2_ROWS, ctx.tune.t2_any_rows != 0) ? 1 : 0;
   ctx.tune.t2_kwin = cfg.num(CZV_T2_KWIN, ctx.tune.t2_kwin);
   ctx.tune.t2_pre = cfg.num(CZV_T2_PRE, ctx.tune.t2_pre);
+  if (const char* v = cfg.str(CZV_RB4)) {  // "enable[,vectors per window[,planes per chunk]]"
+    int en = 1, kw = 0, tj = 0;
+    sscanf(v, "%d,%d,%d", &en, &kw, &tj);
+    ctx.tune.rb4 = en, ctx.tune.rb4_kwin = kw, ctx.tune.rb4_tj = tj;
+  }
   if (const char* pp = cfg.str(CZV_PCR_PIPE)) {  // "form[,seconds[,groups[,rows per thread]]]": form as Tuning::pcr_pipe; bound of the waits inside the kernel
     int w = 1, rows = 0, q = 1;
     double sec = 2.0;
@@ -464,6 +470,34 @@ int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int
     fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
   }
   return launch_jacobi2<1>(u, b, w, make_coef(cf, omg), bx, ba, hist_dev ? flag_dev : skip_flag_dev, fin, rb_parity(g, idx, ofst, 0)) ? 1 : 0;
+}
+
+// TWO red-black SOR iterations (four colour sweeps) in one pass over memory, u -> w (rb4_k; single-domain boxes).  res_dev[0], res_dev[1] receive
+// the sums dp^2 of iteration itr and itr + 1; with hist_dev the last workgroup does the bookkeeping of both (a converged FIRST iteration leaves
+// the flag set with conv_itr = itr: the caller recomputes that one iteration from u, which this kernel never modifies).  probe != 0: only
+// answer whether the launcher takes the geometry.  Returns 1 if launched (or launchable), 0 otherwise.
+int czhip_rbsor4_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf, int ofst, CZ_REAL omg,
+                       double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev, int* conv_itr_dev,
+                       const int* skip_flag_dev, int probe) {
+  ensure_init();
+  const Box bx = make_box(sz, idx, g);
+  if (bx.empty || g < 2) return 0;
+  Fin2 fin;
+  fin.dst = res_dev;
+  if (hist_dev) {
+    fin.do_check = 1, fin.itr = itr, fin.res_normal = res_normal, fin.eps = eps;
+    fin.hist = hist_dev, fin.flag = flag_dev, fin.conv_itr = conv_itr_dev;
+  }
+  return launch_rb4(u, b, w, make_coef(cf, omg), bx, hist_dev ? flag_dev : skip_flag_dev, fin, rb_parity(g, idx, ofst, 0), probe != 0) ? 1 : 0;
+}
+
+// rb4_k switches (measurements): enable 0 | 1, vectors per k window, planes per chunk (0: the launcher's rule); negative: keep.
+int czhip_set_rb4(int enable, int window, int planes) {
+  ensure_init();
+  if (enable >= 0) ctx.tune.rb4 = enable ? 1 : 0;
+  if (window >= 0) ctx.tune.rb4_kwin = window;
+  if (planes >= 0) ctx.tune.rb4_tj = planes;
+  return 0;
 }
 
 // The fused pass split the way a decomposed brick runs it: the slabs behind the faces with nID[f] >= 0 first

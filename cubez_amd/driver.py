@@ -99,7 +99,7 @@ class CZ:
 
     def info(self) -> dict:
         """what a (multi-GPU) run decided (cz_info of include/cz_hip.h)"""
-        keys = ("ranks", "fused_pass", "shell_slabs", "overlap", "lagged_reduce", "rccl_ranks", "comm_cus", "pass_kind", "exchange_depth", "buffers", "bicg_fused")
+        keys = ("ranks", "fused_pass", "shell_slabs", "overlap", "lagged_reduce", "rccl_ranks", "comm_cus", "pass_kind", "exchange_depth", "buffers", "bicg_fused", "rb4_passes")
         return {k: self.lib.cz_info(self.h, i) for i, k in enumerate(keys)}
 
     def timing(self, enable: bool):

@@ -213,6 +213,16 @@ int czhip_jacobi2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const in
 int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, const int* idx1, int g,
                        const CZ_REAL* cf, int ofst, CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr,
                        double* hist_dev, int* flag_dev, int* conv_itr_dev, const int* skip_flag_dev);
+/* TWO red-black SOR iterations (colour 0, 1, 0, 1: cz_Poisson.cpp:205-209 twice) in ONE pass over memory, u -> w out of place (single-domain
+ * boxes, constant coefficients): bit-identical to four psor2sma_core_ calls.  res_dev[0], res_dev[1] = the sums dp^2 of iteration itr and
+ * itr + 1; check arguments as for czhip_jacobi2_async (two iterations; a converged first iteration leaves conv_itr = itr and the caller
+ * recomputes that iteration from u).  probe != 0: only says whether the launch would be taken.  Returns 0 when it is not (the caller then runs
+ * czhip_rbsor2_async twice). */
+int czhip_rbsor4_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf, int ofst,
+                       CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
+                       int* conv_itr_dev, const int* skip_flag_dev, int probe);
+/* ... its switches (measurements; negative = keep): on / off, vectors per k window, planes per chunk (0 = chosen per launch) */
+int czhip_set_rb4(int enable, int window, int planes);
 /* The fused pass split the way a decomposed brick runs it (replaces the reference's "sweep, then Comm_S",
  * cz_Poisson.cpp:58-63): first the slabs two cells thick behind every face with nID[f] >= 0 (the cells the neighbours
  * receive), then the interior, so that the exchange can start after the first launch.  Same result as the unsplit op.
@@ -321,7 +331,8 @@ double cz_last_solve_seconds(const cz_handle*);
  * test transport or single process), 6 CUs per XCD the sweeps leave to the exchange stream (CZ_COMM_CUS); the plan of the last stationary
  * solve: 7 kind of pass (0 single sweeps, 1 fused pass over the whole box, 2 fused pass as shell slabs + interior with the exchange
  * overlapped), 8 ghost layers exchanged per pass, 9 rotating field buffers; 10 vector updates of the last BiCGSTAB solve that were made inside
- * the first pair of the preconditioner solve they feed (czhip_jacobi2_from_zero_made_async). */
+ * the first pair of the preconditioner solve they feed (czhip_jacobi2_from_zero_made_async); 11 passes of the last red-black SOR solve that made
+ * two iterations each (czhip_rbsor4_async). */
 int cz_info(const cz_handle*, int what);
 double cz_kernel_ms(const cz_handle*, const char* label); /* HIP-event time of a labelled section, ms (avg per launch) */
 

@@ -332,6 +332,51 @@ def test_fused_red_black_iteration_equals_two_colour_calls(prec, box, kwin):
         assert launched > 0
 
 
+RB4_FORMS = [(0, 0), (5, 0), (9, 3), (32, 2), (0, 7)]  # (vectors per k window, planes per chunk); 0 = the launcher's rule
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", T2_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in T2_BOXES])
+def test_two_red_black_iterations_per_pass_equal_four_colour_calls(prec, box):
+    """czhip_rbsor4_async (rb4_k, round 4: colour 0, 1, 0, 1 in ONE pass over memory, four stages deep, k cut into windows) == four psor2sma_core
+    calls of the oracle, bit for bit, and the residuals of both iterations; both colour offsets, windows of 5 / 9 / 32 vectors and the
+    launcher's own, chunks of 2, 3, 7 planes; rows that are no multiple of the vector width and rows of 1 104 / 2 104 elements included."""
+    (ni, nj, nk), idx = box
+    sz = [ni, nj, nk]
+    idx = list(idx) if idx else [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(7 * ni + 3 * nj + 5 * nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    cf = rng.uniform(0.5, 1.5, 7).astype(R)
+    cf[6] = 6.2
+    p, b = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    du, db = h.alloc(sz, p), h.alloc(sz, b)
+    launched = 0
+    try:
+        for ofst in (0, 1):
+            a1, r = p.copy(), []
+            for it in range(2):
+                wide = np.zeros(1)
+                for color in (0, 1):
+                    ko.psor2sma_core(a1, sz, idx, cf, ofst, color, 1.3, b, wide=wide)
+                r.append(wide[0])
+            for (kw, tj) in RB4_FORMS:
+                assert h.lib.czhip_set_rb4(1, kw, tj) == 0
+                dw = h.alloc(sz, p)
+                ok, r1, r2 = h.rbsor4(du, dw, db, sz, idx, cf, ofst, 1.3)
+                if ok:
+                    launched += 1
+                    assert _beq(dw.get(), a1), (ofst, kw, tj)
+                    assert _beq(du.get(), p)  # the input is never modified
+                    assert _rel(r1, r[0]) < RTOL_WIDE * 10 and _rel(r2, r[1]) < RTOL_WIDE * 10, (ofst, kw, tj)
+                dw.free()
+    finally:
+        h.lib.czhip_set_rb4(1, 0, 0)
+    if idx[0] >= 2 and idx[2] >= 2:
+        assert launched > 0
+
+
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("box", [(40, 36, 60), (33, 50, 123), (29, 31, 253), (70, 20, 126)], ids=lambda b: "x".join(map(str, b)))
 @pytest.mark.parametrize("rb", [-1, 0, 1], ids=["jacobi_pair", "rb_ofst0", "rb_ofst1"])

@@ -248,6 +248,33 @@ def _fused_equals_unfused(prec, gsz, pc, monkeypatch):
         assert out[tag][:4] == out["none"][:4], tag
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("gsz,itmax,coef", [((32, 32, 32), 100000, 1.5), ((40, 28, 36), 100000, 1.3), ((48, 40, 200), 7, 1.5), ((48, 40, 200), 12, 1.5),
+                                            ((64, 64, 64), 100000, 1.5), ((24, 20, 1100), 9, 1.5)], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else str(v))
+def test_red_black_sor_two_iterations_per_pass_equals_one_per_pass(prec, gsz, itmax, coef):
+    """Round 4: single-domain red-black SOR runs two iterations per pass over memory (rb4_k).  Same iteration count, same history, same field,
+    bit for bit, as with one iteration per pass (czhip_set_rb4(0)) -- to convergence (whichever iteration of a pass converges: a converged
+    first one is re-run alone from the pass's input) and for fixed odd / even counts; and against the oracle."""
+    from cubez_amd import CZ
+    out = {}
+    for on in (1, 0):
+        cz = CZ(prec, quiet=True)
+        cz.lib.czhip_set_rb4(on, -1, -1)
+        try:
+            assert cz.setup(list(gsz) + ["sor2sma", itmax, coef]) == 1
+            itr = cz.solve()
+            out[on] = (itr, cz.res, list(cz.history()), cz.field().tobytes(), cz.info()["rb4_passes"])
+        finally:
+            cz.lib.czhip_set_rb4(1, -1, -1)
+            cz.close()
+    assert out[0][4] == 0 and out[1][4] > 0, (out[0][4], out[1][4])
+    assert out[1][0] == out[0][0] and out[1][3] == out[0][3]  # iteration count and field: bit for bit
+    assert np.allclose(out[1][2], out[0][2], rtol=1e-12, atol=0) and abs(out[1][1] - out[0][1]) <= 1e-12 * out[0][1]  # (the partial sums are grouped by another tiling)
+    o = O.run(gsz, "sor2sma", itmax, coef, None, kind="oracle", prec=prec, wide=True)
+    assert out[1][0] == o.itr and out[1][3] == o.P.tobytes()
+    assert np.allclose(out[1][2], [r for _, r in o.history], rtol=1e-11, atol=0)
+
+
 def test_convergence_stops_at_the_reference_iteration():
     """64^3 FP64 Jacobi to eps: 2742 iterations in the reference CLI; the device-side flag must stop
     the field exactly there although the host keeps queueing sweeps."""
