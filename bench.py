@@ -243,7 +243,7 @@ def event_span_ms(lib, fn):
 def kernel_source_sha():
     """identifies the build a recorded HBM-traffic figure belongs to: the sources of the sweep kernels and their launch geometry"""
     h = hashlib.sha256()
-    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_blas.h", "cz_h_launch.h"):
+    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_rb4.h", "cz_k_blas.h", "cz_h_launch.h"):
         h.update(open(os.path.join(ROOT, "cubez_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -309,12 +309,13 @@ def measure(solver, prec, precond, steps, warmup, repeats, settle):
     line = solver.startswith("pcr")
     single = cz.timing_read("jacobi" if jl else "pcr_rb" if line else "psor" if solver.startswith("psor") else "rbsor")
     fused = cz.timing_read("jacobi2" if jl else "rbsor2")  # fused: 2 sweeps / both colours per launch
-    labels = {lb: cz.timing_read(lb) for lb in ("jacobi2", "rbsor2", "calc_ax", "ewise", "dot", "pair_shell")}
+    fused4 = cz.timing_read("rbsor4")                        # red-black, single domain (round 4): TWO iterations per launch (rb4_k)
+    labels = {lb: cz.timing_read(lb) for lb in ("jacobi2", "rbsor2", "rbsor4", "calc_ax", "ewise", "dot", "pair_shell")}
     cz.timing(False)
     info = cz.info()
     cz.close()
     return dict(solver=solver, prec=prec, precond=precond, bicg=bicg, coef=coef, steps=steps, warmup=warmup, repeats=repeats, dts=dts, dt=statistics.median(dts),
-                my_points=my_points, jac_like=jl, line=line, single=single, fused=fused, labels=labels, info=info, settle_s=settled,
+                my_points=my_points, jac_like=jl, line=line, single=single, fused=fused, fused4=fused4, labels=labels, info=info, settle_s=settled,
                 timed_steps=steps, event_span_ms=ev_ms)
 
 
@@ -371,6 +372,14 @@ def roofline_of(m):
         else:
             kernel_name, tkey = "jacobi2p_k<RB=1> (both colours of one iteration per launch)", f"rbsor2_{n}_{m['prec']}"
             model += "; both colours in ONE pass over memory (12 B/LUP really moved) -- `frac_hbm_traffic` is the physical fraction"
+    nk4, kern4_ms = m.get("fused4", (0, 0.0))
+    if not jl and nk4 > nk:  # the dominant kernel makes TWO red-black iterations per pass over memory: four colour passes of SURVEY's model per launch
+        nk, kern_ms = nk4, kern4_ms
+        alg = 4 * pts * word * 2
+        fused_min = pts * word * 3
+        kernel_name, tkey = "rb4_k (two red-black iterations = four colour sweeps per launch)", f"rbsor4_{n}_{m['prec']}"
+        model = ("16 B/LUP per iteration: two colour passes of 8 B/LUP; TWO iterations in ONE pass over memory (12 B per point really moved per launch), so `achieved` "
+                 "counts 2 x 16 B/LUP per launch and can exceed the peak -- `frac_hbm_traffic` is the physical fraction")
     kern_avg_s = (kern_ms / nk) * 1e-3 if nk else float("nan")
     achieved = alg / kern_avg_s / 1e9 if nk else None
     traffic, tsrc = traffic_record(tkey) if n == 512 else (None, None)

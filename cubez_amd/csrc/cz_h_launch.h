@@ -320,7 +320,11 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
 // TWO red-black iterations per pass (rb4_k, cz_k_rb4.h): single-domain boxes, constant coefficients.  Returns false when the geometry does not suit
 // the kernel (the caller then runs two fused iterations, jacobi2p_k<RB = 1>).  The k axis is cut into windows of about kRb4Win vectors whatever
 // the row length: the six halo rows of a segment must stay a small share of the 1 024 vectors a workgroup holds.
-constexpr int kRb4Win = VW == 4 ? 48 : 28;  // measured at 512^3 (profiles/r04/rb4_two_iterations_per_pass.txt): FP32 three windows of 43 vectors, FP64 ten of 26
+// Window length by measurement (profiles/r04/rb4_two_iterations_per_pass.txt; 128^3 .. 1024^3): FP32 rows up to 50 vectors whole (128^3, 192^3:
+// 1.12 x / 1.25 x the one-iteration pass), rows of 65 / 97 vectors in windows of 22 / 25 (1.14 x / 1.28 x; windows of 33 give 1.02 x / 1.09 x), rows of
+// 129 / 257 in windows of 43 (1.15-1.19 x; 26 and 33 give 1.10 x); FP64 anything from 20 to 33 (1.25-1.32 x).
+inline int rb4_window(int Rfull) { return VW == 4 ? (Rfull < 115 ? 26 : 48) : 28; }
+constexpr int kRb4Win = 48;
 bool launch_rb4(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const int* skip, const Fin2& fin_in, int par, bool probe) {
   constexpr int V = VW, TB = 1024;
   if (!ctx.tune.rb4 || !ctx.tune.fuse_fin) return false;
@@ -329,9 +333,9 @@ bool launch_rb4(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box&
   Geom2 g;
   const int Rfull = (b.nkp + V - 1) / V;
   const int hv = V == 4 ? 1 : 2;  // four stages reach three elements beyond a window
-  int want = ctx.tune.rb4_kwin > 0 ? ctx.tune.rb4_kwin : kRb4Win;
+  int want = ctx.tune.rb4_kwin > 0 ? ctx.tune.rb4_kwin : rb4_window(Rfull);
   g.R = Rfull;
-  if (Rfull > want + 2 * hv) {
+  if (Rfull > (ctx.tune.rb4_kwin > 0 ? want : kRb4Win) + 2 * hv) {
     g.nwin = (Rfull + want - 1) / want;
     g.KT = (Rfull + g.nwin - 1) / g.nwin;
     g.hv = hv, g.KW = g.KT * V, g.R = g.KT + 2 * hv;

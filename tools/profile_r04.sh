@@ -24,7 +24,7 @@ if [ $what = pmc32 ] || [ $what = all ]; then
     rocprofv3 --pmc $c -d $O/pmc_rb_$c --output-format csv -- python3 bench.py --solver sor2sma $PMCARGS > $O/pmc_rb_$c.log 2>&1 || exit 1
   done
   python3 tools/summarize_pmc.py jacobi2_512_f32 jacobi2p_k $O/pmc_jac_FETCH_SIZE $O/pmc_jac_WRITE_SIZE $O/hbm_traffic.json > $O/hbm_jac.txt || exit 1
-  python3 tools/summarize_pmc.py rbsor2_512_f32 jacobi2p_k $O/pmc_rb_FETCH_SIZE $O/pmc_rb_WRITE_SIZE $O/hbm_traffic.json > $O/hbm_rb.txt || exit 1
+  python3 tools/summarize_pmc.py rbsor4_512_f32 rb4_k $O/pmc_rb_FETCH_SIZE $O/pmc_rb_WRITE_SIZE $O/hbm_traffic.json > $O/hbm_rb.txt || exit 1
   rm -rf $O/pmc_jac_* $O/pmc_rb_*
   cat $O/hbm_jac.txt $O/hbm_rb.txt
 fi
@@ -50,7 +50,7 @@ for tag in ("rb", "jac"):
     acc = collections.defaultdict(list)
     for f in glob.glob(O + f"/pmc_{tag}_SQ/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "jacobi2p_k" in r["Kernel_Name"]:
+            if "jacobi2p_k" in r["Kernel_Name"] or "rb4_k" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(O + f"/pmc_jacobi2p_512_f32_{tag}_SQ.txt", "w") as o:
         for c in sorted(acc):

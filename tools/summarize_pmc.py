@@ -56,7 +56,7 @@ def per_kernel(d, counter):
 def build_id():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     h = hashlib.sha256()
-    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_blas.h", "cz_h_launch.h"):
+    for f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_rb4.h", "cz_k_blas.h", "cz_h_launch.h"):
         h.update(open(os.path.join(root, "cubez_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -108,7 +108,7 @@ rec = {"kernel": kname, "launches": [nf, nw], "FETCH_SIZE_KiB_raw": fetch_kib, "
 # which build and box the figure belongs to (bench.py prints it beside `traffic` and says whether it is the build it is running)
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _h = hashlib.sha256()
-for _f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_blas.h", "cz_h_launch.h"):
+for _f in ("cz_k_common.h", "cz_k_fastdiv.h", "cz_k_stencil.h", "cz_k_pair.h", "cz_k_pair2.h", "cz_k_rb4.h", "cz_k_blas.h", "cz_h_launch.h"):
     _h.update(open(os.path.join(_root, "cubez_amd", "csrc", _f), "rb").read())
 rec["kernel_source_sha"] = _h.hexdigest()[:16]
 rec["box"] = socket.gethostname()
