@@ -325,11 +325,23 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
 // 129 / 257 in windows of 43 (1.15-1.19 x; 26 and 33 give 1.10 x); FP64 anything from 20 to 33 (1.25-1.32 x).
 inline int rb4_window(int Rfull) { return VW == 4 ? (Rfull < 115 ? 26 : 48) : 28; }
 constexpr int kRb4Win = 48;
+// do the 256-thread preloaded forms of the one-iteration pass (launch_jacobi2: small grids) take this box?  Where they do they beat rb4_k
+// (32^3 .. 80^3: rb4_k 0.67-0.85 x; from 96^3 on, where they no longer fit, 1.00-1.16 x: profiles/r04/rb4_two_iterations_per_pass.txt)
+inline bool pair_small_form_fits(const Box& b) {
+  if (!ctx.tune.t2_pre || ctx.tune.t2_tj != 0 || ctx.tune.t2_threads == 1024) return false;
+  const int R = (b.nkp + VW - 1) / VW;
+  if (4 * R >= 256) return false;
+  const long long S = 256 - 2 * R, nf = (long long)(b.ii1 - b.ii0 + 1) * R, nseg = (nf + S - 1) / S;
+  const int nplanes = b.jj1 - b.jj0 + 1;
+  const long long slots = (long long)std::max(1, ctx.num_cu / 8 - ctx.cu_reserved) * 8;
+  return nseg * ((nplanes + 1) / 2) <= slots || nseg * ((nplanes + 3) / 4) <= slots;
+}
 bool launch_rb4(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const int* skip, const Fin2& fin_in, int par, bool probe) {
   constexpr int V = VW, TB = 1024;
   if (!ctx.tune.rb4 || !ctx.tune.fuse_fin) return false;
   if (!rows_ok(b, {U, B, W}) || !fastdiv_ok(c.dd)) return false;
   if (b.ii0 < 2 || b.jj0 < 2 || b.ii1 > b.nip - 3 || b.jj1 > b.njp - 3) return false;
+  if (ctx.tune.rb4 == 1 && pair_small_form_fits(b)) return false;  // (rb4 = 2: also there -- measurements and tests)
   Geom2 g;
   const int Rfull = (b.nkp + V - 1) / V;
   const int hv = V == 4 ? 1 : 2;  // four stages reach three elements beyond a window

@@ -494,7 +494,7 @@ int czhip_rbsor4_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int
 // rb4_k switches (measurements): enable 0 | 1, vectors per k window, planes per chunk (0: the launcher's rule); negative: keep.
 int czhip_set_rb4(int enable, int window, int planes) {
   ensure_init();
-  if (enable >= 0) ctx.tune.rb4 = enable ? 1 : 0;
+  if (enable >= 0) ctx.tune.rb4 = enable;  // (2: also on the small grids where the preloaded one-iteration pass is faster -- tests)
   if (window >= 0) ctx.tune.rb4_kwin = window;
   if (planes >= 0) ctx.tune.rb4_tj = planes;
   return 0;

@@ -221,7 +221,8 @@ int czhip_rbsor2_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int
 int czhip_rbsor4_async(const CZ_REAL* u, CZ_REAL* w, const CZ_REAL* b, const int* sz, const int* idx, int g, const CZ_REAL* cf, int ofst,
                        CZ_REAL omg, double* res_dev, double res_normal, double eps, int itr, double* hist_dev, int* flag_dev,
                        int* conv_itr_dev, const int* skip_flag_dev, int probe);
-/* ... its switches (measurements; negative = keep): on / off, vectors per k window, planes per chunk (0 = chosen per launch) */
+/* ... its switches (measurements; negative = keep): 0 off / 1 on / 2 on also for small grids (where the preloaded one-iteration pass is faster
+ * and 1 leaves the box to it), vectors per k window, planes per chunk (0 = chosen per launch) */
 int czhip_set_rb4(int enable, int window, int planes);
 /* The fused pass split the way a decomposed brick runs it (replaces the reference's "sweep, then Comm_S",
  * cz_Poisson.cpp:58-63): first the slabs two cells thick behind every face with nID[f] >= 0 (the cells the neighbours

@@ -362,7 +362,7 @@ def test_two_red_black_iterations_per_pass_equal_four_colour_calls(prec, box):
                     ko.psor2sma_core(a1, sz, idx, cf, ofst, color, 1.3, b, wide=wide)
                 r.append(wide[0])
             for (kw, tj) in RB4_FORMS:
-                assert h.lib.czhip_set_rb4(1, kw, tj) == 0
+                assert h.lib.czhip_set_rb4(2, kw, tj) == 0  # (2: also where the launcher would leave a small box to the preloaded one-iteration pass)
                 dw = h.alloc(sz, p)
                 ok, r1, r2 = h.rbsor4(du, dw, db, sz, idx, cf, ofst, 1.3)
                 if ok:

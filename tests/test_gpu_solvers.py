@@ -259,7 +259,7 @@ def test_red_black_sor_two_iterations_per_pass_equals_one_per_pass(prec, gsz, it
     out = {}
     for on in (1, 0):
         cz = CZ(prec, quiet=True)
-        cz.lib.czhip_set_rb4(on, -1, -1)
+        cz.lib.czhip_set_rb4(2 * on, -1, -1)  # (2: also on small grids)
         try:
             assert cz.setup(list(gsz) + ["sor2sma", itmax, coef]) == 1
             itr = cz.solve()

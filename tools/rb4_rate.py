@@ -49,7 +49,7 @@ def run(fn, reps):
 t2 = run(lambda a, b: f2(a.ptr, b.ptr, db.ptr, szp, idxp, None, 2, cfp, 0, 1.5, dres, 0.0, 0.0, 0, None, None, None, None), 60)
 print(f"{prec} {n}^3  one iteration per pass (jacobi2p_k<RB>): {t2 * 1e3:.4f} ms per iteration  {pts / t2 / 1e6:9.0f} MLUPS", flush=True)
 for kw, tj in forms:
-    h.lib.czhip_set_rb4(1, kw, tj)
+    h.lib.czhip_set_rb4(2, kw, tj)
     ok = f4(du.ptr, dw.ptr, db.ptr, szp, idxp, 2, cfp, 0, 1.5, dres, 0.0, 0.0, 0, None, None, None, None, 1)
     if not ok:
         print(f"   rb4 window {kw} chunk {tj}: refused")
