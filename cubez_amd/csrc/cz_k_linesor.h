@@ -1084,8 +1084,11 @@ pcr_line_reg_maf_k(REAL* X, const REAL* __restrict__ MSK, const REAL* __restrict
 constexpr int kPipeCtlStride = 32;  // one 128-byte line per strip counter; ctl[0] = next strip, ctl[1] = error, counters from ctl[kPipeCtlStride]
 
 // one poll of a bounded wait: true when the wait must be given up (time is up, or another workgroup has given up)
+#ifndef CZ_PIPE_SLEEP
+#define CZ_PIPE_SLEEP 1  // (2, 4 and 8 measured in round 4: see profiles/r04/pcr_lex_what_bounds_it.txt)
+#endif
 __device__ __forceinline__ bool pipe_give_up(unsigned& polls, long long& t0, long long limit, unsigned* ctl) {
-  __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_s_sleep(CZ_PIPE_SLEEP);
   if ((++polls & 255u) != 0) return false;
   if (__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
   const long long now = (long long)wall_clock64();
