@@ -22,7 +22,7 @@ enum CzVar {
   // ---- transport (cz_comm.cpp)
   CZV_COMM_TIMEOUT, CZV_COMM_PACK_J, CZV_COMM_ONE_COMM,
   // ---- kernels (czhip_init)
-  CZV_TUNING, CZV_T2, CZV_T2_MAP, CZV_T2_ROWS, CZV_T2_KWIN, CZV_T2_PRE, CZV_RB4, CZV_FUSE_FIN, CZV_PCR, CZV_PCR_PIPE, CZV_PCR_PIPE_PROF, CZV_PCR_WG_PER_CU, CZV_PCR_MAX_WG, CZV_PCR_SLOTS, CZV_PSOR,
+  CZV_TUNING, CZV_T2, CZV_T2_MAP, CZV_T2_ROWS, CZV_T2_KWIN, CZV_T2_PRE, CZV_RB4, CZV_UNIT_COEF, CZV_FUSE_FIN, CZV_PCR, CZV_PCR_PIPE, CZV_PCR_PIPE_PROF, CZV_PCR_WG_PER_CU, CZV_PCR_MAX_WG, CZV_PCR_SLOTS, CZV_PSOR,
   // ---- diagnostics
   CZV_FATAL_LOG,
   CZV_COUNT
@@ -63,6 +63,7 @@ inline const CzVarDef* cz_var_defs() {
       {"CZHIP_T2_KWIN", "", "two-stage pass: vectors per k window (0 = whole rows where they fit, -1 = chosen per launch)"},
       {"CZHIP_T2_PRE", "1", "two-stage pass on small grids: all operands of a chunk requested before its first plane step (jacobi2p_k<PRE>)"},
       {"CZHIP_RB4", "1", "red-black SOR, single domain: two iterations per pass over memory (rb4_k) \"enable[,vectors per window[,planes per chunk]]\""},
+      {"CZHIP_UNIT_COEF", "1", "jacobi2p_k / rb4_k: the form without the six multiplications where the six coefficients are exactly 1 (same bits)"},
       {"CZHIP_FUSE_FIN", "1", "residual finalised by the last workgroup of the sweep (0: separate reduce + check launches)"},
       {"CZHIP_PCR", "", "line SOR form \"fast[,variant]\": 0 literal, 1 table + d in LDS, 2 table + d in registers"},
       {"CZHIP_PCR_PIPE", "", "lexicographic line SOR \"one_launch[,timeout s[,groups[,rows per thread]]]\""},

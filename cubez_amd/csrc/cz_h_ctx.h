@@ -21,6 +21,7 @@ struct Tuning {
                                               // the balance model (pair_tj_model, cz_h_launch.h); CZHIP_T2=enable,threads,2,tj fixes them
   int t2_kwin = -1;                               // two-stage pass: vectors per k window; -1 = chosen per launch, 0 = whole rows where they fit (CZHIP_T2_KWIN)
   int rb4 = 1, rb4_kwin = 0, rb4_tj = 0;          // two red-black iterations per pass (rb4_k) in single-domain runs; vectors per k window / planes per chunk (0: the launcher's rule); CZHIP_RB4
+  int unit_coef = 1;                              // the kernels' form for coefficients that are all exactly 1 (offdiag_sum<UNIT>; CZHIP_UNIT_COEF)
   int t2_pre = 1;                                 // two-stage pass on small grids: every operand of a chunk requested before its first step (jacobi2p_k<PRE>; CZHIP_T2_PRE)
   int t2_map = 1;                                 // two-stage pass: equal shares of (segment, chunk) items per XCD (CZHIP_T2_MAP=0: whole-segment bands)
   int use_t2 = 1;                                 // driver may fuse pairs of Jacobi sweeps (single-domain runs)  // 1: residual finalised by the last workgroup of the sweep; 0: separate reduce(+check) launches

@@ -175,8 +175,13 @@ inline bool pair_use_map(int nseg) { return ctx.tune.t2_map && 10 * nseg < 9 * 8
 constexpr int kPairWin = 176;
 inline bool pair_whole_rows_ok(int Rfull, int /*LV*/) { return Rfull <= 192; }
 
+// c1 .. c6 all exactly 1: the kernels may leave the six multiplications out (offdiag_sum<UNIT>, cz_k_common.h)
+inline bool coef_is_unit(const Coef& c) {
+  return c.c1 == (REAL)1 && c.c2 == (REAL)1 && c.c3 == (REAL)1 && c.c4 == (REAL)1 && c.c5 == (REAL)1 && c.c6 == (REAL)1;
+}
+
 // two fused sweeps (jacobi2p_k); returns false when the geometry does not suit the kernel (caller falls back to two stencil_k launches)
-template <int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0, int PRE = 0>
+template <int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0, int PRE = 0, int UNIT = 0>
 bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box& b, const Box& ba, int tj_req,
                          const int* skip, const Fin2& fin_in, int par, bool probe, double* model_cost, const MafArgs& ma = MafArgs(),
                          const BSrc& bs = BSrc()) {
@@ -242,7 +247,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS, PRE, UNIT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   160 * 1024));
     attr_set = true;
   }
@@ -250,7 +255,7 @@ bool launch_jacobi2_inst(const REAL* U, const REAL* B, REAL* W, const Coef& c, c
   fin.counter = ctx.counter;
   {
     ScopedTimer tm(RB ? LBL_RBSOR2 : LBL_JACOBI2);
-    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS, PRE>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin, ma, bs);
+    hipLaunchKernelGGL((jacobi2p_k<V, TB, MV, RB, ZU, MAF, BS, PRE, UNIT>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin, ma, bs);
   }
   HIP_CHECK(hipGetLastError());
   return true;
@@ -312,6 +317,12 @@ bool launch_jacobi2(const REAL* U, const REAL* B, REAL* W, const Coef& c, const 
   if ((tu.t2_pre == 1 || tu.t2_pre == TB_ * 10 + PRE_) && launch_jacobi2_inst<TB_, MV_, RB, 0, 0, 0, PRE_>(U, B, W, c, b, ba, 0, skip, fin, par, false, nullptr)) return true;
     CZ_PRE(256, 1, 2) CZ_PRE(256, 1, 4) CZ_PRE(512, 2, 2) CZ_PRE(512, 2, 3) CZ_PRE(512, 2, 4)
 #undef CZ_PRE
+  }
+  // unit coefficients (what CZ sets: cz.h:169-172): the Jacobi pair without the six multiplications per point -- 2-3 % at 512^3 FP32, where the
+  // vector ALU is 77 % busy; the red-black pair is bound by memory and keeps one form (profiles/r04/unit_coefficients.txt)
+  if (RB == 0 && tu.unit_coef && coef_is_unit(c)) {
+    if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 0, 0, 0, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
+    return launch_jacobi2_inst<1024, 2, RB, 0, 0, 0, 0, 1>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
   }
   if (tb == 512) return launch_jacobi2_inst<512, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
   return launch_jacobi2_inst<1024, 2, RB, 0>(U, B, W, c, b, ba, tu.t2_tj, skip, fin, par, probe, nullptr);
@@ -386,15 +397,21 @@ bool launch_rb4(const REAL* U, const REAL* B, REAL* W, const Coef& c, const Box&
   ensure_partials((size_t)2 * nblk);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rb4_k<V, TB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rb4_k<V, TB, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rb4_k<V, TB, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   Fin2 fin = fin_in;
   fin.counter = ctx.counter;
   fin.single = 0;
   {
+    // (unit coefficients: rb4_k is an arithmetic kernel -- vector ALU 93 % busy -- and the six multiplications are a fifth of a point's
+    // instructions: 6-7 % at 512^3 FP32, profiles/r04/unit_coefficients.txt)
     ScopedTimer tm(LBL_RBSOR4);
-    hipLaunchKernelGGL((rb4_k<V, TB>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
+    if (ctx.tune.unit_coef && coef_is_unit(c))
+      hipLaunchKernelGGL((rb4_k<V, TB, 1>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
+    else
+      hipLaunchKernelGGL((rb4_k<V, TB, 0>), dim3((unsigned)nblk), dim3(TB), lds, ctx.stream, U, B, W, c, g, ctx.partials, skip, fin);
   }
   HIP_CHECK(hipGetLastError());
   return true;

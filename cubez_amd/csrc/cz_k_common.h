@@ -8,6 +8,14 @@ struct alignas(sizeof(REAL) * V) Vec {
 struct Coef {
   REAL c1, c2, c3, c4, c5, c6, dd, omg;
 };
+// The six off-diagonal terms of a point (cz_solver.f90:335-341, 436-441).  UNIT: c1 .. c6 are all exactly 1 -- what CZ::CZ sets and never
+// changes (cz.h:169-172) -- and x * 1 is x: the same sum in the same order without the six multiplications, hence the same bits; the
+// launchers take this form only after comparing the six coefficients with 1 (coef_is_unit, cz_h_launch.h).
+template <int UNIT>
+__device__ __forceinline__ REAL offdiag_sum(const Coef& c, REAL ip, REAL im, REAL pn, REAL pm, REAL kp1, REAL km1) {
+  if (UNIT) return ip + im + pn + pm + kp1 + km1;
+  return c.c1 * ip + c.c2 * im + c.c3 * pn + c.c4 * pm + c.c5 * kp1 + c.c6 * km1;
+}
 
 // Geometry of one launch, all in PADDED 0-based indices (kk = k+g-1, ...).
 struct Geom {

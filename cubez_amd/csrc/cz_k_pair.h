@@ -110,7 +110,7 @@ struct MediumDiv {
   __device__ __forceinline__ REAL operator()(REAL n) const { return mediumdiv(n, f); }
 };
 
-template <int V, class DIV>
+template <int V, int UNIT = 0, class DIV>
 __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, const Vec<V>& ip, const Vec<V>& pm,
                                             const Vec<V>& pn, REAL kl, REAL kr, const Vec<V>& bb, const Coef& c, const DIV& dv,
                                             unsigned mask, unsigned count_mask, double& acc) {
@@ -123,7 +123,7 @@ __device__ __forceinline__ Vec<V> relax_vec(const Vec<V>& pc, const Vec<V>& im, 
     const REAL pp = pc.v[cc];
     const REAL km1 = (cc == 0) ? kl : pc.v[cc > 0 ? cc - 1 : 0];
     const REAL kp1 = (cc == V - 1) ? kr : pc.v[cc < V - 1 ? cc + 1 : V - 1];
-    const REAL ss = c.c1 * ip.v[cc] + c.c2 * im.v[cc] + c.c3 * pn.v[cc] + c.c4 * pm.v[cc] + c.c5 * kp1 + c.c6 * km1;
+    const REAL ss = offdiag_sum<UNIT>(c, ip.v[cc], im.v[cc], pn.v[cc], pm.v[cc], kp1, km1);
     const REAL dp = (dv(ss - bb.v[cc]) - pp) * c.omg;
     const REAL d2 = dp * dp;
     o.v[cc] = (mask & (1u << cc)) ? pp + dp : pp;

@@ -110,6 +110,44 @@ __device__ __forceinline__ Vec<V> relax_vec_rb(const Vec<V>& pc_, const Vec<V>& 
   return r;
 }
 
+// The same stage where the colour offset s is (nearly always) the same in all lanes of a wave -- rb4_k deals its vectors so that a wave holds rows
+// of one parity: a branch on s instead of selects.  With s a constant of each side the operand selects of relax_vec_rb (8 per point, a quarter of
+// the stage's vector instructions) fold away; a wave whose lanes disagree runs both sides under their masks.  Same operations on the same values.
+template <int V, int S, class F>
+__device__ __forceinline__ typename NatVec<V>::type relax_rb_side(const typename NatVec<V>::type& pc, const typename NatVec<V>::type& im,
+                                                                  const typename NatVec<V>::type& ip, const typename NatVec<V>::type& pm,
+                                                                  const typename NatVec<V>::type& pn, REAL kl, REAL kr,
+                                                                  const typename NatVec<V>::type& bb, unsigned mask, unsigned count_mask, double& acc,
+                                                                  const F& point) {
+  auto o = pc;
+#pragma unroll
+  for (int a = 0; a < V / 2; a++) {
+    const int cc = 2 * a + S;  // the slot's component
+    const REAL pp = pc[cc];
+    const REAL km1 = (cc == 0) ? kl : pc[cc > 0 ? cc - 1 : 0];
+    const REAL kp1 = (cc == V - 1) ? kr : pc[cc < V - 1 ? cc + 1 : V - 1];
+    const REAL dp = point(pp, ip[cc], im[cc], pn[cc], pm[cc], kp1, km1, bb[cc], (REAL)0, (REAL)0);
+    const REAL d2 = dp * dp;
+    o[cc] = (mask & (1u << cc)) ? pp + dp : pp;
+    acc += (double)((count_mask & (1u << cc)) ? d2 : (REAL)0);
+  }
+  return o;
+}
+template <int V, class F>
+__device__ __forceinline__ Vec<V> relax_vec_rb_branch(const Vec<V>& pc_, const Vec<V>& im_, const Vec<V>& ip_, const Vec<V>& pm_, const Vec<V>& pn_,
+                                                      REAL kl, REAL kr, const Vec<V>& bb_, bool s, unsigned mask, unsigned count_mask, double& acc,
+                                                      const F& point) {
+  static_assert(V == 2 || V == 4, "vector of two or four components");
+  const auto pc = as_native<V>(pc_), im = as_native<V>(im_), ip = as_native<V>(ip_), pm = as_native<V>(pm_), pn = as_native<V>(pn_),
+             bb = as_native<V>(bb_);
+  typename NatVec<V>::type o;
+  if (s) o = relax_rb_side<V, 1>(pc, im, ip, pm, pn, kl, kr, bb, mask, count_mask, acc, point);
+  else o = relax_rb_side<V, 0>(pc, im, ip, pm, pn, kl, kr, bb, mask, count_mask, acc, point);
+  Vec<V> r;
+  __builtin_memcpy(&r, &o, sizeof(r));
+  return r;
+}
+
 // ZU = 1: the input field is identically zero and is not read (the first pair of a preconditioner solve).
 // MAF = 1: weights from the 1-D coordinate arrays `ma` (device copies; index = padded index for g = 2) instead of c.
 // BS = 1 | 2 (with ZU = 1): the right-hand side is not read but MADE, point by point, from the vectors the preceding element-wise update of
@@ -122,12 +160,13 @@ __device__ __forceinline__ Vec<V> relax_vec_rb(const Vec<V>& pc_, const Vec<V>& 
 // pass is resident at once, a chunk is two or three planes, and the launch lasts as long as ONE workgroup's chain of dependent round trips:
 // three in the prologue and one per step, 16-24 us for 2-4 us of work (profiles/r03/small_grids_chunk_length.txt).  With everything in flight
 // at once it is one round trip, then n + 2 steps of LDS and arithmetic.  Same operations on the same values: same bits.
-template <int V, int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0, int PRE = 0>
+template <int V, int TB, int MV, int RB, int ZU, int MAF = 0, int BS = 0, int PRE = 0, int UNIT = 0>
 __global__ void __launch_bounds__(TB, (TB == 512 && !MAF && !PRE) ? 4 : 1)  // (MAF, 512 threads: 256 registers instead of 21-30 spilled)
 jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
            const int* __restrict__ skip, Fin2 fin, MafArgs ma, BSrc bs) {
   static_assert(BS == 0 || (ZU == 1 && MAF == 0), "a made right-hand side belongs to the first pass of a preconditioner solve");
   static_assert(PRE == 0 || (ZU == 0 && MAF == 0 && BS == 0), "the preloaded form is the plain pass");
+  static_assert(UNIT == 0 || MAF == 0, "unit coefficients are constant coefficients");
   if (skip != nullptr && *skip != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int t = threadIdx.x;
@@ -439,14 +478,14 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
             } else {
               vc[m] = relax_vec_rb<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], ZT, ZTT, sc, msk, cnt & msk, acc1,
                                       [&](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL, REAL) {
-                                        const REAL ss = c.c1 * ipv + c.c2 * imv + c.c3 * pnv + c.c4 * pmv + c.c5 * kp1 + c.c6 * km1;
+                                        const REAL ss = offdiag_sum<UNIT>(c, ipv, imv, pnv, pmv, kp1, km1);
                                         return (dv(ss - bv) - pp) * c.omg;
                                       });
             }
           } else if (MAF) {
             vc[m] = relax_vec_maf<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], XG[m], XGG[m], YE1, YEE1, ZT, ZTT, c.omg, msk, cnt & msk, acc1);
           } else {
-            vc[m] = relax_vec<V>(pc, im, ip, pm, uc[m], kl, kr, b1[m], c, dv, msk, cnt & msk, acc1);
+            vc[m] = relax_vec<V, UNIT>(pc, im, ip, pm, uc[m], kl, kr, b1[m], c, dv, msk, cnt & msk, acc1);
           }
         }
       } else {
@@ -491,14 +530,14 @@ jacobi2p_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restr
               } else {
                 o = relax_vec_rb<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], ZT, ZTT, sc, m2, m2, acc2,
                                     [&](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL, REAL) {
-                                      const REAL ss = c.c1 * ipv + c.c2 * imv + c.c3 * pnv + c.c4 * pmv + c.c5 * kp1 + c.c6 * km1;
+                                      const REAL ss = offdiag_sum<UNIT>(c, ipv, imv, pnv, pmv, kp1, km1);
                                       return (dv(ss - bv) - pp) * c.omg;
                                     });
               }
             } else if (MAF) {
               o = relax_vec_maf<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], XG[m], XGG[m], YE2, YEE2, ZT, ZTT, c.omg, m2, m2, acc2);
             } else {
-              o = relax_vec<V>(vb, im, ip, pm, vc[m], kl, kr, b2[m], c, dv, m2, m2, acc2);
+              o = relax_vec<V, UNIT>(vb, im, ip, pm, vc[m], kl, kr, b2[m], c, dv, m2, m2, acc2);
             }
             if (own[m] == (1u << V) - 1) {
               st16<V>(Wq, bo[m], o);

@@ -13,10 +13,15 @@
 //     k windows   KT vectors + hv halo vectors per side; four stages reach 3 elements beyond a window: hv = 1 (FP32), 2 (FP64)
 //     planes      stage s at step q works on plane q - s + 1: f1(q) from u(q-1..q+1), f2(q-1) from f1, f3(q-2), f4(q-3) -> W
 // Same per-point operations on the same values as four psor2sma_core_ calls => the same bits (relax_vec_rb is the stage of jacobi2p_k).
+// Threads -> vectors: which components of a vector a stage updates depends on the parity of its ROW (k of component 0 is even in every window);
+// E3 is therefore dealt out by row parity -- threads 0 .. nA-1 take the first row of E3 and every second one after it, the others the rows in
+// between -- so that all lanes of a wave (one wave of the sixteen excepted) agree on the colour offset and a stage BRANCHES on it instead of
+// selecting every operand per lane (relax_vec_rb_branch): the selects were a quarter of the vector instructions of a kernel whose vector ALU
+// is 93 % busy (profiles/r04/rb4_two_iterations_per_pass.txt).  LDS and memory are indexed by the vector (x), not by the thread.
 // Both residuals are produced (iteration n+1 = stages 1 + 2, iteration n+2 = stages 3 + 4); if the FIRST of the two iterations converges
 // the driver re-runs that single iteration from the untouched input (out of place, like the Jacobi pair).
 // ------------------------------------------------------------------------------------------------------------
-template <int V, int TB>
+template <int V, int TB, int UNIT>
 __global__ void __launch_bounds__(TB, 1)
 rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__ W, Coef c, Geom2 g, double* partials,
       const int* __restrict__ skip, Fin2 fin) {
@@ -77,8 +82,22 @@ rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__
     };
     auto lim = [&](unsigned off, int plane) -> unsigned { return plane == g.jlast ? (off < g.last_off ? off : g.last_off) : off; };
     auto pl = [&](int p) -> int { return p < 0 ? 0 : (p > g.jlast ? g.jlast : p); };  // planes beyond the array are never used: clamped
-    // this thread's vector
-    const long long f = e3_0 + t;
+    // this thread's vector: x = its index in E3, rows dealt by parity (see the head of the file)
+    int x;
+    {
+      const int off = (int)(((e3_0 % R) + R) % R);
+      const int L0 = off == 0 ? R : R - off;  // vectors of the first row of E3
+      int nA = L0;                            // vectors in the first row and every second row after it
+      for (int st = L0 + R; st < LV; st += 2 * R) nA += min(R, LV - st);
+      if (t < nA) {
+        const int m = t - L0, j = m / R;
+        x = t < L0 ? t : L0 + R + 2 * R * j + (m - j * R);
+      } else {
+        const int n = t - nA, j = n / R;
+        x = L0 + 2 * R * j + (n - j * R);
+      }
+    }
+    const long long f = e3_0 + x;
     const unsigned bo = off_of(f);
     unsigned inbox = 0;  // components inside the inner box (every stage updates only those)
     unsigned own = 0;    // ... of a vector this workgroup owns (stores, residual counts)
@@ -98,7 +117,7 @@ rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__
       const bool rows_in = f >= g.F0 && f < g.Fend;
       inbox = rows_in ? bits : 0u;
       const bool kown = kv >= g.hv && kv < g.hv + g.KT;
-      own = (t >= 3 * R && t < LV - 3 * R && rows_in && kown) ? bits : 0u;
+      own = (x >= 3 * R && x < LV - 3 * R && rows_in && kown) ? bits : 0u;
     }
     // the outer rows of E4: the first R threads stage the lower one, the last R threads the upper one
     const bool has_halo = (t < R) || (t >= TB - R);
@@ -117,31 +136,36 @@ rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__
       const Vec<V> h1 = ld16<V>(Ub + (size_t)pl(q0) * PB, lim(hbo, pl(q0)));
       uA = ld16<V>(Ub + (size_t)pl(q0 + 1) * PB, lim(bo, pl(q0 + 1)));
       bA = ld16<V>(Bb + (size_t)pl(q0) * PB, lim(bo, pl(q0)));
-      ldsU[(size_t)((q0 - 1) & 1) * LU + R + t] = t2;
-      ldsU[(size_t)(q0 & 1) * LU + R + t] = t1;
+      ldsU[(size_t)((q0 - 1) & 1) * LU + R + x] = t2;
+      ldsU[(size_t)(q0 & 1) * LU + R + x] = t1;
       if (has_halo) ldsU[(size_t)(q0 & 1) * LU + hl] = h1;
     }
     Vec<V> bq1 = zerov<V>(), bq2 = zerov<V>(), bq3 = zerov<V>();  // b of the planes of stages 2, 3, 4
     __syncthreads();
 
-    const int w0 = t & ~63;  // first lane of the wave
+    // (a wave that lies wholly outside the set of a stage -- E2 for stage 2, E1 for stage 3 -- skips it: nothing valid reads its result)
+    const bool in2 = __builtin_amdgcn_ballot_w64(x >= R && x < LV - R) != 0ull, in3 = __builtin_amdgcn_ballot_w64(x >= 2 * R && x < LV - 2 * R) != 0ull;
+    // the k neighbours beyond the wave's first and last vector come from LDS (one element each, the same address in all lanes)
+    const int x_first = __builtin_amdgcn_readfirstlane(x), x_last = __builtin_amdgcn_readlane(x, 63);
     // one stage: the field `fin_` (centre plane p in LDS buffer `cur`, own vector of plane p-1 in `prv`, plane p+1 in `nxt`) -> the stage's result
     auto stage = [&](const Vec<V>* cur, const Vec<V>* prv, int x, const Vec<V>& nxt, const Vec<V>& bb, int p, int colour, unsigned msk, unsigned cnt,
-                     double& acc) __attribute__((always_inline)) -> Vec<V> {
-      const int xw = x - (t - w0);
+                     double& acc, const bool first = false) __attribute__((always_inline)) -> Vec<V> {
       const Vec<V> pc = lds_ld<V>(cur + x);
       const Vec<V> im = lds_ld<V>(cur + x - R);
       const Vec<V> ip = lds_ld<V>(cur + x + R);
       const Vec<V> pm = lds_ld<V>(prv + x);
-      const REAL elo = reinterpret_cast<const REAL*>(cur)[(long long)xw * V - 1];
-      const REAL ehi = reinterpret_cast<const REAL*>(cur)[(long long)(xw + 64) * V];
+      const REAL elo = reinterpret_cast<const REAL*>(cur)[(long long)x_first * V - 1];
+      const REAL ehi = reinterpret_cast<const REAL*>(cur)[(long long)(x_last + 1) * V];
       const REAL kl = lane_shr1(elo, pc.v[V - 1]);
-      const REAL kr = lane_shl1(ehi, pc.v[0]);
+      REAL kr = lane_shl1(ehi, pc.v[0]);
+      // The last vector of E3 is not the last lane of a wave (rows are dealt by parity), and stage 1 needs its true neighbour -- the first
+      // vector of E4's upper row: the corner of the dependence cone of the last owned vector runs through it.  (E3's first vector is thread 0,
+      // lane 0: `elo`.  In the later stages both ends lie outside the stage's set.)
+      if (first) kr = (x == LV - 1) ? reinterpret_cast<const REAL*>(cur)[(long long)LV * V] : kr;
       const bool sc = ((pbase + p + colour) & 1) != 0;
-      const Vec<V> z = zerov<V>();
-      return relax_vec_rb<V>(pc, im, ip, pm, nxt, kl, kr, bb, z, z, sc, msk, cnt, acc,
+      return relax_vec_rb_branch<V>(pc, im, ip, pm, nxt, kl, kr, bb, sc, msk, cnt, acc,
                              [&](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL, REAL) {
-                               const REAL ss = c.c1 * ipv + c.c2 * imv + c.c3 * pnv + c.c4 * pmv + c.c5 * kp1 + c.c6 * km1;
+                               const REAL ss = offdiag_sum<UNIT>(c, ipv, imv, pnv, pmv, kp1, km1);
                                return (dv(ss - bv) - pp) * c.omg;
                              });
     };
@@ -156,29 +180,27 @@ rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__
       }
       // planes of the four stages and whether they lie in the inner box (outside it a stage leaves the plane alone)
       const int p1 = q, p2 = q - 1, p3 = q - 2, p4 = q - 3;
-      const Vec<V>* cU = ldsU + (size_t)(p1 & 1) * LU + R;  // u(p1) in E3 coordinates (index t)
+      const Vec<V>* cU = ldsU + (size_t)(p1 & 1) * LU + R;  // u(p1) in E3 coordinates (index x)
       const Vec<V>* pU = ldsU + (size_t)((p1 - 1) & 1) * LU + R;
       Vec<V>* F1 = ldsF;
       Vec<V>* F2 = ldsF + (size_t)2 * LV;
       Vec<V>* F3 = ldsF + (size_t)4 * LV;
       // ---- stage 1: f1(p1), colour 0, every vector of E3
       Vec<V> v1;
-      if (p1 >= g.jj0 && p1 <= g.jj1) v1 = stage(cU, pU, t, uc, b1, p1, 0, inbox, (p1 >= ja && p1 <= jb) ? own : 0u, acc1);
-      else v1 = lds_ld<V>(cU + t);
-      // (a wave that lies wholly outside the set of a stage -- E2 for stage 2, E1 for stage 3 -- skips it: nothing valid reads its result)
-      const bool in2 = w0 + 63 >= R && w0 < LV - R, in3 = w0 + 63 >= 2 * R && w0 < LV - 2 * R;
+      if (p1 >= g.jj0 && p1 <= g.jj1) v1 = stage(cU, pU, x, uc, b1, p1, 0, inbox, (p1 >= ja && p1 <= jb) ? own : 0u, acc1, true);
+      else v1 = lds_ld<V>(cU + x);
       // ---- stage 2: f2(p2), colour 1, from f1(p2 - 1) [LDS], f1(p2) [LDS], f1(p1) [v1]
       Vec<V> v2;
-      if (in2 && p2 >= g.jj0 && p2 <= g.jj1) v2 = stage(F1 + (size_t)(p2 & 1) * LV, F1 + (size_t)((p2 - 1) & 1) * LV, t, v1, bq1, p2, 1, inbox, (p2 >= ja && p2 <= jb) ? own : 0u, acc1);
-      else v2 = lds_ld<V>(F1 + (size_t)(p2 & 1) * LV + t);
+      if (in2 && p2 >= g.jj0 && p2 <= g.jj1) v2 = stage(F1 + (size_t)(p2 & 1) * LV, F1 + (size_t)((p2 - 1) & 1) * LV, x, v1, bq1, p2, 1, inbox, (p2 >= ja && p2 <= jb) ? own : 0u, acc1);
+      else v2 = lds_ld<V>(F1 + (size_t)(p2 & 1) * LV + x);
       // ---- stage 3: f3(p3), colour 0
       Vec<V> v3;
-      if (in3 && p3 >= g.jj0 && p3 <= g.jj1) v3 = stage(F2 + (size_t)(p3 & 1) * LV, F2 + (size_t)((p3 - 1) & 1) * LV, t, v2, bq2, p3, 0, inbox, (p3 >= ja && p3 <= jb) ? own : 0u, acc2);
-      else v3 = lds_ld<V>(F2 + (size_t)(p3 & 1) * LV + t);
+      if (in3 && p3 >= g.jj0 && p3 <= g.jj1) v3 = stage(F2 + (size_t)(p3 & 1) * LV, F2 + (size_t)((p3 - 1) & 1) * LV, x, v2, bq2, p3, 0, inbox, (p3 >= ja && p3 <= jb) ? own : 0u, acc2);
+      else v3 = lds_ld<V>(F2 + (size_t)(p3 & 1) * LV + x);
       // ---- stage 4: f4(p4) = the output, colour 1, owned vectors of the chunk's planes.  Whole waves: the k neighbours travel by lane
       // shifts, and the lane next to the first owned vector of a window holds a halo vector -- it owns nothing but must take part.
       if (p4 >= ja && __builtin_amdgcn_ballot_w64(own != 0) != 0ull) {
-        const Vec<V> o = stage(F3 + (size_t)(p4 & 1) * LV, F3 + (size_t)((p4 - 1) & 1) * LV, t, v3, bq3, p4, 1, own, own, acc2);
+        const Vec<V> o = stage(F3 + (size_t)(p4 & 1) * LV, F3 + (size_t)((p4 - 1) & 1) * LV, x, v3, bq3, p4, 1, own, own, acc2);
         char* Wq = Wb + (size_t)p4 * PB;
         if (own == (1u << V) - 1) {
           st16<V>(Wq, bo, o);
@@ -190,11 +212,11 @@ rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__
         }
       }
       // ---- publish: f1(p1), f2(p2), f3(p3) and the next u centre plane u(q+1) with its outer rows
-      F1[(size_t)(p1 & 1) * LV + t] = v1;
-      F2[(size_t)(p2 & 1) * LV + t] = v2;
-      F3[(size_t)(p3 & 1) * LV + t] = v3;
+      F1[(size_t)(p1 & 1) * LV + x] = v1;
+      F2[(size_t)(p2 & 1) * LV + x] = v2;
+      F3[(size_t)(p3 & 1) * LV + x] = v3;
       Vec<V>* nU = ldsU + (size_t)((p1 + 1) & 1) * LU;
-      nU[R + t] = uc;
+      nU[R + x] = uc;
       if (has_halo) nU[hl] = hx;
       bq3 = bq2, bq2 = bq1, bq1 = b1;  // (b1 is complete: stage 1 used it)
       __syncthreads();

@@ -179,6 +179,7 @@ int czhip_init(int device) {
   ctx.tune.t2_any_rows = cfg.on(CZV_T2_ROWS, ctx.tune.t2_any_rows != 0) ? 1 : 0;
   ctx.tune.t2_kwin = cfg.num(CZV_T2_KWIN, ctx.tune.t2_kwin);
   ctx.tune.t2_pre = cfg.num(CZV_T2_PRE, ctx.tune.t2_pre);
+  ctx.tune.unit_coef = cfg.num(CZV_UNIT_COEF, ctx.tune.unit_coef);
   if (const char* v = cfg.str(CZV_RB4)) {  // "enable[,vectors per window[,planes per chunk]]"
     int en = 1, kw = 0, tj = 0;
     sscanf(v, "%d,%d,%d", &en, &kw, &tj);
@@ -544,6 +545,15 @@ int czhip_set_pair_preload(int enable) {
   ensure_init();
   const int before = ctx.tune.t2_pre;
   if (enable >= 0) ctx.tune.t2_pre = enable;  // (TB * 10 + PRE: that form only -- measurements)
+  return before;
+}
+
+// the kernels' form for unit coefficients (offdiag_sum<UNIT>: c1 .. c6 all exactly 1, as CZ sets them): 1 = taken where the coefficients allow
+// (default), 0 = never; negative: keep.  Returns the setting that was in force.  Same bits either way.
+int czhip_set_unit_coef(int enable) {
+  ensure_init();
+  const int before = ctx.tune.unit_coef;
+  if (enable >= 0) ctx.tune.unit_coef = enable;
   return before;
 }
 

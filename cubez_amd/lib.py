@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "czhip_real_bytes", "czhip_arch", "czhip_init", "czhip_finalize", "czhip_alloc_s3d", "czhip_free", "czhip_h2d",
     "czhip_d2h", "czhip_sync", "czhip_stream", "czhip_set_tuning", "czhip_get_tuning",
     "czhip_jacobi_async", "czhip_rbsor_async", "czhip_check_async", "czhip_jacobi_checked_async",
-    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_set_pcr_mode", "czhip_set_pcr_lex", "czhip_set_pcr_lex_timeout", "czhip_set_pcr_lex_limits", "czhip_set_psor", "czhip_set_psor_ahead", "czhip_use_t2", "czhip_set_pair_window", "czhip_set_pair_preload", "czhip_config_describe", "czhip_set_comm_cus", "czhip_selftest_fastdiv", "czhip_pair_maf_async", "czhip_rbsor2_async", "czhip_rbsor4_async", "czhip_set_rb4", "czhip_jacobi2_from_zero_async", "czhip_jacobi2_from_zero_made_async", "czhip_check2_async", "czhip_pair_split_async", "psor_", "psor_maf_", "pcr_", "pcr_eda_", "pcr_esa_", "pcr_rb_esa_", "pcr_j_esa_", "pcr_rb_maf_", "pcr_rb_esa_maf_", "pcr_maf_", "pcr_eda_maf_", "pcr_esa_maf_",
+    "czhip_rbsor_checked_async", "czhip_jacobi2_async", "czhip_set_tuning2", "czhip_set_pcr_mode", "czhip_set_pcr_lex", "czhip_set_pcr_lex_timeout", "czhip_set_pcr_lex_limits", "czhip_set_psor", "czhip_set_psor_ahead", "czhip_use_t2", "czhip_set_pair_window", "czhip_set_pair_preload", "czhip_set_unit_coef", "czhip_config_describe", "czhip_set_comm_cus", "czhip_selftest_fastdiv", "czhip_pair_maf_async", "czhip_rbsor2_async", "czhip_rbsor4_async", "czhip_set_rb4", "czhip_jacobi2_from_zero_async", "czhip_jacobi2_from_zero_made_async", "czhip_check2_async", "czhip_pair_split_async", "psor_", "psor_maf_", "pcr_", "pcr_eda_", "pcr_esa_", "pcr_rb_esa_", "pcr_j_esa_", "pcr_rb_maf_", "pcr_rb_esa_maf_", "pcr_maf_", "pcr_eda_maf_", "pcr_esa_maf_",
     "cz_create", "cz_destroy", "cz_evaluate", "cz_setup", "cz_solve", "cz_sweeps", "cz_result_iter", "cz_result_res",
     "cz_history", "cz_field", "cz_local_size", "cz_error_max", "cz_set_quiet", "cz_last_solve_seconds", "cz_kernel_ms",
     "cz_set_debug", "cz_set_profile", "cz_info", "czhip_timing", "czhip_timing_read",

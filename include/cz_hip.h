@@ -286,6 +286,10 @@ int czhip_set_pair_window(int vectors);
 /* Small grids (every workgroup of a pass resident at once): the pass requests all operands of a chunk before its first plane step instead of one
  * plane ahead; 1 = on (default), 0 = off, negative = keep.  Returns the previous setting.  Results do not depend on it. */
 int czhip_set_pair_preload(int enable);
+/* The reference's coefficients are c1 .. c6 = 1, dd = 6 (cz.h:169-172): where the six are exactly 1 the Jacobi pass and the two-iteration red-black
+ * pass take a form without the six multiplications (x * 1 is x: same sum, same order).  1 = on (default), 0 = always the general form, negative =
+ * keep.  Returns the previous setting.  Results do not depend on it. */
+int czhip_set_unit_coef(int enable);
 /* Every environment variable the library and the cz command line read (one table, cubez_amd/csrc/cz_config.h), one per line: NAME=value where set,
  * NAME (unset; default ...) otherwise; only_set != 0 lists the former only.  The string lives until the next call on the calling thread. */
 const char* czhip_config_describe(int only_set);

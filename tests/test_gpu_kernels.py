@@ -378,6 +378,72 @@ def test_two_red_black_iterations_per_pass_equal_four_colour_calls(prec, box):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("box", T2_BOXES, ids=[f"{b[0][0]}x{b[0][1]}x{b[0][2]}{'' if b[1] is None else '_idx'}" for b in T2_BOXES])
+def test_unit_coefficient_forms_equal_the_oracle_and_the_general_forms(prec, box):
+    """The reference's coefficients are c1 .. c6 = 1, dd = 6 (cz.h:169-172).  Where the six are exactly 1 the Jacobi pair and the two-iteration
+    red-black pass leave the six multiplications out (offdiag_sum<UNIT>): == the oracle with those coefficients and == the general form
+    (czhip_set_unit_coef(0)), bit for bit, residuals to the last bit between the two forms.  A coefficient one ULP from 1 takes the general form
+    and differs from the unit result somewhere (the switch looks at the values, not at a promise)."""
+    (ni, nj, nk), idx = box
+    sz = [ni, nj, nk]
+    idx = list(idx) if idx else [2, ni - 1, 2, nj - 1, 2, nk - 1]
+    h, ko = _hip(prec), O.Kernels("oracle", prec)
+    R = ko.real
+    rng = np.random.default_rng(11 * ni + 3 * nj + 7 * nk)
+    shape = (nj + 4, ni + 4, nk + 4)
+    cf = np.array([1, 1, 1, 1, 1, 1, 6], dtype=R)
+    p, b = (rng.uniform(-1, 1, shape).astype(R) for _ in range(2))
+    aj, wj = p.copy(), np.zeros_like(p)
+    for _ in range(2):
+        ko.jacobi(aj, sz, idx, cf, 0.9, b, wj, wide=np.zeros(1))
+    ar = p.copy()
+    for it in range(2):
+        for color in (0, 1):
+            ko.psor2sma_core(ar, sz, idx, cf, 0, color, 1.3, b, wide=np.zeros(1))
+    du, db = h.alloc(sz, p), h.alloc(sz, b)
+    launched = 0
+    try:
+        assert h.lib.czhip_set_rb4(2, 0, 0) == 0
+        res = {}
+        for unit in (1, 0):
+            h.lib.czhip_set_unit_coef(unit)
+            dw = h.alloc(sz, p)
+            ok, r1, r2 = h.jacobi2(du, dw, db, sz, idx, cf, 0.9)
+            if ok:
+                launched += 1
+                assert _beq(dw.get(), aj), unit
+                res[("j", unit)] = (r1, r2)
+            dw.free()
+            dw = h.alloc(sz, p)
+            ok, r1, r2 = h.rbsor4(du, dw, db, sz, idx, cf, 0, 1.3)
+            if ok:
+                launched += 1
+                assert _beq(dw.get(), ar), unit
+                res[("r", unit)] = (r1, r2)
+            dw.free()
+        for k in ("j", "r"):
+            if (k, 1) in res:
+                assert res[(k, 1)] == res[(k, 0)], k  # same values summed in the same order
+        # one coefficient a single ULP above 1: the general form, and the oracle's result with THAT coefficient
+        h.lib.czhip_set_unit_coef(1)
+        cf2 = cf.copy()
+        cf2[4] = np.nextafter(R(1), R(2))
+        a2, w2 = p.copy(), np.zeros_like(p)
+        for _ in range(2):
+            ko.jacobi(a2, sz, idx, cf2, 0.9, b, w2, wide=np.zeros(1))
+        dw = h.alloc(sz, p)
+        ok, _, _ = h.jacobi2(du, dw, db, sz, idx, cf2, 0.9)
+        if ok:
+            assert _beq(dw.get(), a2)
+        dw.free()
+    finally:
+        h.lib.czhip_set_unit_coef(1)
+        h.lib.czhip_set_rb4(1, 0, 0)
+    if nk + 4 >= 64:
+        assert launched > 0
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("box", [(40, 36, 60), (33, 50, 123), (29, 31, 253), (70, 20, 126)], ids=lambda b: "x".join(map(str, b)))
 @pytest.mark.parametrize("rb", [-1, 0, 1], ids=["jacobi_pair", "rb_ofst0", "rb_ofst1"])
 def test_first_pass_of_a_preconditioner_solve_from_a_literal_zero(prec, box, rb, kwin):

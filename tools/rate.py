@@ -39,6 +39,8 @@ for spec in sys.argv[1:]:
             cz.lib.czhip_set_pair_preload(int(env["CZHIP_T2_PRE"]))
         if "CZHIP_T2_KWIN" in env:
             cz.lib.czhip_set_pair_window(int(env["CZHIP_T2_KWIN"]))
+        if "CZHIP_UNIT_COEF" in env:
+            cz.lib.czhip_set_unit_coef(int(env["CZHIP_UNIT_COEF"]))
         pts = (gsz[0] - 2) * (gsz[1] - 2) * (gsz[2] - 2)
         if solver.startswith("pbicgstab"):
             assert cz.setup(gsz + [solver, 3, COEF.get(pc, 0.8), pc or "jacobi"]) == 1
@@ -89,6 +91,7 @@ for spec in sys.argv[1:]:
             cz.lib.czhip_set_tuning2(-2, 2, 0, 1)
         cz.lib.czhip_set_pair_preload(1)
         cz.lib.czhip_set_pair_window(-1)
+        cz.lib.czhip_set_unit_coef(1)
         cz.lib.czhip_set_psor(1, 0)
         cz.lib.czhip_set_psor_ahead(0)
         cz.close()

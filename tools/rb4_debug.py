@@ -17,7 +17,7 @@ for it in range(2):
     for color in (0, 1):
         ko.psor2sma_core(a1, sz, idx, cf, 0, color, 1.3, b)
 du, db, dw = h.alloc(sz, p), h.alloc(sz, b), h.alloc(sz, p)
-h.lib.czhip_set_rb4(1, kw, tj)
+h.lib.czhip_set_rb4(2, kw, tj)
 ok, r1, r2 = h.rbsor4(du, dw, db, sz, idx, cf, 0, 1.3)
 w = dw.get()
 bad = np.argwhere(w != a1)
