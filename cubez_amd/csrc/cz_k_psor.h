@@ -131,7 +131,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
     unsigned long long* faceI = faces + (size_t)(2 * col) * g.face_words;       // this column's high-i face, for column (a+1, b)
     unsigned long long* faceJ = faces + (size_t)(2 * col + 1) * g.face_words;   // high-j face, for column (a, b+1)
     double acc = 0.0;
-    if (prof && has_col && (t & 255) == 0 && wv < NCW) prof[4 * col] = (long long)wall_clock64(), prof[4 * col + 2] = blockIdx.x;
+    if (prof && has_col && (t & 255) == 0 && wv < NCW) prof[4 * col] = (long long)wall_clock64(), prof[4 * col + 2] = blockIdx.x, prof[4 * col + 3] = -(long long)__builtin_readcyclecounter();
 
     if (wv < NCW) {
       // ================================================================ compute waves
@@ -189,7 +189,11 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
 #pragma unroll
       for (int q = 0; q < NG; q++) {
         pc_load<G>(line + (G * q - i - j), &pbuf[G * q]);
+#if defined(PSOR_LAB_NO_B)  // tools/psor_lab only: the right-hand side is not streamed (what a third less read traffic is worth; the results differ)
+        for (int u = 0; u < G; u++) bbuf[G * q + u] = (REAL)0.25;
+#else
         pc_load<G>(bline + (G * q - i - j), &bbuf[G * q]);
+#endif
       }
       REAL prev_new = line[-1];  // new value of k - 1 of the first point: the low boundary
       // (consumed here, once: a loop-carried register that starts life as a load makes the compiler wait for ALL loads in flight -- the
@@ -243,7 +247,9 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
           }
           // ---- this group's slot of the rings is free: ask for the runs NG groups ahead
           pc_load<G>(line + kb + NS, &pbuf[G * q]);
+#if !defined(PSOR_LAB_NO_B)
           pc_load<G>(bline + kb + NS, &bbuf[G * q]);
+#endif
         }
         // ---- the lines completed in this loop body (NS steps <= EL: at most one per thread, two entries of the ring are never in doubt)
         flush_lines(G * (sg + NG) - 1 - i - j, false);
@@ -257,7 +263,13 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       // lanes 16..31 face J (i = lane - 16).
       const int fc = lane & 15;                       // coordinate inside the face
       const bool toI = (lane & 16) == 0;
+#if defined(PSOR_LAB_FORCE_FEED)  // tools/psor_lab only: every column stores both faces (what the stores cost a column that nobody follows)
+      const bool feeds = has_col && (NC > 1 || lane < 32);
+#elif defined(PSOR_LAB_NO_FEED)   // tools/psor_lab only: nobody stores (timing of a column's own steps; the sweep is wrong and gives up)
+      const bool feeds = false;
+#else
       const bool feeds = has_col && (NC > 1 || lane < 32) && (toI ? (a + 1 < g.nti && J0 + fc <= g.jj1) : (b + 1 < g.ntj && I0 + fc <= g.ii1));
+#endif
       const int src = toI ? (PC_T + PC_L * (fc + 1)) : ((fc + 1) + PC_L * PC_T);  // LDS place of thread (15, fc) / (fc, 15)
       unsigned long long* face = toI ? faceI : faceJ;
       lds_barrier();  // (step -1)
@@ -377,7 +389,7 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       }
     }
     __syncthreads();
-    if (prof && has_col && (t & 255) == 0 && wv < NCW) prof[4 * col + 1] = (long long)wall_clock64();
+    if (prof && has_col && (t & 255) == 0 && wv < NCW) prof[4 * col + 1] = (long long)wall_clock64(), prof[4 * col + 3] += (long long)__builtin_readcyclecounter();  // (shader-clock cycles of the column)
     // one partial sum per column (in the order of the columns whatever NC is: the same bits)
 #pragma unroll
     for (int n = 0; n < NC; n++) {

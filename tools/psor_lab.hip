@@ -185,7 +185,10 @@ int main(int argc, char** argv) {
         smin = std::min(smin, st), smax = std::max(smax, st), dur += en - st, cntc++;
         if (a > 0) lag += st - (h[4 * (cc - 1)] - t0) * 0.01, nl++;
       }
-      printf("  %3d: %3d | %8.1f .. %8.1f | %7.1f -> %.3f | %6.1f\n", d, cntc, smin, smax, dur / cntc, dur / cntc / nsteps, nl ? lag / nl : 0.0);
+      double cyc = 0;
+      for (int a = std::max(0, d - (q.ntj - 1)); a <= std::min(q.nti - 1, d); a++) cyc += (double)h[4 * (a + q.nti * (d - a)) + 3];
+      printf("  %3d: %3d | %8.1f .. %8.1f | %7.1f -> %.3f | %6.1f | %.0f cycles per step = %.0f MHz\n", d, cntc, smin, smax, dur / cntc, dur / cntc / nsteps, nl ? lag / nl : 0.0,
+             cyc / cntc / nsteps, cyc / dur);
     }
   }
   unsigned long long* cnt;
