@@ -39,6 +39,9 @@ for spec in sys.argv[1:]:
             cz.lib.czhip_set_pair_preload(int(env["CZHIP_T2_PRE"]))
         if "CZHIP_T2_KWIN" in env:
             cz.lib.czhip_set_pair_window(int(env["CZHIP_T2_KWIN"]))
+        if "CZHIP_RB4" in env:
+            a = [int(v) for v in env["CZHIP_RB4"].split(",")] + [0, 0]
+            cz.lib.czhip_set_rb4(a[0], a[1], a[2])
         if "CZHIP_UNIT_COEF" in env:
             cz.lib.czhip_set_unit_coef(int(env["CZHIP_UNIT_COEF"]))
         pts = (gsz[0] - 2) * (gsz[1] - 2) * (gsz[2] - 2)
@@ -92,6 +95,7 @@ for spec in sys.argv[1:]:
         cz.lib.czhip_set_pair_preload(1)
         cz.lib.czhip_set_pair_window(-1)
         cz.lib.czhip_set_unit_coef(1)
+        cz.lib.czhip_set_rb4(1, 0, 0)
         cz.lib.czhip_set_psor(1, 0)
         cz.lib.czhip_set_psor_ahead(0)
         cz.close()
