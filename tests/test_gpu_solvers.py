@@ -99,6 +99,35 @@ def test_solvers_on_rows_that_are_no_multiple_of_the_vector_width(case):
         assert np.allclose(g["hist"], oh, rtol=1e-11, atol=0)
 
 
+def _random_shapes(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        g = (int(rng.integers(12, 71)), int(rng.integers(12, 61)), int(rng.integers(20, 261)))
+        out.append((g, int(rng.integers(5, 15))))
+    return out
+
+
+RANDOM_SHAPES = [dict(gsz=g, solver=sv, itr_max=it, coef=cf, precond=None, prec=pr, tag=f"{sv}_{'x'.join(map(str, g))}_{it}_{pr}")
+                 for (g, it) in _random_shapes(10, 20261005)
+                 for (sv, cf) in (("jacobi", 0.8), ("sor2sma", 1.5))
+                 for pr in ("f32", "f64")]
+
+
+@pytest.mark.parametrize("case", RANDOM_SHAPES, ids=[c["tag"] for c in RANDOM_SHAPES])
+def test_stationary_solvers_on_seeded_random_shapes_vs_oracle(case):
+    """Ten box shapes drawn once (seed in the file) -- extents that are multiples of nothing, k from 20 to 260 cells, odd and even iteration
+    counts -- through CZ::JACOBI and CZ::RBSOR in their default forms (the unit-coefficient pair; two red-black iterations per pass, its last pass
+    a single iteration where the count is odd) against the oracle: iteration count, field bit for bit, history."""
+    g = _run_gpu(case)
+    o = O.run(case["gsz"], case["solver"], case["itr_max"], case["coef"], case["precond"], kind="oracle", prec=case["prec"], wide=True)
+    assert g["itr"] == o.itr
+    assert g["P"].tobytes() == o.P.tobytes()
+    oh = [r for _, r in o.history]
+    assert len(oh) == len(g["hist"])
+    assert np.allclose(g["hist"], oh, rtol=1e-11, atol=0)
+
+
 LONG_ROWS = [dict(gsz=g, solver=sv, itr_max=12, coef=cf, precond=pc, prec=pr, tag=f"{sv}_{pc or ''}_{'x'.join(map(str, g))}_{pr}")
              for (g, pr) in (((20, 16, 1100), "f64"), ((16, 20, 2100), "f32"), ((12, 14, 4100), "f32"))
              for (sv, cf, pc) in (("jacobi", 0.8, None), ("sor2sma", 1.5, None), ("jacobi_maf", 0.8, None), ("pbicgstab", 0.8, "jacobi"))]
