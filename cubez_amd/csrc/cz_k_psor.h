@@ -149,6 +149,9 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       int next_line = 0;  // lines of this thread's row stored so far (line n holds the positions n EL .. n EL + EL - 1)
       // store every complete line that has not been stored yet; `kdone`: the last k this thread has produced (all = the row is finished)
       auto flush_lines = [&](int kdone, bool all) __attribute__((always_inline)) {
+#if defined(PSOR_LAB_NO_STORE)  // tools/psor_lab only, TIMING only: nothing is stored (what the stores cost)
+        return;
+#endif
         if (!col_in) return;
         const int kd = min(kdone, g.nk - 1);
         while (kd >= 0 && (next_line + 1) * EL - 1 <= phi + kd + ((all && kd == g.nk - 1) ? EL : 0) && next_line * EL <= phi + g.nk - 1) {
@@ -186,6 +189,9 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
       // unconditional: elements before k = -1 or behind k = nk belong to the neighbouring rows of the padded array (the launcher makes sure
       // they exist) and are never used; k = -1 and k = nk ARE the boundary values the first / last point needs.
       REAL pbuf[NS], bbuf[NS];
+#if defined(PSOR_LAB_WHOLE_LINES)
+      RunVec wl[2 * (EL / kRunW)] = {};
+#endif
 #pragma unroll
       for (int q = 0; q < NG; q++) {
         pc_load<G>(line + (G * q - i - j), &pbuf[G * q]);
@@ -246,11 +252,28 @@ psor_col_k(REAL* __restrict__ P, const REAL* __restrict__ B, Coef c, PsorColGeom
             lds_barrier();
           }
           // ---- this group's slot of the rings is free: ask for the runs NG groups ahead
+#if !defined(PSOR_LAB_WHOLE_LINES)
           pc_load<G>(line + kb + NS, &pbuf[G * q]);
 #if !defined(PSOR_LAB_NO_B)
           pc_load<G>(bline + kb + NS, &bbuf[G * q]);
 #endif
+#endif
         }
+#if defined(PSOR_LAB_WHOLE_LINES)  // tools/psor_lab only, TIMING only (the values are not used, the results are wrong): what the memory system makes of
+        // one ALIGNED whole 128-byte line of p and of b per thread and loop body, requested in one burst, instead of four unaligned 32-byte runs
+        {
+#pragma unroll
+          for (int v = 0; v < 2 * (EL / kRunW); v++) asm volatile("" ::"v"(wl[v]));  // (the burst of the body before has to be there by now)
+          const size_t ea = (reinterpret_cast<size_t>(line + (G * (sg + NG) - i - j) + NS)) & ~(size_t)127;
+          const size_t eb = (reinterpret_cast<size_t>(bline + (G * (sg + NG) - i - j) + NS)) & ~(size_t)127;
+#pragma unroll
+          for (int v = 0; v < EL / kRunW; v++) {
+            wl[v] = *reinterpret_cast<const RunVec*>(ea + (size_t)v * sizeof(RunVec));
+            wl[EL / kRunW + v] = *reinterpret_cast<const RunVec*>(eb + (size_t)v * sizeof(RunVec));
+          }
+        }
+#endif
+
         // ---- the lines completed in this loop body (NS steps <= EL: at most one per thread, two entries of the ring are never in doubt)
         flush_lines(G * (sg + NG) - 1 - i - j, false);
         if (sh[2] != 0) break;  // a wait was given up (published by the taking wave before the LAST barrier of this body, see there)
