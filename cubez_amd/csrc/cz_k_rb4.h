@@ -143,27 +143,36 @@ rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__
     Vec<V> bq1 = zerov<V>(), bq2 = zerov<V>(), bq3 = zerov<V>();  // b of the planes of stages 2, 3, 4
     __syncthreads();
 
-    // (a wave that lies wholly outside the set of a stage -- E2 for stage 2, E1 for stage 3 -- skips it: nothing valid reads its result)
-    const bool in2 = __builtin_amdgcn_ballot_w64(x >= R && x < LV - R) != 0ull, in3 = __builtin_amdgcn_ballot_w64(x >= 2 * R && x < LV - 2 * R) != 0ull;
     // the k neighbours beyond the wave's first and last vector come from LDS (one element each, the same address in all lanes)
     const int x_first = __builtin_amdgcn_readfirstlane(x), x_last = __builtin_amdgcn_readlane(x, 63);
-    // one stage: the field `fin_` (centre plane p in LDS buffer `cur`, own vector of plane p-1 in `prv`, plane p+1 in `nxt`) -> the stage's result
-    auto stage = [&](const Vec<V>* cur, const Vec<V>* prv, int x, const Vec<V>& nxt, const Vec<V>& bb, int p, int colour, unsigned msk, unsigned cnt,
-                     double& acc, const bool first = false) __attribute__((always_inline)) -> Vec<V> {
-      const Vec<V> pc = lds_ld<V>(cur + x);
-      const Vec<V> im = lds_ld<V>(cur + x - R);
-      const Vec<V> ip = lds_ld<V>(cur + x + R);
+    // One stage in two halves, so that the operands of the NEXT stage are requested from LDS before this stage's arithmetic starts (the stages of
+    // a step depend on each other only through one register vector): `fetch` reads the field (centre plane p in LDS buffer `cur`, own vector of
+    // plane p-1 in `prv`), `compute` makes the stage's result from them and plane p+1 (`nxt`).  A plane outside the inner box is left alone by an
+    // empty mask (the result is then the centre value), not by a branch around the stage.
+    struct Ops {
+      Vec<V> pc, im, ip;  // (the own vector of plane p-1 is read by `compute`: 128 registers are all a thread of 1 024 has)
+      REAL elo, ehi;
+    };
+    auto fetch = [&](const Vec<V>* cur) __attribute__((always_inline)) -> Ops {
+      Ops o;
+      o.pc = lds_ld<V>(cur + x);
+      o.im = lds_ld<V>(cur + x - R);
+      o.ip = lds_ld<V>(cur + x + R);
+      o.elo = reinterpret_cast<const REAL*>(cur)[(long long)x_first * V - 1];
+      o.ehi = reinterpret_cast<const REAL*>(cur)[(long long)(x_last + 1) * V];
+      return o;
+    };
+    auto compute = [&](const Ops& o, const Vec<V>* cur, const Vec<V>* prv, const Vec<V>& nxt, const Vec<V>& bb, int p, int colour, unsigned msk, unsigned cnt, double& acc,
+                       const bool first = false) __attribute__((always_inline)) -> Vec<V> {
       const Vec<V> pm = lds_ld<V>(prv + x);
-      const REAL elo = reinterpret_cast<const REAL*>(cur)[(long long)x_first * V - 1];
-      const REAL ehi = reinterpret_cast<const REAL*>(cur)[(long long)(x_last + 1) * V];
-      const REAL kl = lane_shr1(elo, pc.v[V - 1]);
-      REAL kr = lane_shl1(ehi, pc.v[0]);
+      const REAL kl = lane_shr1(o.elo, o.pc.v[V - 1]);
+      REAL kr = lane_shl1(o.ehi, o.pc.v[0]);
       // The last vector of E3 is not the last lane of a wave (rows are dealt by parity), and stage 1 needs its true neighbour -- the first
       // vector of E4's upper row: the corner of the dependence cone of the last owned vector runs through it.  (E3's first vector is thread 0,
       // lane 0: `elo`.  In the later stages both ends lie outside the stage's set.)
       if (first) kr = (x == LV - 1) ? reinterpret_cast<const REAL*>(cur)[(long long)LV * V] : kr;
       const bool sc = ((pbase + p + colour) & 1) != 0;
-      return relax_vec_rb_branch<V>(pc, im, ip, pm, nxt, kl, kr, bb, sc, msk, cnt, acc,
+      return relax_vec_rb_branch<V>(o.pc, o.im, o.ip, pm, nxt, kl, kr, bb, sc, msk, cnt, acc,
                              [&](REAL pp, REAL ipv, REAL imv, REAL pnv, REAL pmv, REAL kp1, REAL km1, REAL bv, REAL, REAL) {
                                const REAL ss = offdiag_sum<UNIT>(c, ipv, imv, pnv, pmv, kp1, km1);
                                return (dv(ss - bv) - pp) * c.omg;
@@ -178,29 +187,29 @@ rb4_k(const REAL* __restrict__ U, const REAL* __restrict__ B, REAL* __restrict__
         un = ld16<V>(Ub + (size_t)qu * PB, lim(bo, qu));
         bn = ld16<V>(Bb + (size_t)qb * PB, lim(bo, qb));
       }
-      // planes of the four stages and whether they lie in the inner box (outside it a stage leaves the plane alone)
+      // planes of the four stages; masks: inside the inner box a stage updates, inside the chunk the owner counts the residual
       const int p1 = q, p2 = q - 1, p3 = q - 2, p4 = q - 3;
+      auto upd = [&](int p) -> unsigned { return (p >= g.jj0 && p <= g.jj1) ? inbox : 0u; };
+      auto cnt = [&](int p) -> unsigned { return (p >= ja && p <= jb) ? own : 0u; };
       const Vec<V>* cU = ldsU + (size_t)(p1 & 1) * LU + R;  // u(p1) in E3 coordinates (index x)
       const Vec<V>* pU = ldsU + (size_t)((p1 - 1) & 1) * LU + R;
       Vec<V>* F1 = ldsF;
       Vec<V>* F2 = ldsF + (size_t)2 * LV;
       Vec<V>* F3 = ldsF + (size_t)4 * LV;
+      const Ops o1 = fetch(cU);
+      const Ops o2 = fetch(F1 + (size_t)(p2 & 1) * LV);
       // ---- stage 1: f1(p1), colour 0, every vector of E3
-      Vec<V> v1;
-      if (p1 >= g.jj0 && p1 <= g.jj1) v1 = stage(cU, pU, x, uc, b1, p1, 0, inbox, (p1 >= ja && p1 <= jb) ? own : 0u, acc1, true);
-      else v1 = lds_ld<V>(cU + x);
+      const Vec<V> v1 = compute(o1, cU, pU, uc, b1, p1, 0, upd(p1), cnt(p1), acc1, true);
+      const Ops o3 = fetch(F2 + (size_t)(p3 & 1) * LV);
       // ---- stage 2: f2(p2), colour 1, from f1(p2 - 1) [LDS], f1(p2) [LDS], f1(p1) [v1]
-      Vec<V> v2;
-      if (in2 && p2 >= g.jj0 && p2 <= g.jj1) v2 = stage(F1 + (size_t)(p2 & 1) * LV, F1 + (size_t)((p2 - 1) & 1) * LV, x, v1, bq1, p2, 1, inbox, (p2 >= ja && p2 <= jb) ? own : 0u, acc1);
-      else v2 = lds_ld<V>(F1 + (size_t)(p2 & 1) * LV + x);
+      const Vec<V> v2 = compute(o2, nullptr, F1 + (size_t)((p2 - 1) & 1) * LV, v1, bq1, p2, 1, upd(p2), cnt(p2), acc1);
+      const Ops o4 = fetch(F3 + (size_t)(p4 & 1) * LV);
       // ---- stage 3: f3(p3), colour 0
-      Vec<V> v3;
-      if (in3 && p3 >= g.jj0 && p3 <= g.jj1) v3 = stage(F2 + (size_t)(p3 & 1) * LV, F2 + (size_t)((p3 - 1) & 1) * LV, x, v2, bq2, p3, 0, inbox, (p3 >= ja && p3 <= jb) ? own : 0u, acc2);
-      else v3 = lds_ld<V>(F2 + (size_t)(p3 & 1) * LV + x);
+      const Vec<V> v3 = compute(o3, nullptr, F2 + (size_t)((p3 - 1) & 1) * LV, v2, bq2, p3, 0, upd(p3), cnt(p3), acc2);
       // ---- stage 4: f4(p4) = the output, colour 1, owned vectors of the chunk's planes.  Whole waves: the k neighbours travel by lane
       // shifts, and the lane next to the first owned vector of a window holds a halo vector -- it owns nothing but must take part.
       if (p4 >= ja && __builtin_amdgcn_ballot_w64(own != 0) != 0ull) {
-        const Vec<V> o = stage(F3 + (size_t)(p4 & 1) * LV, F3 + (size_t)((p4 - 1) & 1) * LV, x, v3, bq3, p4, 1, own, own, acc2);
+        const Vec<V> o = compute(o4, nullptr, F3 + (size_t)((p4 - 1) & 1) * LV, v3, bq3, p4, 1, own, own, acc2);
         char* Wq = Wb + (size_t)p4 * PB;
         if (own == (1u << V) - 1) {
           st16<V>(Wq, bo, o);
