@@ -379,7 +379,7 @@ def roofline_of(m):
         fused_min = pts * word * 3
         kernel_name, tkey = "rb4_k (two red-black iterations = four colour sweeps per launch)", f"rbsor4_{n}_{m['prec']}"
         model = ("16 B/LUP per iteration: two colour passes of 8 B/LUP; TWO iterations in ONE pass over memory (12 B per point really moved per launch), so `achieved` "
-                 "counts 2 x 16 B/LUP per launch and can exceed the peak -- `frac_hbm_traffic` is the physical fraction; neither pipe is saturated: vector ALU 74 % busy "
+                 "counts 2 x 16 B/LUP per launch and can exceed the peak -- `frac_hbm_traffic` is the physical fraction; neither pipe is saturated: vector ALU 77 % busy "
                  "(profiles/r04/pmc_rb4_512_f32_SQ.txt), 3.9 TB/s of counter traffic; one workgroup per CU, a barrier per plane step")
     kern_avg_s = (kern_ms / nk) * 1e-3 if nk else float("nan")
     achieved = alg / kern_avg_s / 1e9 if nk else None
